@@ -1,0 +1,160 @@
+/*
+ * mrca_env.h -- C ABI of the MI355X-native multi-robot collision-avoidance environment.
+ *
+ * This is the drop-in boundary for ONE path of Acmece/rl-collision-avoidance: the per-robot
+ * ROS/Stage simulation behind the `StageWorld` class.  The reference has no C plugin API for
+ * this path; what a caller binds to is (a) the StageWorld method set and (b) the stageros topic
+ * contract underneath it.  Every entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream);
+ *   - every pointer suffixed _dev is DEVICE memory on the env's GPU, everything else is host;
+ *   - all calls are asynchronous on `stream`, there is no hidden synchronisation;
+ *   - return value: 0 (MRCA_OK) or a negative mrca_status; mrca_last_error() gives the text
+ *     for the calling thread;
+ *   - one env per GPU, not thread-safe per handle;
+ *   - the env owns one contiguous device arena (either caller-provided or hipMalloc'ed) laid out
+ *     structure-of-arrays, every field 256-byte aligned; mrca_get_field() exposes the fields
+ *     zero-copy.
+ *
+ * Robot numbering: robot n lives in world n / robots_per_world with local index
+ * n % robots_per_world (the reference's `index` = MPI rank, ppo_stage1.py:168).  Robots only
+ * interact (collide, see each other's bodies with the lidar) inside their world.
+ */
+#ifndef MRCA_ENV_H
+#define MRCA_ENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRCA_ABI_VERSION 1
+
+typedef struct mrca_env mrca_env; /* opaque */
+
+enum mrca_status {
+    MRCA_OK = 0,
+    MRCA_ERR_INVALID = -1,     /* bad argument / config */
+    MRCA_ERR_HIP = -2,         /* a HIP runtime call failed */
+    MRCA_ERR_NOMEM = -3,       /* arena too small / allocation failed */
+    MRCA_ERR_UNSUPPORTED = -4  /* e.g. robots_per_world > 64 */
+};
+
+/* episode structure */
+enum mrca_auto_reset {
+    MRCA_AUTO_NONE = 0,  /* circle_test.py:36-83 : nothing resets, first terminal event latched  */
+    MRCA_AUTO_ROBOT = 1, /* ppo_stage1.py:51-58  : each robot starts a new episode when done     */
+    MRCA_AUTO_GROUP = 2  /* ppo_stage2.py:72-107 : done robots idle until their whole group done */
+};
+
+/* per-local-index rule for reset_pose / generate_goal_point */
+enum mrca_reset_mode {
+    MRCA_RESET_TABLE = 0, /* model/utils.py:6-63 tables (stage_world2.py:213-214, circle_world.py:205) */
+    MRCA_RESET_DISC = 1,  /* stage_world1.py:251-274                                                  */
+    MRCA_RESET_REGION = 2 /* stage_world2.py:250-287 (robots 34..43)                                   */
+};
+
+/* get_reward_and_terminate's third return value (stage_world1.py:194,201,208) */
+enum mrca_result { MRCA_RESULT_NONE = 0, MRCA_RESULT_REACH = 1, MRCA_RESULT_CRASH = 2, MRCA_RESULT_TIMEOUT = 3 };
+
+/* device-resident fields; shapes in [] with N = num_worlds*robots_per_world, B = beams, F = frames */
+enum mrca_field {
+    MRCA_F_POSE = 0,      /* f32 [N,3]   get_self_stateGT   stage_world1.py:116 ; base_pose_ground_truth stageros.cpp:575 */
+    MRCA_F_SPEED,         /* f32 [N,2]   get_self_speed     stage_world1.py:143 ; odom twist stageros.cpp:543-558        */
+    MRCA_F_SPEED_GT,      /* f32 [N,2]   get_self_speedGT   stage_world1.py:119 ; stageros.cpp:585-590                   */
+    MRCA_F_GOAL,          /* f32 [N,2]   env.goal_point     stage_world1.py:173                                          */
+    MRCA_F_INIT_POSE,     /* f32 [N,3]   env.init_pose      stage_world1.py:263                                          */
+    MRCA_F_SCAN,          /* f32 [N,B]   base_scan ranges   stageros.cpp:479-516                                         */
+    MRCA_F_OBS,           /* f32 [N,F,B] get_laser_observation x frame deque  stage_world1.py:122-140, ppo_stage1.py:59-60,87-89 */
+    MRCA_F_LOCAL_GOAL,    /* f32 [N,2]   get_local_goal     stage_world1.py:155-160                                      */
+    MRCA_F_REWARD,        /* f32 [N]     get_reward_and_terminate[0]  stage_world1.py:180-211                            */
+    MRCA_F_DONE,          /* u8  [N]     get_reward_and_terminate[1]                                                     */
+    MRCA_F_RESULT,        /* u8  [N]     get_reward_and_terminate[2] as enum mrca_result                                 */
+    MRCA_F_FIRST_RESULT,  /* u8  [N]     first terminal event since reset (success-rate metric)               */
+    MRCA_F_CRASHED,       /* u8  [N]     get_crash_state    stage_world1.py:149 ; is_crashed stageros.cpp:562-564        */
+    MRCA_F_LIVE,          /* u8  [N]     `liveflag`         ppo_stage2.py:52,85-86                                       */
+    MRCA_F_FRESH,         /* u8  [N]     1 where the last call started a new episode for the robot                      */
+    MRCA_F_T,             /* i32 [N]     the `step` argument of get_reward_and_terminate (ppo_stage1.py:57,118)          */
+    MRCA_F_EPISODE,       /* i32 [N]     episode counter (RNG stream position)                                          */
+    MRCA_F_PREV_DIST,     /* f32 [N]     self.distance      stage_world1.py:176-177,185-186                              */
+    MRCA_F_COUNT
+};
+
+typedef struct mrca_config {
+    int32_t abi_version;       /* MRCA_ABI_VERSION */
+    int32_t device;            /* HIP device ordinal */
+    int32_t num_worlds;
+    int32_t robots_per_world;  /* 1..64 */
+    int32_t beams;             /* 512 (stage1.world:14); 64..1024, multiple of 64 */
+    int32_t frames;            /* 3 (LASER_HIST, ppo_stage1.py:24); 1..8 */
+    /* occupancy grid shared by all worlds; cells outside it are free */
+    int32_t map_width, map_height, map_words_per_row;
+    float map_cell, map_x0, map_y0; /* cell edge [m]; world coords of the lower-left corner */
+    const uint32_t* map_bits;       /* host, [map_height][map_words_per_row], bit b of word w = column 32w+b */
+    /* reward / episode rules (stage_world1.py:180-211 and the stage2 / circle variants) */
+    int32_t timeout;        /* 150 / 200 / 10000 */
+    float w_thresh;         /* 1.05 / 1.05 / 0.7 */
+    int32_t pre_dist_zero;  /* stage_world2.py:170-171, circle_world.py:166-167 quirk */
+    int32_t auto_reset;     /* enum mrca_auto_reset */
+    uint64_t seed;          /* Philox key */
+    /* per local index (robots_per_world entries each); NULL = all MRCA_RESET_DISC / zeros */
+    const int32_t* reset_mode;
+    const int32_t* goal_mode;
+    const float* init_table;  /* [R,3] */
+    const float* goal_table;  /* [R,2] */
+    const int32_t* group_id;  /* [R] in 0..15, model/utils.py:83 */
+} mrca_config;
+
+/* Bytes of device arena an env with this config needs (256-byte granules). */
+int mrca_arena_bytes(const mrca_config* cfg, size_t* bytes_out);
+
+/* Replaces: StageWorld.__init__ (stage_world1.py:17-84) + the stageros process it talks to
+ * (stageros.cpp:311-437).  arena_dev may be NULL (the library allocates) or caller-owned device
+ * memory of at least mrca_arena_bytes() (e.g. a torch tensor's data_ptr). */
+int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrca_env** env_out);
+int mrca_destroy(mrca_env* env);
+
+/* Replaces: reset_world / reset_pose / control_pose / generate_goal_point
+ * (stage_world1.py:162-177,213-223,237-249; stageros.cpp:260-296).
+ *   mask_dev  u8[N] or NULL (= all robots): which robots begin a new episode
+ *   poses_dev f32[N,3] or NULL: teleport targets (control_pose); NULL = sample per reset_mode
+ *   goals_dev f32[N,2] or NULL: goal points; NULL = sample per goal_mode
+ * Re-casts the lidar for the masked robots and fills all F frames with the fresh scan. */
+int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, const float* goals_dev, void* stream);
+
+/* Replaces one trip round the loop body of ppo_stage1.py:75-91:
+ *   control_vel (cmd_vel -> SetSpeed, stageros.cpp:272-280) for every robot,
+ *   one Stage tick (UpdateWorld, stageros.cpp:445-449),
+ *   get_reward_and_terminate(step), get_laser_observation, get_local_goal, get_self_speed.
+ * actions_dev f32[N,2] = (v, omega) already clipped by the caller (ppo_stage1.py:170, model/ppo.py:75). */
+int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
+
+/* Zero-copy access to a field: device pointer, byte offset inside the arena and byte size. */
+int mrca_get_field(mrca_env* env, int field, void** ptr_dev_out, size_t* offset_out, size_t* bytes_out);
+
+/* Replaces: generate_train_data (model/ppo.py:122-139) -- reverse GAE scan, one thread per robot.
+ *   rewards_dev f32[T,N], values_dev f32[T,N], last_value_dev f32[N], dones_dev u8[T,N]
+ *   targets_dev f32[T,N], advs_dev f32[T,N] */
+int mrca_gae(const float* rewards_dev, const float* values_dev, const float* last_value_dev,
+             const uint8_t* dones_dev, float gamma, float lam, int32_t T, int32_t N,
+             float* targets_dev, float* advs_dev, void* stream);
+
+/* Diagnostics */
+int mrca_abi_version(void);
+const char* mrca_last_error(void);
+/* Per-kernel timing with HIP events recorded on the stream each mrca_step launches on
+ * (event, move kernel, event, ray-cast kernel, event), up to 1024 steps between reads.
+ * mrca_read_timing synchronises on the last recorded event, returns the summed durations of the
+ * recorded launches in milliseconds and clears the ring. */
+int mrca_enable_timing(mrca_env* env, int32_t on);
+int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRCA_ENV_H */

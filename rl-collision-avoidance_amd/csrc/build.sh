@@ -1,0 +1,14 @@
+#!/usr/bin/env bash
+# Build libmrca_env.so for gfx950 in-tree (cross-compiles without a GPU).
+#   -ffp-contract=off + correctly rounded div/sqrt: the tick is specified as separately rounded
+#   IEEE fp32 operations so a launch can be compared bit-for-bit with the oracle's fp32 mode.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${here}/../mrca/libmrca_env.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+    -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
+    -Wall -Wno-unused-function \
+    "${here}/mrca_kernels.hip" "${here}/mrca_abi.hip" \
+    -o "${out}" "$@"
+echo "built ${out}"

@@ -1,0 +1,386 @@
+// mrca_abi.hip -- host side of include/mrca_env.h: config validation, the SoA device arena,
+// table / map upload, kernel sequencing and optional HIP-event timing.  No torch, no Python.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/mrca_env.h"
+#include "mrca_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) return fail(MRCA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+struct Layout {
+    size_t field_off[MRCA_F_COUNT];
+    size_t field_bytes[MRCA_F_COUNT];
+    size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
+    size_t off_beam_cos, off_beam_sin, off_map;
+    size_t total;
+};
+
+int validate(const mrca_config* c) {
+    if (!c) return fail(MRCA_ERR_INVALID, "config is NULL");
+    if (c->abi_version != MRCA_ABI_VERSION)
+        return fail(MRCA_ERR_INVALID, "abi_version %d != %d", c->abi_version, MRCA_ABI_VERSION);
+    if (c->num_worlds < 1) return fail(MRCA_ERR_INVALID, "num_worlds must be >= 1");
+    if (c->robots_per_world < 1) return fail(MRCA_ERR_INVALID, "robots_per_world must be >= 1");
+    if (c->robots_per_world > 64)
+        return fail(MRCA_ERR_UNSUPPORTED, "robots_per_world %d > 64 (one wavefront per world)", c->robots_per_world);
+    if (c->beams < 64 || c->beams > 1024 || c->beams % 64)
+        return fail(MRCA_ERR_INVALID, "beams %d must be a multiple of 64 in [64,1024]", c->beams);
+    if (c->frames < 1 || c->frames > 8) return fail(MRCA_ERR_INVALID, "frames %d out of [1,8]", c->frames);
+    if (c->map_width < 1 || c->map_height < 1 || c->map_words_per_row < (c->map_width + 31) / 32)
+        return fail(MRCA_ERR_INVALID, "bad map geometry %dx%d wpr %d", c->map_width, c->map_height,
+                    c->map_words_per_row);
+    if (!(c->map_cell > 0.0f)) return fail(MRCA_ERR_INVALID, "map_cell must be > 0");
+    if (!c->map_bits) return fail(MRCA_ERR_INVALID, "map_bits is NULL");
+    if (c->auto_reset < 0 || c->auto_reset > 2) return fail(MRCA_ERR_INVALID, "auto_reset %d", c->auto_reset);
+    const int R = c->robots_per_world;
+    for (int i = 0; i < R; ++i) {
+        if (c->reset_mode && (c->reset_mode[i] < 0 || c->reset_mode[i] > 2))
+            return fail(MRCA_ERR_INVALID, "reset_mode[%d] = %d", i, c->reset_mode[i]);
+        if (c->goal_mode && (c->goal_mode[i] < 0 || c->goal_mode[i] > 2))
+            return fail(MRCA_ERR_INVALID, "goal_mode[%d] = %d", i, c->goal_mode[i]);
+        if (c->group_id && (c->group_id[i] < 0 || c->group_id[i] > 15))
+            return fail(MRCA_ERR_INVALID, "group_id[%d] = %d out of [0,15]", i, c->group_id[i]);
+        if (c->reset_mode && c->reset_mode[i] == MRCA_RESET_TABLE && !c->init_table)
+            return fail(MRCA_ERR_INVALID, "reset_mode[%d] is TABLE but init_table is NULL", i);
+        if (c->goal_mode && c->goal_mode[i] == MRCA_RESET_TABLE && !c->goal_table)
+            return fail(MRCA_ERR_INVALID, "goal_mode[%d] is TABLE but goal_table is NULL", i);
+    }
+    return MRCA_OK;
+}
+
+void make_layout(const mrca_config* c, Layout* L) {
+    const size_t N = (size_t)c->num_worlds * c->robots_per_world;
+    const size_t B = c->beams, F = c->frames, R = c->robots_per_world;
+    size_t sz[MRCA_F_COUNT];
+    sz[MRCA_F_POSE] = N * 3 * 4;
+    sz[MRCA_F_SPEED] = N * 2 * 4;
+    sz[MRCA_F_SPEED_GT] = N * 2 * 4;
+    sz[MRCA_F_GOAL] = N * 2 * 4;
+    sz[MRCA_F_INIT_POSE] = N * 3 * 4;
+    sz[MRCA_F_SCAN] = N * B * 4;
+    sz[MRCA_F_OBS] = N * F * B * 4;
+    sz[MRCA_F_LOCAL_GOAL] = N * 2 * 4;
+    sz[MRCA_F_REWARD] = N * 4;
+    sz[MRCA_F_DONE] = N;
+    sz[MRCA_F_RESULT] = N;
+    sz[MRCA_F_FIRST_RESULT] = N;
+    sz[MRCA_F_CRASHED] = N;
+    sz[MRCA_F_LIVE] = N;
+    sz[MRCA_F_FRESH] = N;
+    sz[MRCA_F_T] = N * 4;
+    sz[MRCA_F_EPISODE] = N * 4;
+    sz[MRCA_F_PREV_DIST] = N * 4;
+    size_t off = 0;
+    for (int f = 0; f < MRCA_F_COUNT; ++f) {
+        L->field_off[f] = off;
+        L->field_bytes[f] = sz[f];
+        off += align_up(sz[f]);
+    }
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes);
+        return o;
+    };
+    L->off_reset_mode = take(R * 4);
+    L->off_goal_mode = take(R * 4);
+    L->off_group_id = take(R * 4);
+    L->off_init_table = take(R * 3 * 4);
+    L->off_goal_table = take(R * 2 * 4);
+    L->off_beam_cos = take(B * 4);
+    L->off_beam_sin = take(B * 4);
+    L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
+    L->total = off;
+}
+
+constexpr int kTimingRing = 1024;
+
+}  // namespace
+
+struct mrca_env {
+    mrca_config cfg;
+    Layout layout;
+    char* arena = nullptr;
+    bool owns_arena = false;
+    mrca::EnvView view;
+    size_t lds_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // 3 per recorded step: before move, before ray, after ray
+    int ev_used = 0;
+};
+
+extern "C" {
+
+int mrca_abi_version(void) { return MRCA_ABI_VERSION; }
+
+const char* mrca_last_error(void) { return g_err; }
+
+int mrca_arena_bytes(const mrca_config* cfg, size_t* bytes_out) {
+    if (int rc = validate(cfg)) return rc;
+    if (!bytes_out) return fail(MRCA_ERR_INVALID, "bytes_out is NULL");
+    Layout L;
+    make_layout(cfg, &L);
+    *bytes_out = L.total;
+    return MRCA_OK;
+}
+
+int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrca_env** env_out) {
+    if (int rc = validate(cfg)) return rc;
+    if (!env_out) return fail(MRCA_ERR_INVALID, "env_out is NULL");
+    *env_out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(MRCA_ERR_INVALID, "device %d not in [0,%d)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    mrca_env* env = new (std::nothrow) mrca_env();
+    if (!env) return fail(MRCA_ERR_NOMEM, "host allocation failed");
+    env->cfg = *cfg;
+    make_layout(cfg, &env->layout);
+    const Layout& L = env->layout;
+    if (arena_dev) {
+        if (arena_bytes < L.total) {
+            delete env;
+            return fail(MRCA_ERR_NOMEM, "arena of %zu bytes < required %zu", arena_bytes, L.total);
+        }
+        if (reinterpret_cast<uintptr_t>(arena_dev) % kAlign) {
+            delete env;
+            return fail(MRCA_ERR_INVALID, "arena must be %zu-byte aligned", kAlign);
+        }
+        env->arena = static_cast<char*>(arena_dev);
+    } else {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&env->arena), L.total);
+        if (e != hipSuccess) {
+            delete env;
+            return fail(MRCA_ERR_NOMEM, "hipMalloc(%zu) failed: %s", L.total, hipGetErrorString(e));
+        }
+        env->owns_arena = true;
+    }
+    auto bail = [&](int rc) {
+        if (env->owns_arena) (void)hipFree(env->arena);
+        delete env;
+        return rc;
+    };
+#define HIP_TRY_BAIL(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return bail(fail(MRCA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)));       \
+    } while (0)
+
+    HIP_TRY_BAIL(hipMemset(env->arena, 0, L.total));
+
+    const int R = cfg->robots_per_world, B = cfg->beams;
+    const size_t N = (size_t)cfg->num_worlds * R;
+    // scenario tables
+    std::vector<int32_t> reset_mode(R, MRCA_RESET_DISC), goal_mode(R, MRCA_RESET_DISC), group(R, 0);
+    std::vector<float> init_tab(R * 3, 0.0f), goal_tab(R * 2, 0.0f);
+    if (cfg->reset_mode) memcpy(reset_mode.data(), cfg->reset_mode, R * 4);
+    if (cfg->goal_mode) memcpy(goal_mode.data(), cfg->goal_mode, R * 4);
+    else if (cfg->reset_mode) goal_mode = reset_mode;
+    if (cfg->group_id) memcpy(group.data(), cfg->group_id, R * 4);
+    if (cfg->init_table) memcpy(init_tab.data(), cfg->init_table, R * 3 * 4);
+    if (cfg->goal_table) memcpy(goal_tab.data(), cfg->goal_table, R * 2 * 4);
+    int num_groups = 0;
+    for (int i = 0; i < R; ++i) num_groups = group[i] + 1 > num_groups ? group[i] + 1 : num_groups;
+    // beam directions: bearing_i = -pi/2 + i*pi/(B-1) (stageros.cpp:495-497), evaluated in
+    // double, rounded once to fp32
+    std::vector<float> bcos(B), bsin(B);
+    for (int i = 0; i < B; ++i) {
+        const double b = -M_PI / 2.0 + (double)i * (M_PI / (double)(B - 1));
+        bcos[i] = (float)std::cos(b);
+        bsin[i] = (float)std::sin(b);
+    }
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_reset_mode, reset_mode.data(), R * 4, hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_goal_mode, goal_mode.data(), R * 4, hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_group_id, group.data(), R * 4, hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_init_table, init_tab.data(), R * 3 * 4, hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_goal_table, goal_tab.data(), R * 2 * 4, hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_cos, bcos.data(), B * 4, hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_sin, bsin.data(), B * 4, hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_map, cfg->map_bits,
+                           (size_t)cfg->map_height * cfg->map_words_per_row * 4, hipMemcpyHostToDevice));
+    // live = 1, t = 1 at construction (a robot exists and is idle before the first reset)
+    HIP_TRY_BAIL(hipMemset(env->arena + L.field_off[MRCA_F_LIVE], 1, N));
+    {
+        std::vector<int32_t> ones(N, 1);
+        HIP_TRY_BAIL(hipMemcpy(env->arena + L.field_off[MRCA_F_T], ones.data(), N * 4, hipMemcpyHostToDevice));
+    }
+    env->cfg.map_bits = nullptr;  // host pointers are not retained
+    env->cfg.reset_mode = env->cfg.goal_mode = env->cfg.group_id = nullptr;
+    env->cfg.init_table = env->cfg.goal_table = nullptr;
+
+    mrca::EnvView& v = env->view;
+    char* a = env->arena;
+    v.N = (int32_t)N;
+    v.R = R;
+    v.W = cfg->num_worlds;
+    v.B = B;
+    v.F = cfg->frames;
+    v.pose = reinterpret_cast<float*>(a + L.field_off[MRCA_F_POSE]);
+    v.speed = reinterpret_cast<float*>(a + L.field_off[MRCA_F_SPEED]);
+    v.speed_gt = reinterpret_cast<float*>(a + L.field_off[MRCA_F_SPEED_GT]);
+    v.goal = reinterpret_cast<float*>(a + L.field_off[MRCA_F_GOAL]);
+    v.init_pose = reinterpret_cast<float*>(a + L.field_off[MRCA_F_INIT_POSE]);
+    v.scan = reinterpret_cast<float*>(a + L.field_off[MRCA_F_SCAN]);
+    v.obs = reinterpret_cast<float*>(a + L.field_off[MRCA_F_OBS]);
+    v.local_goal = reinterpret_cast<float*>(a + L.field_off[MRCA_F_LOCAL_GOAL]);
+    v.reward = reinterpret_cast<float*>(a + L.field_off[MRCA_F_REWARD]);
+    v.prev_dist = reinterpret_cast<float*>(a + L.field_off[MRCA_F_PREV_DIST]);
+    v.done = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_DONE]);
+    v.result = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_RESULT]);
+    v.first_result = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_FIRST_RESULT]);
+    v.crashed = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_CRASHED]);
+    v.live = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_LIVE]);
+    v.fresh = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_FRESH]);
+    v.t = reinterpret_cast<int32_t*>(a + L.field_off[MRCA_F_T]);
+    v.episode = reinterpret_cast<int32_t*>(a + L.field_off[MRCA_F_EPISODE]);
+    v.reset_mode = reinterpret_cast<const int32_t*>(a + L.off_reset_mode);
+    v.goal_mode = reinterpret_cast<const int32_t*>(a + L.off_goal_mode);
+    v.group_id = reinterpret_cast<const int32_t*>(a + L.off_group_id);
+    v.init_table = reinterpret_cast<const float*>(a + L.off_init_table);
+    v.goal_table = reinterpret_cast<const float*>(a + L.off_goal_table);
+    v.beam_cos = reinterpret_cast<const float*>(a + L.off_beam_cos);
+    v.beam_sin = reinterpret_cast<const float*>(a + L.off_beam_sin);
+    v.map_bits = reinterpret_cast<const uint32_t*>(a + L.off_map);
+    v.g.x0 = cfg->map_x0;
+    v.g.y0 = cfg->map_y0;
+    v.g.cell = cfg->map_cell;
+    v.g.inv_cell = 1.0f / cfg->map_cell;
+    v.g.width = cfg->map_width;
+    v.g.height = cfg->map_height;
+    v.g.wpr = cfg->map_words_per_row;
+    v.timeout = cfg->timeout;
+    v.w_thresh = cfg->w_thresh;
+    v.pre_dist_zero = cfg->pre_dist_zero;
+    v.auto_reset = cfg->auto_reset;
+    v.num_groups = num_groups;
+    v.key0 = (uint32_t)(cfg->seed & 0xFFFFFFFFull);
+    v.key1 = (uint32_t)(cfg->seed >> 32);
+    // tile: every cell a 6 m ray can enter lies within ceil(6/cell) cells of the start cell;
+    // +2 cells of slack for the rounding of the closed-form boundary times
+    v.tile_rc = (int32_t)std::ceil(mrca::kRangeMax * v.g.inv_cell) + 2;
+    v.tile_h = 2 * v.tile_rc + 1;
+    v.tile_stride = ((v.tile_h + 31) / 32 + 1) | 1;
+    env->lds_bytes = mrca::ray_lds_bytes(v);
+    if (env->lds_bytes > 160 * 1024)
+        return bail(fail(MRCA_ERR_UNSUPPORTED, "ray-cast tile needs %zu B of LDS (> 160 KiB): use a coarser map_cell",
+                         env->lds_bytes));
+    *env_out = env;
+    return MRCA_OK;
+#undef HIP_TRY_BAIL
+}
+
+int mrca_destroy(mrca_env* env) {
+    if (!env) return MRCA_OK;
+    for (hipEvent_t e : env->ev) (void)hipEventDestroy(e);
+    if (env->owns_arena) HIP_TRY(hipFree(env->arena));
+    delete env;
+    return MRCA_OK;
+}
+
+int mrca_get_field(mrca_env* env, int field, void** ptr_dev_out, size_t* offset_out, size_t* bytes_out) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (field < 0 || field >= MRCA_F_COUNT) return fail(MRCA_ERR_INVALID, "field %d out of range", field);
+    if (ptr_dev_out) *ptr_dev_out = env->arena + env->layout.field_off[field];
+    if (offset_out) *offset_out = env->layout.field_off[field];
+    if (bytes_out) *bytes_out = env->layout.field_bytes[field];
+    return MRCA_OK;
+}
+
+int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, const float* goals_dev, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    mrca::launch_reset(env->view, mask_dev, poses_dev, goals_dev, s);
+    mrca::launch_raycast(env->view, /*only_fresh=*/1, s);
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
+int mrca_step(mrca_env* env, const float* actions_dev, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (!actions_dev) return fail(MRCA_ERR_INVALID, "actions_dev is NULL");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool rec = env->timing && env->ev_used + 3 <= (int)env->ev.size();
+    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 0], s));
+    mrca::launch_move(env->view, actions_dev, s);
+    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
+    mrca::launch_raycast(env->view, /*only_fresh=*/0, s);
+    if (rec) {
+        HIP_TRY(hipEventRecord(env->ev[env->ev_used + 2], s));
+        env->ev_used += 3;
+    }
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
+int mrca_gae(const float* rewards_dev, const float* values_dev, const float* last_value_dev,
+             const uint8_t* dones_dev, float gamma, float lam, int32_t T, int32_t N, float* targets_dev,
+             float* advs_dev, void* stream) {
+    if (!rewards_dev || !values_dev || !last_value_dev || !dones_dev || !targets_dev || !advs_dev)
+        return fail(MRCA_ERR_INVALID, "mrca_gae: NULL pointer");
+    if (T < 1 || N < 1) return fail(MRCA_ERR_INVALID, "mrca_gae: T=%d N=%d", T, N);
+    mrca::launch_gae(rewards_dev, values_dev, last_value_dev, dones_dev, gamma, lam, T, N, targets_dev, advs_dev,
+                     static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
+int mrca_enable_timing(mrca_env* env, int32_t on) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (on && env->ev.empty()) {
+        env->ev.resize(3 * kTimingRing);
+        for (auto& e : env->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    env->timing = on != 0;
+    env->ev_used = 0;
+    return MRCA_OK;
+}
+
+int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    float mv = 0.0f, ry = 0.0f;
+    const int n = env->ev_used / 3;
+    if (n > 0) HIP_TRY(hipEventSynchronize(env->ev[env->ev_used - 1]));
+    for (int i = 0; i < n; ++i) {
+        float a = 0.0f, b = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&a, env->ev[3 * i], env->ev[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, env->ev[3 * i + 1], env->ev[3 * i + 2]));
+        mv += a;
+        ry += b;
+    }
+    if (move_ms_total) *move_ms_total = mv;
+    if (ray_ms_total) *ray_ms_total = ry;
+    if (launches) *launches = n;
+    env->ev_used = 0;
+    return MRCA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// mrca_device.h -- per-lane arithmetic of the Stage tick for gfx950 (and a plain host build
+// used only by the CPU test harness under tests/host_emul/).
+//
+// Every function is built from separately rounded IEEE fp32 +,-,*,/,sqrt and comparisons, in a
+// fixed order (compile with -ffp-contract=off, correctly rounded div/sqrt), so a launch is
+// reproducible bit-for-bit and can be checked against the fp32 mode of the oracle.
+//
+// Reference behaviour restated here (paths relative to the reference checkout):
+//   kinematic tick .......... libstage ModelPosition (un-vendored) driven by stageros.cpp:445-449
+//   lidar geometry .......... stageros.cpp:479-516, worlds/stage1.world:9-15
+//   reward / terminal ....... stage_world1.py:180-211 (+ stage_world2.py:175-208, circle_world.py:171-203)
+//   local goal .............. stage_world1.py:155-160
+//   reset distributions ..... stage_world1.py:251-274, stage_world2.py:250-287
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define MRCA_HD __host__ __device__ __forceinline__
+#else
+#define MRCA_HD inline
+#endif
+
+namespace mrca {
+
+constexpr float kDt = 0.1f;           // Stage default interval_sim (worlds/*.world set none)
+constexpr float kRangeMax = 6.0f;     // stage1.world:13
+constexpr float kHalfLen = 0.22f;     // stage1.world:83  size [0.44 0.38 0.22]
+constexpr float kHalfWid = 0.19f;
+constexpr float kGoalRadius = 0.5f;   // stage_world1.py:34
+constexpr float kRArrive = 15.0f;     // stage_world1.py:195
+constexpr float kRCrash = -15.0f;     // stage_world1.py:200
+constexpr float kKProgress = 2.5f;    // stage_world1.py:187
+constexpr float kKOmega = -0.1f;      // stage_world1.py:204
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTwoPi = 6.28318530717958647692f;
+constexpr int kMaxTriesPose = 64;
+constexpr int kMaxTriesGoal = 256;
+constexpr uint32_t kStreamPose = 0u, kStreamGoal = 1u;
+constexpr float kInf = __builtin_huge_valf();
+
+// ------------------------------------------------------------------------------------------
+// sincos: Cody-Waite reduction by pi/2 + Cephes single-precision minimax polynomials.
+MRCA_HD void sincos_det(float th, float* sn, float* cs) {
+    const float k = rintf(th * 0.6366197723675814f);
+    const float r = ((th - k * 1.5703125f) - k * 4.837512969970703125e-4f) - k * 7.54978995489188e-8f;
+    const float z = r * r;
+    const float s = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z + -1.6666654611e-1f) * z * r + r;
+    const float c = ((2.443315711809948e-5f * z + -1.388731625493765e-3f) * z + 4.166664568298827e-2f) * (z * z) +
+                    (1.0f - 0.5f * z);
+    const int q = ((int)k) & 3;
+    *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+
+// (-pi, pi]: the GT yaw after the quaternion round trip (stageros.cpp:575-583, stage_world1.py:88-91)
+MRCA_HD float wrap_angle(float th) {
+    th = (th > kPi) ? th - kTwoPi : th;
+    th = (th <= -kPi) ? th + kTwoPi : th;
+    return th;
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 (Random123).  Counter = (robot id, episode, try, stream), key = seed.
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+MRCA_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) {
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+MRCA_HD float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// ------------------------------------------------------------------------------------------
+// Occupancy grid views.  Cells outside [0,W)x[0,H) are free.
+struct GridGeom {
+    float x0, y0, cell, inv_cell;
+    int32_t width, height, wpr;
+};
+
+struct GlobalGrid {  // bit lookups straight from the (L2-resident) bitmap
+    const uint32_t* bits;
+    int32_t width, height, wpr;
+    MRCA_HD bool operator()(int ix, int iy) const {
+        if (ix < 0 || iy < 0 || ix >= width || iy >= height) return false;
+        return (bits[iy * wpr + (ix >> 5)] >> (ix & 31)) & 1u;
+    }
+};
+
+// First occupied cell along o + t*d, 0 <= t < tmax (metres, |d| = 1).  The visited cell sequence
+// is driven by closed-form boundary times t(b) = (float(b) - f) * (1/d) in cell units, so it is
+// independent of how the walk is organised.  Returns the entry distance of the first occupied
+// cell (0 when the start cell is occupied) or tmax.  Ties step in y.
+template <class Occ>
+MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, float dx, float dy, float tmax) {
+    const float fx = (ox - g.x0) * g.inv_cell;
+    const float fy = (oy - g.y0) * g.inv_cell;
+    int ix = (int)floorf(fx);
+    int iy = (int)floorf(fy);
+    const float tmax_c = tmax * g.inv_cell;
+    if (occ(ix, iy)) return 0.0f;
+    if (!(tmax_c > 0.0f)) return tmax;
+    const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
+    const float inv_dx = xnz ? 1.0f / dx : kInf;
+    const float inv_dy = ynz ? 1.0f / dy : kInf;
+    const int sx = dx > 0.0f ? 1 : -1;
+    const int sy = dy > 0.0f ? 1 : -1;
+    int bx = dx > 0.0f ? ix + 1 : ix;
+    int by = dy > 0.0f ? iy + 1 : iy;
+    float tx = xnz ? ((float)bx - fx) * inv_dx : kInf;
+    float ty = ynz ? ((float)by - fy) * inv_dy : kInf;
+    for (;;) {
+        float t;
+        if (tx < ty) {
+            t = tx;
+            ix += sx;
+            bx += sx;
+            tx = ((float)bx - fx) * inv_dx;
+        } else {
+            t = ty;
+            iy += sy;
+            by += sy;
+            ty = ynz ? ((float)by - fy) * inv_dy : kInf;
+        }
+        if (t >= tmax_c) return tmax;
+        if (occ(ix, iy)) return t * g.cell;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Robot outline (0.44 x 0.38 rectangle) against the grid: march the four edges.
+template <class Occ>
+MRCA_HD bool static_hit(const Occ& occ, const GridGeom& g, float x, float y, float s, float c) {
+    const float hx[4] = {kHalfLen, -kHalfLen, -kHalfLen, kHalfLen};
+    const float hy[4] = {kHalfWid, kHalfWid, -kHalfWid, -kHalfWid};
+    const float ex[4] = {-c, s, c, -s};
+    const float ey[4] = {-s, -c, s, c};
+    const float el[4] = {2.0f * kHalfLen, 2.0f * kHalfWid, 2.0f * kHalfLen, 2.0f * kHalfWid};
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float cx = x + (hx[k] * c - hy[k] * s);
+        const float cy = y + (hx[k] * s + hy[k] * c);
+        const float t = grid_march(occ, g, cx, cy, ex[k], ey[k], el[k]);
+        hit = hit || (t < el[k]);
+    }
+    return hit;
+}
+
+// Separating-axis test of two robot rectangles; touching counts as overlap.
+MRCA_HD bool obb_overlap(float xi, float yi, float si, float ci, float xj, float yj, float sj, float cj) {
+    const float tx = xj - xi;
+    const float ty = yj - yi;
+    const float a0 = fabsf(ci * cj + si * sj);
+    const float a1 = fabsf(si * cj - ci * sj);
+    const float ex = kHalfLen + (kHalfLen * a0 + kHalfWid * a1);
+    const float ey = kHalfWid + (kHalfLen * a1 + kHalfWid * a0);
+    const bool sep = (fabsf(tx * ci + ty * si) > ex) || (fabsf(ty * ci - tx * si) > ey) ||
+                     (fabsf(tx * cj + ty * sj) > ex) || (fabsf(ty * cj - tx * sj) > ey);
+    return !sep;
+}
+
+MRCA_HD void slab(float lo, float ld, float h, float* t0, float* t1) {
+    const bool par = fabsf(ld) < 1e-12f;
+    const float inv = 1.0f / (par ? 1.0f : ld);
+    const float ta = (-h - lo) * inv;
+    const float tb = (h - lo) * inv;
+    const bool out = fabsf(lo) > h;
+    *t0 = par ? (out ? kInf : -kInf) : (ta < tb ? ta : tb);
+    *t1 = par ? (out ? -kInf : kInf) : (ta < tb ? tb : ta);
+}
+
+// Entry distance of the ray into robot j's rectangle; +inf on a miss.  Robots are visible to
+// each other's lidar: ranger_return 0.5 (stage1.world:95).
+MRCA_HD float ray_box(float ox, float oy, float dx, float dy, float xj, float yj, float sj, float cj) {
+    const float rx = ox - xj;
+    const float ry = oy - yj;
+    const float lx = rx * cj + ry * sj;
+    const float ly = ry * cj - rx * sj;
+    const float ldx = dx * cj + dy * sj;
+    const float ldy = dy * cj - dx * sj;
+    float t0x, t1x, t0y, t1y;
+    slab(lx, ldx, kHalfLen, &t0x, &t1x);
+    slab(ly, ldy, kHalfWid, &t0y, &t1y);
+    const float tin = t0x > t0y ? t0x : t0y;
+    const float tout = t1x < t1y ? t1x : t1y;
+    const bool hit = (tin <= tout) && (tout >= 0.0f);
+    return hit ? (tin > 0.0f ? tin : 0.0f) : kInf;
+}
+
+// ------------------------------------------------------------------------------------------
+// reset_pose / generate_goal_point
+MRCA_HD void region_xy(float ua, float ub, float* x, float* y) {  // stage_world2.py:252-257
+    *x = 9.0f + 10.0f * ua;
+    *y = (ub <= 0.4f) ? -(ub * 10.0f + 1.0f) : -(ub * 10.0f + 9.0f);
+}
+
+// mode: 1 disc (stage_world1.py:251-260), 2 region (stage_world2.py:250-268)
+MRCA_HD void sample_pose(int mode, uint32_t gid, uint32_t episode, uint32_t k0, uint32_t k1, float curx, float cury,
+                         float* px, float* py, float* pth) {
+    for (int k = 0; k < kMaxTriesPose; ++k) {
+        const U4 r = philox4x32_10(gid, episode, (uint32_t)k, kStreamPose, k0, k1);
+        const float ua = u01(r.x), ub = u01(r.y), uc = u01(r.z);
+        float x, y;
+        bool ok;
+        if (mode == 1) {
+            x = -9.0f + 18.0f * ua;
+            y = -9.0f + 18.0f * ub;
+            ok = sqrtf(x * x + y * y) <= 9.0f;
+        } else {
+            region_xy(ua, ub, &x, &y);
+            const float ddx = x - curx, ddy = y - cury;
+            ok = !(sqrtf(ddx * ddx + ddy * ddy) < 7.0f);
+        }
+        if (ok || k == kMaxTriesPose - 1) {
+            *px = x;
+            *py = y;
+            *pth = wrap_angle(kTwoPi * uc);
+            return;
+        }
+    }
+}
+
+// mode: 1 disc with 8..10 m from the robot (stage_world1.py:262-274), 2 region (stage_world2.py:270-287)
+MRCA_HD void sample_goal(int mode, uint32_t gid, uint32_t episode, uint32_t k0, uint32_t k1, float curx, float cury,
+                         float* gx, float* gy) {
+    for (int k = 0; k < kMaxTriesGoal; ++k) {
+        const U4 r = philox4x32_10(gid, episode, (uint32_t)k, kStreamGoal, k0, k1);
+        const float ua = u01(r.x), ub = u01(r.y);
+        float x, y;
+        bool ok;
+        if (mode == 1) {
+            x = -9.0f + 18.0f * ua;
+            y = -9.0f + 18.0f * ub;
+            const float d_o = sqrtf(x * x + y * y);
+            const float ex = x - curx, ey = y - cury;
+            const float d_g = sqrtf(ex * ex + ey * ey);
+            ok = !((d_o > 9.0f) || (d_g > 10.0f) || (d_g < 8.0f));
+        } else {
+            region_xy(ua, ub, &x, &y);
+            const float ex = x - curx, ey = y - cury;
+            ok = !(sqrtf(ex * ex + ey * ey) < 7.0f);
+        }
+        if (ok || k == kMaxTriesGoal - 1) {
+            *gx = x;
+            *gy = y;
+            return;
+        }
+    }
+}
+
+}  // namespace mrca

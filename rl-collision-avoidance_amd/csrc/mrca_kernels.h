@@ -1,0 +1,66 @@
+// mrca_kernels.h -- launch interface between the C ABI (mrca_abi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrca_device.h"
+
+namespace mrca {
+
+// Everything a kernel needs, passed by value (kernarg segment).  All pointers are device memory
+// inside the env's arena.
+struct EnvView {
+    int32_t N, R, W, B, F;
+    // per-robot state (SoA arena, 256-B aligned fields)
+    float* pose;        // [N,3]
+    float* speed;       // [N,2]
+    float* speed_gt;    // [N,2]
+    float* goal;        // [N,2]
+    float* init_pose;   // [N,3]
+    float* scan;        // [N,B]
+    float* obs;         // [N,F,B]
+    float* local_goal;  // [N,2]
+    float* reward;      // [N]
+    float* prev_dist;   // [N]
+    uint8_t* done;
+    uint8_t* result;
+    uint8_t* first_result;
+    uint8_t* crashed;
+    uint8_t* live;
+    uint8_t* fresh;
+    int32_t* t;
+    int32_t* episode;
+    // scenario tables, per local index
+    const int32_t* reset_mode;
+    const int32_t* goal_mode;
+    const int32_t* group_id;
+    const float* init_table;  // [R,3]
+    const float* goal_table;  // [R,2]
+    // lidar beam directions in the robot frame (stageros.cpp:495-497), fp64-computed, fp32-rounded
+    const float* beam_cos;
+    const float* beam_sin;
+    // occupancy grid
+    const uint32_t* map_bits;
+    GridGeom g;
+    // rules
+    int32_t timeout;
+    float w_thresh;
+    int32_t pre_dist_zero;
+    int32_t auto_reset;
+    int32_t num_groups;
+    uint32_t key0, key1;
+    // LDS tile geometry for the ray cast
+    int32_t tile_rc;      // half extent in cells
+    int32_t tile_h;       // rows = 2*rc+1
+    int32_t tile_stride;  // words per LDS row (odd)
+};
+
+size_t ray_lds_bytes(const EnvView& e);
+
+void launch_move(const EnvView& e, const float* actions, hipStream_t s);
+void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s);
+void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
+void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
+                float lam, int T, int N, float* targets, float* advs, hipStream_t s);
+
+}  // namespace mrca

@@ -1,0 +1,383 @@
+// mrca_kernels.hip -- gfx950 kernels of the batched Stage tick.
+//
+//   move_kernel    one 64-lane wavefront per world, lane = robot.  Latch action, integrate,
+//                  outline-vs-grid test, then the collision pass in robot order (Stage moves
+//                  its models one after another): iteration i broadcasts robot i's provisional
+//                  pose, every lane runs the rectangle SAT against its own current pose and a
+//                  wavefront ballot decides revert+stall.  Reward / terminal / episode
+//                  bookkeeping (Philox resets, group-synchronous episodes) follow in-lane.
+//   raycast_kernel one workgroup per robot, one thread per beam (512 threads = 8 waves).
+//                  The (2*rc+1)-row occupancy tile around the robot is staged bit-packed into
+//                  LDS, the other robots of the world within lidar reach are compacted into
+//                  LDS by the first wave (ballot + popcount), then every beam walks the tile
+//                  and slab-tests the neighbours.  Scan, normalised observation and the frame
+//                  stack shift are written coalesced (thread = beam = column).
+//   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
+//   gae_kernel     reverse GAE scan, thread per robot, coalesced over N.
+//
+// No dense contraction anywhere: MFMA is deliberately unused (BASELINE.json north_star).
+#include "mrca_kernels.h"
+
+namespace mrca {
+
+namespace {
+
+constexpr int kWave = 64;
+
+struct TileGrid {  // occupancy lookups in the LDS tile (no bounds checks: margin by construction)
+    const uint32_t* tile;
+    int y0, w0, stride;
+    __device__ __forceinline__ bool operator()(int ix, int iy) const {
+        return (tile[(iy - y0) * stride + ((ix >> 5) - w0)] >> (ix & 31)) & 1u;
+    }
+};
+
+__device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
+                                              float* py, float* pth, float* gx, float* gy, float* pdist,
+                                              const float* pose_override, const float* goal_override) {
+    const uint32_t ep = (uint32_t)e.episode[n];
+    float x, y, th;
+    if (pose_override) {
+        x = pose_override[0];
+        y = pose_override[1];
+        th = pose_override[2];
+    } else {
+        const int mode = e.reset_mode[local];
+        if (mode == 0) {
+            x = e.init_table[local * 3 + 0];
+            y = e.init_table[local * 3 + 1];
+            th = wrap_angle(e.init_table[local * 3 + 2]);
+        } else {
+            sample_pose(mode, (uint32_t)n, ep, e.key0, e.key1, curx, cury, &x, &y, &th);
+        }
+    }
+    float qx, qy;
+    if (goal_override) {
+        qx = goal_override[0];
+        qy = goal_override[1];
+    } else {
+        const int gmode = e.goal_mode[local];
+        if (gmode == 0) {
+            qx = e.goal_table[local * 2 + 0];
+            qy = e.goal_table[local * 2 + 1];
+        } else {
+            sample_goal(gmode, (uint32_t)n, ep, e.key0, e.key1, x, y, &qx, &qy);
+        }
+    }
+    const float ddx = qx - x, ddy = qy - y;
+    const float d = sqrtf(ddx * ddx + ddy * ddy);
+    *px = x;
+    *py = y;
+    *pth = th;
+    *gx = qx;
+    *gy = qy;
+    *pdist = e.pre_dist_zero ? 0.0f : d;
+    e.init_pose[n * 3 + 0] = x;
+    e.init_pose[n * 3 + 1] = y;
+    e.init_pose[n * 3 + 2] = th;
+}
+
+__global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __restrict__ actions) {
+    const int world = blockIdx.x;
+    const int lane = threadIdx.x;
+    const bool valid = lane < e.R;
+    const int n = world * e.R + (valid ? lane : 0);
+
+    const GlobalGrid occ{e.map_bits, e.g.width, e.g.height, e.g.wpr};
+
+    float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
+    const bool live = e.live[n] != 0;
+    const float v = live ? actions[n * 2 + 0] : 0.0f;
+    const float w = live ? actions[n * 2 + 1] : 0.0f;
+
+    // integrate: explicit Euler with the heading at tick start
+    float s, c;
+    sincos_det(th, &s, &c);
+    const float d = v * kDt;
+    const float nx = x + d * c;
+    const float ny = y + d * s;
+    const float nth = wrap_angle(th + w * kDt);
+    float ns, nc;
+    sincos_det(nth, &ns, &nc);
+    const bool moving = valid && ((v != 0.0f) || (w != 0.0f));
+    const bool shit = valid && static_hit(occ, e.g, nx, ny, ns, nc);
+
+    // collision pass in robot order; (x,y,s,c) always holds the lane's CURRENT pose
+    bool moved = false;
+    uint8_t crashed = e.crashed[n];
+    for (int i = 0; i < e.R; ++i) {
+        const float xi = __shfl(nx, i, kWave);
+        const float yi = __shfl(ny, i, kWave);
+        const float si = __shfl(ns, i, kWave);
+        const float ci = __shfl(nc, i, kWave);
+        const bool ov = valid && (lane != i) && obb_overlap(xi, yi, si, ci, x, y, s, c);
+        const unsigned long long m = __ballot(ov);
+        if (lane == i && moving) {
+            const bool hit = shit || (m != 0ull);
+            if (!hit) {
+                x = nx;
+                y = ny;
+                th = nth;
+                s = ns;
+                c = nc;
+                moved = true;
+            }
+            crashed = hit ? 1 : 0;
+        }
+    }
+
+    // GT velocity = finite difference of the pose (stageros.cpp:585-590)
+    const float vgt = moved ? fabsf(v) : 0.0f;
+    const float wgt = moved ? w : 0.0f;
+
+    // reward / terminal (stage_world1.py:180-211)
+    float gx = e.goal[n * 2 + 0], gy = e.goal[n * 2 + 1];
+    const float ddx = gx - x, ddy = gy - y;
+    const float dist = sqrtf(ddx * ddx + ddy * ddy);
+    float pdist = e.prev_dist[n];
+    int t = e.t[n];
+    float rg = (pdist - dist) * kKProgress;
+    const bool reach = dist < kGoalRadius;
+    rg = reach ? kRArrive : rg;
+    const bool crash = crashed == 1;
+    const float rc = crash ? kRCrash : 0.0f;
+    const float aw = fabsf(wgt);
+    const float rw = (aw > e.w_thresh) ? kKOmega * aw : 0.0f;
+    const bool tout = t > e.timeout;
+    uint8_t result = reach ? 1 : 0;
+    result = crash ? 2 : result;
+    result = tout ? 3 : result;
+    const bool done_now = reach || crash || tout;
+    float reward = e.reward[n];
+    uint8_t done = e.done[n];
+    uint8_t res = e.result[n];
+    uint8_t first = e.first_result[n];
+    uint8_t lv = live ? 1 : 0;
+    if (live) {
+        reward = (rg + rc) + rw;
+        done = done_now ? 1 : 0;
+        res = result;
+        pdist = dist;
+        t = t + 1;
+        if (done_now && first == 0) first = result;
+    }
+
+    // episode bookkeeping
+    bool fresh = false;
+    if (e.auto_reset == 1) {
+        fresh = valid && live && done_now;
+    } else if (e.auto_reset == 2) {
+        if (live && done_now) lv = 0;
+        const int gid = valid ? e.group_id[lane] : -1;
+        for (int g = 0; g < e.num_groups; ++g) {
+            const bool in = valid && (gid == g);
+            const unsigned long long members = __ballot(in);
+            const unsigned long long finished = __ballot(in && (done != 0));
+            if (in && members == finished) fresh = true;
+        }
+    }
+    float spv = v, spw = w, ovgt = vgt, owgt = wgt;
+    if (fresh) {
+        e.episode[n] += 1;
+        begin_episode(e, n, lane, x, y, &x, &y, &th, &gx, &gy, &pdist, nullptr, nullptr);
+        t = 1;
+        crashed = 0;
+        lv = 1;
+        spv = spw = ovgt = owgt = 0.0f;
+    }
+
+    if (valid) {
+        e.pose[n * 3 + 0] = x;
+        e.pose[n * 3 + 1] = y;
+        e.pose[n * 3 + 2] = th;
+        e.speed[n * 2 + 0] = spv;
+        e.speed[n * 2 + 1] = spw;
+        e.speed_gt[n * 2 + 0] = ovgt;
+        e.speed_gt[n * 2 + 1] = owgt;
+        e.goal[n * 2 + 0] = gx;
+        e.goal[n * 2 + 1] = gy;
+        e.prev_dist[n] = pdist;
+        e.t[n] = t;
+        e.reward[n] = reward;
+        e.done[n] = done;
+        e.result[n] = res;
+        e.first_result[n] = first;
+        e.crashed[n] = crashed;
+        e.live[n] = lv;
+        e.fresh[n] = fresh ? 1 : 0;
+    }
+}
+
+__global__ void reset_kernel(EnvView e, const uint8_t* __restrict__ mask, const float* __restrict__ poses,
+                             const float* __restrict__ goals) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    const bool sel = mask ? (mask[n] != 0) : true;
+    e.fresh[n] = sel ? 1 : 0;
+    if (!sel) return;
+    const int local = n % e.R;
+    e.episode[n] += 1;
+    float x, y, th, gx, gy, pd;
+    begin_episode(e, n, local, e.pose[n * 3 + 0], e.pose[n * 3 + 1], &x, &y, &th, &gx, &gy, &pd,
+                  poses ? poses + n * 3 : nullptr, goals ? goals + n * 2 : nullptr);
+    e.pose[n * 3 + 0] = x;
+    e.pose[n * 3 + 1] = y;
+    e.pose[n * 3 + 2] = th;
+    e.goal[n * 2 + 0] = gx;
+    e.goal[n * 2 + 1] = gy;
+    e.prev_dist[n] = pd;
+    e.t[n] = 1;
+    e.crashed[n] = 0;
+    e.live[n] = 1;
+    e.speed[n * 2 + 0] = 0.0f;
+    e.speed[n * 2 + 1] = 0.0f;
+    e.speed_gt[n * 2 + 0] = 0.0f;
+    e.speed_gt[n * 2 + 1] = 0.0f;
+    e.done[n] = 0;
+    e.result[n] = 0;
+    e.reward[n] = 0.0f;
+    e.first_result[n] = 0;
+}
+
+// blockIdx -> robot: consecutive robots (one world's robots) share an XCD's L2 (block b runs on
+// XCD b % 8, guide T1); a pure permutation, so correctness never depends on it.
+__device__ __forceinline__ int block_to_robot(int b, int N) {
+    if (N % 8) return b;
+    const int per = N / 8;
+    return (b % 8) * per + b / 8;
+}
+
+__global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int n = block_to_robot(blockIdx.x, e.N);
+    const int tid = threadIdx.x;
+    const bool fresh = e.fresh[n] != 0;
+    if (only_fresh && !fresh) return;  // block-uniform
+
+    uint32_t* tile = lds;
+    const int tile_words = e.tile_h * e.tile_stride;
+    float4* nb = reinterpret_cast<float4*>(lds + ((tile_words + 3) & ~3));
+    int* nb_count = reinterpret_cast<int*>(nb + kWave);
+
+    const int world = n / e.R;
+    const int local = n - world * e.R;
+    const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
+    float s, c;
+    sincos_det(th, &s, &c);
+
+    // --- stage the occupancy tile around the robot
+    const int ix0 = (int)floorf((x - e.g.x0) * e.g.inv_cell);
+    const int iy0 = (int)floorf((y - e.g.y0) * e.g.inv_cell);
+    const int ty0 = iy0 - e.tile_rc;
+    const int tw0 = (ix0 - e.tile_rc) >> 5;
+    const int tw = ((ix0 + e.tile_rc) >> 5) - tw0 + 1;
+    for (int k = tid; k < e.tile_h * tw; k += blockDim.x) {
+        const int r = k / tw;
+        const int wi = k - r * tw;
+        const int gy = ty0 + r;
+        const int gw = tw0 + wi;
+        uint32_t val = 0u;
+        if (gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val = e.map_bits[gy * e.g.wpr + gw];
+        tile[r * e.tile_stride + wi] = val;
+    }
+
+    // --- first wave: compact the world's other robots within lidar reach into LDS
+    if (tid < kWave) {
+        const bool cand = (tid < e.R) && (tid != local);
+        const int j = world * e.R + (cand ? tid : local);
+        const float xj = e.pose[j * 3 + 0], yj = e.pose[j * 3 + 1], thj = e.pose[j * 3 + 2];
+        const float ddx = xj - x, ddy = yj - y;
+        // conservative cull: a hit below 6 m needs the centre within 6 + circumradius(0.2907) m
+        const bool keep = cand && (ddx * ddx + ddy * ddy <= 39.69f);
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            float sj, cj;
+            sincos_det(thj, &sj, &cj);
+            const int idx = __popcll(m & ((1ull << tid) - 1ull));
+            nb[idx] = make_float4(xj, yj, sj, cj);
+        }
+        if (tid == 0) *nb_count = __popcll(m);
+    }
+    __syncthreads();
+
+    // --- one beam per thread
+    const TileGrid occ{tile, ty0, tw0, e.tile_stride};
+    const float bc = e.beam_cos[tid], bs = e.beam_sin[tid];
+    const float dx = c * bc - s * bs;
+    const float dy = s * bc + c * bs;
+    float rng = grid_march(occ, e.g, x, y, dx, dy, kRangeMax);
+    const int cnt = *nb_count;
+    for (int k = 0; k < cnt; ++k) {
+        const float4 q = nb[k];
+        const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
+        rng = t < rng ? t : rng;
+    }
+    rng = rng < kRangeMax ? rng : kRangeMax;
+
+    // --- scan, normalised observation (stage_world1.py:140), frame stack (ppo_stage1.py:59-60,87-89)
+    e.scan[(size_t)n * e.B + tid] = rng;
+    const float o = rng / 6.0f - 0.5f;
+    float* ob = e.obs + (size_t)n * e.F * e.B + tid;
+    if (fresh) {
+        for (int f = 0; f < e.F; ++f) ob[f * e.B] = o;
+    } else {
+        for (int f = 0; f + 1 < e.F; ++f) ob[f * e.B] = ob[(f + 1) * e.B];
+        ob[(e.F - 1) * e.B] = o;
+    }
+    if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
+        const float gx = e.goal[n * 2 + 0] - x, gy = e.goal[n * 2 + 1] - y;
+        e.local_goal[n * 2 + 0] = gx * c + gy * s;
+        e.local_goal[n * 2 + 1] = gy * c - gx * s;
+    }
+}
+
+// generate_train_data (model/ppo.py:122-139)
+__global__ void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                           const float* __restrict__ last_value, const uint8_t* __restrict__ dones, float gamma,
+                           float lam, int T, int N, float* __restrict__ targets, float* __restrict__ advs) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float gl = gamma * lam;
+    float vnext = last_value[n];
+    float g = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t k = (size_t)t * N + n;
+        const float nd = 1.0f - (float)dones[k];
+        const float v = values[k];
+        const float delta = (rewards[k] + gamma * vnext * nd) - v;
+        g = delta + gl * nd * g;
+        const float tg = g + v;
+        targets[k] = tg;
+        advs[k] = tg - v;
+        vnext = v;
+    }
+}
+
+}  // namespace
+
+size_t ray_lds_bytes(const EnvView& e) {
+    const size_t tile_words = (size_t)e.tile_h * e.tile_stride;
+    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * sizeof(float4) + 16;
+}
+
+void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
+    hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), 0, s, e, actions);
+}
+
+void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(reset_kernel, dim3((e.N + bs - 1) / bs), dim3(bs), 0, s, e, mask, poses, goals);
+}
+
+void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
+    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B), ray_lds_bytes(e), s, e, only_fresh);
+}
+
+void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
+                float lam, int T, int N, float* targets, float* advs, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(gae_kernel, dim3((N + bs - 1) / bs), dim3(bs), 0, s, rewards, values, last_value, dones, gamma,
+                       lam, T, N, targets, advs);
+}
+
+}  // namespace mrca

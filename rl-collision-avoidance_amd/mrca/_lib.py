@@ -1,0 +1,72 @@
+"""ctypes binding of libmrca_env.so (include/mrca_env.h).  There is no fallback: if the HIP
+library is missing this module raises, loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrca_env.so")
+
+ABI_VERSION = 1
+
+FIELDS = [  # order = enum mrca_field
+    ("pose", "f32", 3), ("speed", "f32", 2), ("speed_gt", "f32", 2), ("goal", "f32", 2), ("init_pose", "f32", 3),
+    ("scan", "f32", "B"), ("obs", "f32", "FB"), ("local_goal", "f32", 2), ("reward", "f32", 1), ("done", "u8", 1),
+    ("result", "u8", 1), ("first_result", "u8", 1), ("crashed", "u8", 1), ("live", "u8", 1), ("fresh", "u8", 1),
+    ("t", "i32", 1), ("episode", "i32", 1), ("prev_dist", "f32", 1),
+]
+
+EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
+           "mrca_step", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing"]
+
+
+class MrcaConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("num_worlds", C.c_int32),
+        ("robots_per_world", C.c_int32), ("beams", C.c_int32), ("frames", C.c_int32),
+        ("map_width", C.c_int32), ("map_height", C.c_int32), ("map_words_per_row", C.c_int32),
+        ("map_cell", C.c_float), ("map_x0", C.c_float), ("map_y0", C.c_float),
+        ("map_bits", C.c_void_p),
+        ("timeout", C.c_int32), ("w_thresh", C.c_float), ("pre_dist_zero", C.c_int32), ("auto_reset", C.c_int32),
+        ("seed", C.c_uint64),
+        ("reset_mode", C.c_void_p), ("goal_mode", C.c_void_p), ("init_table", C.c_void_p),
+        ("goal_table", C.c_void_p), ("group_id", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the in-tree HIP library (built by ``__graft_entry__.build()`` / csrc/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or csrc/build.sh). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mrca_abi_version.restype = C.c_int
+    lib.mrca_last_error.restype = C.c_char_p
+    lib.mrca_arena_bytes.argtypes = [C.POINTER(MrcaConfig), C.POINTER(C.c_size_t)]
+    lib.mrca_create.argtypes = [C.POINTER(MrcaConfig), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.mrca_destroy.argtypes = [C.c_void_p]
+    lib.mrca_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_get_field.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_size_t)]
+    lib.mrca_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
+                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
+    lib.mrca_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    if lib.mrca_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libmrca_env.so ABI {lib.mrca_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mrca_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")

@@ -1,0 +1,140 @@
+"""VecStageWorld -- the batched, device-resident replacement of N ``StageWorld`` objects.
+
+One instance owns one libmrca_env handle on one GPU.  Every reference getter
+(stage_world1.py:116-160) is a zero-copy torch view on a field of the env's device arena;
+``step`` is one trip round the reference's loop body (ppo_stage1.py:75-91) for all robots at
+once.  torch is used for device memory and streams only; all arithmetic runs in the HIP library.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .scenario import Scenario
+
+_DTYPES = {"f32": torch.float32, "u8": torch.uint8, "i32": torch.int32}
+
+RESULT_NAMES = {0: 0, 1: "Reach Goal", 2: "Crashed", 3: "Time out"}  # stage_world1.py:190-208
+
+
+class VecStageWorld:
+    def __init__(self, scenario: Scenario, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("VecStageWorld needs an MI355X (torch.cuda is unavailable); there is no CPU path")
+        self.lib = _lib.load()
+        self.scenario = sc = scenario
+        if device is None:
+            index = torch.cuda.current_device()
+        else:
+            d = torch.device(device)
+            index = d.index if d.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        self.N, self.R, self.W = sc.num_robots, sc.robots_per_world, sc.num_worlds
+        self.B, self.F = sc.beams, sc.frames
+
+        # host-side tables must outlive mrca_create only
+        bits = np.ascontiguousarray(sc.grid.bits, dtype=np.uint32)
+        reset_mode = np.ascontiguousarray(sc.reset_mode, np.int32)
+        goal_mode = np.ascontiguousarray(sc.goal_mode, np.int32)
+        group_id = np.ascontiguousarray(sc.group_id, np.int32)
+        init_table = np.ascontiguousarray(sc.init_table, np.float32)
+        goal_table = np.ascontiguousarray(sc.goal_table, np.float32)
+        cfg = _lib.MrcaConfig(
+            abi_version=_lib.ABI_VERSION, device=self.device.index, num_worlds=sc.num_worlds,
+            robots_per_world=sc.robots_per_world, beams=sc.beams, frames=sc.frames,
+            map_width=sc.grid.width, map_height=sc.grid.height, map_words_per_row=sc.grid.words_per_row,
+            map_cell=sc.grid.cell, map_x0=sc.grid.x0, map_y0=sc.grid.y0, map_bits=bits.ctypes.data,
+            timeout=sc.timeout, w_thresh=sc.w_thresh, pre_dist_zero=int(sc.pre_dist_zero),
+            auto_reset=sc.auto_reset, seed=sc.seed, reset_mode=reset_mode.ctypes.data,
+            goal_mode=goal_mode.ctypes.data, init_table=init_table.ctypes.data,
+            goal_table=goal_table.ctypes.data, group_id=group_id.ctypes.data)
+        nbytes = C.c_size_t()
+        _lib.check(self.lib.mrca_arena_bytes(C.byref(cfg), C.byref(nbytes)), "mrca_arena_bytes")
+        # the arena is a torch allocation so that every field is a plain torch view (zero copy)
+        self.arena = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mrca_create(C.byref(cfg), self.arena.data_ptr(), nbytes.value, C.byref(handle)),
+                       "mrca_create")
+        self._h = handle
+        for k, (name, dt, shape) in enumerate(_lib.FIELDS):
+            ptr, off, nb = C.c_void_p(), C.c_size_t(), C.c_size_t()
+            _lib.check(self.lib.mrca_get_field(self._h, k, C.byref(ptr), C.byref(off), C.byref(nb)), "mrca_get_field")
+            assert ptr.value == self.arena.data_ptr() + off.value
+            flat = self.arena[off.value: off.value + nb.value].view(_DTYPES[dt])
+            if shape == "B":
+                t = flat.view(self.N, self.B)
+            elif shape == "FB":
+                t = flat.view(self.N, self.F, self.B)
+            elif shape == 1:
+                t = flat.view(self.N)
+            else:
+                t = flat.view(self.N, shape)
+            setattr(self, name, t)
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.mrca_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ptr(t, dtype, numel):
+        if t is None:
+            return None
+        if not (t.is_cuda and t.dtype == dtype and t.is_contiguous() and t.numel() == numel):
+            raise ValueError(f"expected a contiguous cuda {dtype} tensor with {numel} elements")
+        return C.c_void_p(t.data_ptr())
+
+    # ------------------------------------------------------------------ the StageWorld surface, batched
+    def reset(self, mask=None, poses=None, goals=None):
+        """reset_pose + generate_goal_point (+ first observation) for the masked robots
+        (stage_world1.py:171-177,213-223; ppo_stage1.py:52-62)."""
+        _lib.check(self.lib.mrca_reset(self._h, self._ptr(mask, torch.uint8, self.N),
+                                       self._ptr(poses, torch.float32, self.N * 3),
+                                       self._ptr(goals, torch.float32, self.N * 2), self._stream()), "mrca_reset")
+        return self.obs, self.local_goal, self.speed
+
+    def step(self, actions):
+        """control_vel + one Stage tick + get_reward_and_terminate + next observation for every
+        robot (ppo_stage1.py:75-91).  ``actions`` f32[N,2] = clipped (v, omega)."""
+        _lib.check(self.lib.mrca_step(self._h, self._ptr(actions, torch.float32, self.N * 2), self._stream()),
+                   "mrca_step")
+        return self.obs, self.local_goal, self.speed, self.reward, self.done, self.result
+
+    # ------------------------------------------------------------------ timing (bench / profiles)
+    def enable_timing(self, on=True):
+        _lib.check(self.lib.mrca_enable_timing(self._h, int(on)), "mrca_enable_timing")
+
+    def read_timing(self):
+        mv, ry, n = C.c_float(), C.c_float(), C.c_int32()
+        _lib.check(self.lib.mrca_read_timing(self._h, C.byref(mv), C.byref(ry), C.byref(n)), "mrca_read_timing")
+        return mv.value, ry.value, n.value
+
+
+def gae(rewards, values, last_value, dones, gamma, lam):
+    """generate_train_data (model/ppo.py:122-139) on device: rewards/values f32[T,N], last_value
+    f32[N], dones u8[T,N] -> (targets, advs) f32[T,N]."""
+    lib = _lib.load()
+    T, N = rewards.shape
+    for t, dt in ((rewards, torch.float32), (values, torch.float32), (last_value, torch.float32),
+                  (dones, torch.uint8)):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == dt):
+            raise ValueError("gae: expected contiguous cuda tensors (f32, f32, f32, u8)")
+    targets = torch.empty_like(rewards)
+    advs = torch.empty_like(rewards)
+    stream = C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
+    _lib.check(lib.mrca_gae(rewards.data_ptr(), values.data_ptr(), last_value.data_ptr(), dones.data_ptr(),
+                            float(gamma), float(lam), T, N, targets.data_ptr(), advs.data_ptr(), stream), "mrca_gae")
+    return targets, advs

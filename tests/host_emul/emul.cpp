@@ -1,0 +1,253 @@
+// tests/host_emul/emul.cpp -- TEST HARNESS ONLY (never shipped, never loaded by the product).
+//
+// Drives the product's per-lane arithmetic (rl-collision-avoidance_amd/csrc/mrca_device.h, the
+// exact functions the gfx950 kernels inline) with plain host loops, so the arithmetic can be
+// checked bit-for-bit against the oracle's fp32 mode in the CPU-only container before any GPU
+// time is spent.  The loop structure mirrors move_kernel / raycast_kernel / reset_kernel in
+// mrca_kernels.hip (wavefront ballot -> a plain OR over robots).
+//
+// Build: g++ -O2 -ffp-contract=off -shared -fPIC emul.cpp -o libmrca_emul.so
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../rl-collision-avoidance_amd/csrc/mrca_device.h"
+
+using namespace mrca;
+
+extern "C" {
+
+struct EmulEnv {
+    int32_t N, R, W, B, F;
+    float *pose, *speed, *speed_gt, *goal, *init_pose, *scan, *obs, *local_goal, *reward, *prev_dist;
+    uint8_t *done, *result, *first_result, *crashed, *live, *fresh;
+    int32_t *t, *episode;
+    const int32_t *reset_mode, *goal_mode, *group_id;
+    const float *init_table, *goal_table;
+    const float *beam_cos, *beam_sin;
+    const uint32_t* map_bits;
+    float x0, y0, cell;
+    int32_t width, height, wpr;
+    int32_t timeout;
+    float w_thresh;
+    int32_t pre_dist_zero, auto_reset, num_groups;
+    uint32_t key0, key1;
+};
+
+static GridGeom geom(const EmulEnv* e) {
+    GridGeom g;
+    g.x0 = e->x0;
+    g.y0 = e->y0;
+    g.cell = e->cell;
+    g.inv_cell = 1.0f / e->cell;
+    g.width = e->width;
+    g.height = e->height;
+    g.wpr = e->wpr;
+    return g;
+}
+
+static void begin_episode(const EmulEnv* e, int n, int local, float curx, float cury, const float* po,
+                          const float* go) {
+    const uint32_t ep = (uint32_t)e->episode[n];
+    float x, y, th;
+    if (po) {
+        x = po[0]; y = po[1]; th = po[2];
+    } else if (e->reset_mode[local] == 0) {
+        x = e->init_table[local * 3];
+        y = e->init_table[local * 3 + 1];
+        th = wrap_angle(e->init_table[local * 3 + 2]);
+    } else {
+        sample_pose(e->reset_mode[local], (uint32_t)n, ep, e->key0, e->key1, curx, cury, &x, &y, &th);
+    }
+    float gx, gy;
+    if (go) {
+        gx = go[0]; gy = go[1];
+    } else if (e->goal_mode[local] == 0) {
+        gx = e->goal_table[local * 2];
+        gy = e->goal_table[local * 2 + 1];
+    } else {
+        sample_goal(e->goal_mode[local], (uint32_t)n, ep, e->key0, e->key1, x, y, &gx, &gy);
+    }
+    const float ddx = gx - x, ddy = gy - y;
+    const float d = sqrtf(ddx * ddx + ddy * ddy);
+    e->pose[n * 3] = x; e->pose[n * 3 + 1] = y; e->pose[n * 3 + 2] = th;
+    e->init_pose[n * 3] = x; e->init_pose[n * 3 + 1] = y; e->init_pose[n * 3 + 2] = th;
+    e->goal[n * 2] = gx; e->goal[n * 2 + 1] = gy;
+    e->prev_dist[n] = e->pre_dist_zero ? 0.0f : d;
+    e->t[n] = 1;
+    e->crashed[n] = 0;
+    e->live[n] = 1;
+    e->speed[n * 2] = e->speed[n * 2 + 1] = 0.0f;
+    e->speed_gt[n * 2] = e->speed_gt[n * 2 + 1] = 0.0f;
+}
+
+void emul_raycast(const EmulEnv* e, int only_fresh) {
+    const GridGeom g = geom(e);
+    const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
+    for (int n = 0; n < e->N; ++n) {
+        const bool fresh = e->fresh[n] != 0;
+        if (only_fresh && !fresh) continue;
+        const int world = n / e->R, local = n % e->R;
+        const float x = e->pose[n * 3], y = e->pose[n * 3 + 1], th = e->pose[n * 3 + 2];
+        float s, c;
+        sincos_det(th, &s, &c);
+        std::vector<float> nb;
+        for (int j = 0; j < e->R; ++j) {
+            if (j == local) continue;
+            const int m = world * e->R + j;
+            const float xj = e->pose[m * 3], yj = e->pose[m * 3 + 1];
+            const float ddx = xj - x, ddy = yj - y;
+            if (!(ddx * ddx + ddy * ddy <= 39.69f)) continue;
+            float sj, cj;
+            sincos_det(e->pose[m * 3 + 2], &sj, &cj);
+            nb.insert(nb.end(), {xj, yj, sj, cj});
+        }
+        for (int b = 0; b < e->B; ++b) {
+            const float bc = e->beam_cos[b], bs = e->beam_sin[b];
+            const float dx = c * bc - s * bs;
+            const float dy = s * bc + c * bs;
+            float rng = grid_march(occ, g, x, y, dx, dy, kRangeMax);
+            for (size_t k = 0; k < nb.size(); k += 4) {
+                const float t = ray_box(x, y, dx, dy, nb[k], nb[k + 1], nb[k + 2], nb[k + 3]);
+                rng = t < rng ? t : rng;
+            }
+            rng = rng < kRangeMax ? rng : kRangeMax;
+            e->scan[(size_t)n * e->B + b] = rng;
+            const float o = rng / 6.0f - 0.5f;
+            float* ob = e->obs + (size_t)n * e->F * e->B + b;
+            if (fresh) {
+                for (int f = 0; f < e->F; ++f) ob[f * e->B] = o;
+            } else {
+                for (int f = 0; f + 1 < e->F; ++f) ob[f * e->B] = ob[(f + 1) * e->B];
+                ob[(e->F - 1) * e->B] = o;
+            }
+        }
+        const float gx = e->goal[n * 2] - x, gy = e->goal[n * 2 + 1] - y;
+        e->local_goal[n * 2] = gx * c + gy * s;
+        e->local_goal[n * 2 + 1] = gy * c - gx * s;
+    }
+}
+
+void emul_reset(const EmulEnv* e, const uint8_t* mask, const float* poses, const float* goals) {
+    for (int n = 0; n < e->N; ++n) {
+        const bool sel = mask ? mask[n] != 0 : true;
+        e->fresh[n] = sel;
+        if (!sel) continue;
+        e->episode[n] += 1;
+        begin_episode(e, n, n % e->R, e->pose[n * 3], e->pose[n * 3 + 1], poses ? poses + n * 3 : nullptr,
+                      goals ? goals + n * 2 : nullptr);
+        e->done[n] = 0;
+        e->result[n] = 0;
+        e->reward[n] = 0.0f;
+        e->first_result[n] = 0;
+    }
+    emul_raycast(e, 1);
+}
+
+void emul_step(const EmulEnv* e, const float* actions) {
+    const GridGeom g = geom(e);
+    const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
+    const int R = e->R;
+    std::vector<float> x(R), y(R), th(R), s(R), c(R), nx(R), ny(R), nth(R), ns(R), nc(R), v(R), w(R);
+    std::vector<char> moving(R), shit(R), moved(R), livev(R), done_now(R);
+    for (int world = 0; world < e->W; ++world) {
+        for (int l = 0; l < R; ++l) {
+            const int n = world * R + l;
+            x[l] = e->pose[n * 3]; y[l] = e->pose[n * 3 + 1]; th[l] = e->pose[n * 3 + 2];
+            livev[l] = e->live[n] != 0;
+            v[l] = livev[l] ? actions[n * 2] : 0.0f;
+            w[l] = livev[l] ? actions[n * 2 + 1] : 0.0f;
+            sincos_det(th[l], &s[l], &c[l]);
+            const float d = v[l] * kDt;
+            nx[l] = x[l] + d * c[l];
+            ny[l] = y[l] + d * s[l];
+            nth[l] = wrap_angle(th[l] + w[l] * kDt);
+            sincos_det(nth[l], &ns[l], &nc[l]);
+            moving[l] = (v[l] != 0.0f) || (w[l] != 0.0f);
+            shit[l] = static_hit(occ, g, nx[l], ny[l], ns[l], nc[l]);
+            moved[l] = 0;
+        }
+        for (int i = 0; i < R; ++i) {
+            bool any = false;
+            for (int j = 0; j < R; ++j)
+                if (j != i) any = any || obb_overlap(nx[i], ny[i], ns[i], nc[i], x[j], y[j], s[j], c[j]);
+            if (moving[i]) {
+                const bool hit = shit[i] || any;
+                if (!hit) {
+                    x[i] = nx[i]; y[i] = ny[i]; th[i] = nth[i]; s[i] = ns[i]; c[i] = nc[i];
+                    moved[i] = 1;
+                }
+                e->crashed[world * R + i] = hit ? 1 : 0;
+            }
+        }
+        for (int l = 0; l < R; ++l) {
+            const int n = world * R + l;
+            e->pose[n * 3] = x[l]; e->pose[n * 3 + 1] = y[l]; e->pose[n * 3 + 2] = th[l];
+            e->speed[n * 2] = v[l]; e->speed[n * 2 + 1] = w[l];
+            const float vgt = moved[l] ? fabsf(v[l]) : 0.0f;
+            const float wgt = moved[l] ? w[l] : 0.0f;
+            e->speed_gt[n * 2] = vgt; e->speed_gt[n * 2 + 1] = wgt;
+            const float ddx = e->goal[n * 2] - x[l], ddy = e->goal[n * 2 + 1] - y[l];
+            const float dist = sqrtf(ddx * ddx + ddy * ddy);
+            float rg = (e->prev_dist[n] - dist) * kKProgress;
+            const bool reach = dist < kGoalRadius;
+            rg = reach ? kRArrive : rg;
+            const bool crash = e->crashed[n] == 1;
+            const float rc = crash ? kRCrash : 0.0f;
+            const float aw = fabsf(wgt);
+            const float rw = (aw > e->w_thresh) ? kKOmega * aw : 0.0f;
+            const bool tout = e->t[n] > e->timeout;
+            uint8_t result = reach ? 1 : 0;
+            result = crash ? 2 : result;
+            result = tout ? 3 : result;
+            done_now[l] = reach || crash || tout;
+            if (livev[l]) {
+                e->reward[n] = (rg + rc) + rw;
+                e->done[n] = done_now[l];
+                e->result[n] = result;
+                e->prev_dist[n] = dist;
+                e->t[n] += 1;
+                if (done_now[l] && e->first_result[n] == 0) e->first_result[n] = result;
+            }
+            e->fresh[n] = 0;
+        }
+        if (e->auto_reset == 1) {
+            for (int l = 0; l < R; ++l)
+                if (livev[l] && done_now[l]) e->fresh[world * R + l] = 1;
+        } else if (e->auto_reset == 2) {
+            for (int l = 0; l < R; ++l)
+                if (livev[l] && done_now[l]) e->live[world * R + l] = 0;
+            for (int gi = 0; gi < e->num_groups; ++gi) {
+                bool all = true, any = false;
+                for (int l = 0; l < R; ++l)
+                    if (e->group_id[l] == gi) {
+                        any = true;
+                        all = all && e->done[world * R + l];
+                    }
+                if (any && all)
+                    for (int l = 0; l < R; ++l)
+                        if (e->group_id[l] == gi) e->fresh[world * R + l] = 1;
+            }
+        }
+        for (int l = 0; l < R; ++l) {
+            const int n = world * R + l;
+            if (e->fresh[n]) {
+                e->episode[n] += 1;
+                begin_episode(e, n, l, e->pose[n * 3], e->pose[n * 3 + 1], nullptr, nullptr);
+            }
+        }
+    }
+    emul_raycast(e, 0);
+}
+
+void emul_sincos(const float* th, int n, float* s, float* c) {
+    for (int i = 0; i < n; ++i) sincos_det(th[i], &s[i], &c[i]);
+}
+
+void emul_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+    const U4 r = philox4x32_10(c0, c1, c2, c3, k0, k1);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+}  // extern "C"
