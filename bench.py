@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/s of the MI355X-native multi-robot environment (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode env|rollout|train]
+
+A "step" is one pass of the hot path over one batch: every robot of every world on this rank
+advances one Stage tick (latch action -> kinematics -> collision -> 512-beam ray cast -> reward /
+terminal / auto-reset -> observation stack).  Workload at N=1 = BASELINE.json configs[1]: 4096
+robots (128 independent Stage-1 rinks x 32 robots), 512 beams, state resident in HBM.  For N>1 the
+worlds are sharded across ranks with no data-path collective (weak scaling: 4096 robots per GPU).
+
+--mode env      (default, the figure `value`, the >=10 M target and `roofline` refer to)
+--mode rollout  env + policy inference per tick                                  
+--mode train    rollout + GAE + PPO update with RCCL gradient all-reduce         
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (raycast_kernel), timed live
+with HIP events on the stream it is launched on; `cpu_baseline` times the NumPy oracle (a port,
+not the reference binary, which cannot run here -- BASELINE.md 3) on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "rl-collision-avoidance_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_AGENT_STEP = 10332   # SURVEY 8(d) B_env_stack: 2140 + frame-stack shift (4096 read + 4096 write)
+
+
+def cpu_baseline(robots_per_world, seconds_target=12.0):
+    """NumPy oracle, fp32 mode, one core, a bounded sample of the same Stage-1 workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util as U
+    from mrca import scenario as S
+    worlds = 8
+    sc = S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=0)
+    ora = U.oracle_env(sc, np.float32)
+    ora.reset()
+    rng = np.random.default_rng(1)
+    ora.step(U.random_actions(rng, sc.num_robots))
+    t0 = time.perf_counter()
+    ticks = 0
+    while time.perf_counter() - t0 < seconds_target and ticks < 200:
+        ora.step(U.random_actions(rng, sc.num_robots))
+        ticks += 1
+    dt = time.perf_counter() - t0
+    return {"value": sc.num_robots * ticks / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": f"NumPy oracle (fp32 mode), {worlds} Stage-1 rinks x {robots_per_world} robots x 512 beams, "
+                      f"{ticks} ticks in {dt:.1f} s on 1 host core"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--mode", default="env", choices=["env", "rollout", "train"])
+    ap.add_argument("--worlds", type=int, default=128)
+    ap.add_argument("--robots-per-world", type=int, default=32)
+    ap.add_argument("--scenario", default="stage1", choices=["stage1", "stage2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the rollout/train side figures")
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda is unavailable and there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world_size and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world_size}; using {world_size}", file=sys.stderr)
+
+    import __graft_entry__ as G
+    if rank == 0:
+        G.build()
+    if dist is not None:
+        dist.barrier()
+    from mrca import scenario as S
+    from mrca.vec_env import VecStageWorld
+
+    if args.scenario == "stage1":
+        sc = S.stage1(num_worlds=args.worlds, robots_per_world=args.robots_per_world, seed=1000 + rank)
+    else:
+        sc = S.stage2(num_worlds=args.worlds, seed=1000 + rank)
+    env = VecStageWorld(sc)
+    N = sc.num_robots
+    dev = env.device
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    pool = [torch.stack([torch.rand(N, generator=gen, device=dev),
+                         torch.rand(N, generator=gen, device=dev) * 2 - 1], 1).contiguous() for _ in range(16)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    extra = {}
+    if args.mode == "env":
+        step_fn = lambda k: env.step(pool[k % len(pool)])  # noqa: E731
+    else:
+        from mrca.trainer import make_bench_step
+        step_fn = make_bench_step(env, args.mode, dist)
+
+    env.reset()
+    for k in range(args.warmup):
+        step_fn(k)
+    barrier()
+    env.enable_timing(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step_fn(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mv_ms, ray_ms, launches = env.read_timing()
+    env.enable_timing(False)
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    total_robots = N * world_size
+    value = total_robots * args.steps / elapsed
+
+    if rank == 0:
+        ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
+        achieved = BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
+        out = {
+            "metric": "agent-steps/s (N robots x 512-beam lidar)" if args.mode == "env" else
+                      f"agent-steps/s ({args.mode}: env + policy" + (" + GAE + PPO update)" if args.mode == "train" else ")"),
+            "value": value, "unit": "agent-steps/s", "n_gpus": world_size, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scenario}: {args.worlds} worlds x {sc.robots_per_world} robots = {N} "
+                                   f"robots/GPU, 512 beams, 3 frames, cell {sc.grid.cell} m, auto-reset, "
+                                   f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}",
+                       "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode},
+            "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "bytes_per_agent_step": BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
+                         "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
+                         "launches_timed": launches,
+                         "note": "HBM is the nominal roof (SURVEY 8d); the ray march is LDS/VALU bound, see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(sc.robots_per_world if args.scenario == "stage1" else 32)
+            out["cpu_baseline"]["reference_structural_cap"] = "240 agent-steps/s (24 robots x 10 Hz, stageros.cpp:819-828)"
+        out.update(extra)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

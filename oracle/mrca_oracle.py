@@ -299,7 +299,7 @@ class OracleConfig:
 
     def __init__(self, num_worlds, robots_per_world, grid, *, timeout=150, w_thresh=1.05,
                  pre_dist_zero=False, auto_reset=AUTO_ROBOT, seed=0, reset_mode=None,
-                 init_table=None, goal_table=None, group_id=None, beams=BEAMS, frames=3):
+                 init_table=None, goal_table=None, group_id=None, beams=BEAMS, frames=3, first_world=0):
         self.W, self.R = int(num_worlds), int(robots_per_world)
         self.grid = grid
         self.timeout, self.w_thresh = int(timeout), float(w_thresh)
@@ -311,6 +311,7 @@ class OracleConfig:
         self.goal_table = np.zeros((R, 2)) if goal_table is None else np.asarray(goal_table, np.float64)
         self.group_id = np.zeros(R, np.int32) if group_id is None else np.asarray(group_id, np.int32)
         self.beams, self.frames = int(beams), int(frames)
+        self.first_world = int(first_world)   # simulate worlds [first_world, first_world+W) of a larger batch
 
 
 class OracleEnv:
@@ -352,6 +353,7 @@ class OracleEnv:
 
     def _draw(self, gid, episode, k, stream):
         k0, k1 = self._key()
+        gid = gid + self.cfg.first_world * self.cfg.R
         return philox4x32(gid.astype(np.uint32), episode.astype(np.uint32),
                           np.full(gid.shape, k, np.uint32), np.full(gid.shape, stream, np.uint32), k0, k1)
 
@@ -460,7 +462,9 @@ class OracleEnv:
         self.result[idx] = 0
         self.reward[idx] = 0
         self.first_result[idx] = 0
-        self._observe(fresh)
+        # only the robots that were reset are re-observed; the others keep the scan of the last
+        # tick until the next one (their cached LaserScan in the reference, stage_world1.py:97-101)
+        self._observe(fresh, only_fresh=True)
 
     # ---------------------------------------------------------------- tick
     def step(self, actions):
@@ -587,21 +591,23 @@ class OracleEnv:
             rng = np.minimum(rng, tj)
         return np.minimum(rng, f(RANGE_MAX)).reshape(N, B).astype(f)
 
-    def _observe(self, fresh):
+    def _observe(self, fresh, only_fresh=False):
         f = self.f
-        self.scan = self.raycast()
+        upd = fresh if only_fresh else np.ones(self.N, bool)
+        self.scan = np.where(upd[:, None], self.raycast(), self.scan).astype(f)
         # stage_world1.py:122-140: NaN/inf -> 6, identity sub-sampling at 512 beams, scan/6 - 0.5
         new = (self.scan / f(6.0) - f(0.5)).astype(f)
         F = self.cfg.frames
         shifted = np.concatenate([self.obs[:, 1:], new[:, None]], axis=1)
         filled = np.repeat(new[:, None], F, axis=1)      # deque([obs, obs, obs]) ppo_stage1.py:59-60
-        self.obs = np.where(fresh[:, None, None], filled, shifted).astype(f)
+        nobs = np.where(fresh[:, None, None], filled, shifted)
+        self.obs = np.where(upd[:, None, None], nobs, self.obs).astype(f)
         # stage_world1.py:155-160
         s, c = sincos(self.pose[:, 2], f)
         gx = self.goal[:, 0] - self.pose[:, 0]
         gy = self.goal[:, 1] - self.pose[:, 1]
-        self.local_goal[:, 0] = gx * c + gy * s
-        self.local_goal[:, 1] = gy * c - gx * s
+        self.local_goal[:, 0] = np.where(upd, gx * c + gy * s, self.local_goal[:, 0])
+        self.local_goal[:, 1] = np.where(upd, gy * c - gx * s, self.local_goal[:, 1])
 
 
 # --------------------------------------------------------------------------------------------

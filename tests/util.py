@@ -19,12 +19,14 @@ STATE_FIELDS = ["pose", "speed", "speed_gt", "goal", "init_pose", "scan", "obs",
                 "done", "result", "first_result", "crashed", "live", "t", "episode"]
 
 
-def oracle_env(sc, dtype=np.float32):
+def oracle_env(sc, dtype=np.float32, first_world=0, num_worlds=None):
+    """Oracle for worlds [first_world, first_world+num_worlds) of scenario ``sc`` (all by default)."""
     gm = O.GridMap(sc.grid.bits, sc.grid.width, sc.grid.height, sc.grid.cell, sc.grid.x0, sc.grid.y0)
-    cfg = O.OracleConfig(sc.num_worlds, sc.robots_per_world, gm, timeout=sc.timeout, w_thresh=sc.w_thresh,
+    cfg = O.OracleConfig(sc.num_worlds if num_worlds is None else num_worlds, sc.robots_per_world, gm,
+                         timeout=sc.timeout, w_thresh=sc.w_thresh,
                          pre_dist_zero=sc.pre_dist_zero, auto_reset=sc.auto_reset, seed=sc.seed,
                          reset_mode=sc.reset_mode, init_table=sc.init_table, goal_table=sc.goal_table,
-                         group_id=sc.group_id, beams=sc.beams, frames=sc.frames)
+                         group_id=sc.group_id, beams=sc.beams, frames=sc.frames, first_world=first_world)
     cfg.goal_mode = np.asarray(sc.goal_mode, np.int32)
     return O.OracleEnv(cfg, dtype)
 
@@ -163,3 +165,11 @@ def assert_state_equal(a, b, fields=STATE_FIELDS, what=""):
             i = tuple(bad[0])
             raise AssertionError(f"{what}: field {k} differs at {len(bad)} of {same.size} entries; first {i}: "
                                  f"{x[i]!r} vs {y[i]!r}")
+
+
+class HostView:
+    """Host copy of a VecStageWorld's state (optionally a slice of robots)."""
+
+    def __init__(self, env, lo=0, hi=None, fields=STATE_FIELDS):
+        for k in fields:
+            setattr(self, k, getattr(env, k)[lo:hi].cpu().numpy())
