@@ -1,0 +1,117 @@
+"""Vectorised twins of the reference's training loops.
+
+``Stage1Trainer.run`` is ppo_stage1.py:39-131 with the 24 MPI ranks replaced by one batched device
+env: state never leaves HBM, ``comm.gather`` / ``comm.scatter`` disappear, episodes restart inside
+the env (auto reset), and the learner runs every HORIZON ticks exactly like rank 0 does.
+Multi-GPU: one process per GPU, worlds sharded, no data-path collective; the only exchanges are the
+flat gradient all-reduce and the 3-scalar advantage statistics, both RCCL.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import ppo
+from .net import CNNPolicy
+
+
+@dataclass
+class HParams:
+    """ppo_stage1.py:22-35 (Stage-2 overrides: batch 512, epoch 4 -- ppo_stage2.py:28-29)."""
+    horizon: int = 128
+    gamma: float = 0.99
+    lam: float = 0.95
+    batch_size: int = 1024
+    epoch: int = 2
+    coeff_entropy: float = 5e-4
+    clip_value: float = 0.1
+    learning_rate: float = 5e-5
+    laser_hist: int = 3
+    obs_size: int = 512
+    act_size: int = 2
+    value_coef: float = 20.0          # model/ppo.py:185
+    action_bound: tuple = ((0.0, -1.0), (1.0, 1.0))   # ppo_stage1.py:170
+
+
+def broadcast_parameters(module, dist):
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        for p in module.parameters():
+            dist.broadcast(p.data, src=0)
+
+
+class Stage1Trainer:
+    def __init__(self, env, policy=None, hp=None, dist=None, seed=0, stage2=False):
+        self.env, self.dist, self.stage2 = env, dist, stage2
+        self.hp = hp or HParams()
+        dev = env.device
+        torch.manual_seed(seed)
+        self.policy = policy or CNNPolicy(frames=self.hp.laser_hist, action_space=self.hp.act_size,
+                                          beams=self.hp.obs_size)
+        self.policy.to(dev)
+        broadcast_parameters(self.policy, dist)
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate)
+        self.flat_grads = ppo.FlatGrads(self.policy.parameters())
+        self.buffer = ppo.RolloutBuffer(self.hp.horizon, env.N, self.hp.laser_hist, self.hp.obs_size, dev,
+                                        self.hp.act_size)
+        self.gen = torch.Generator(device=dev)
+        rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+        self.gen.manual_seed(seed * 1000 + rank)
+        self.t = 0
+        self.global_update = 0
+        self.loss_log = []
+        self.started = False
+
+    def start(self):
+        self.env.reset()
+        self.started = True
+
+    def tick(self):
+        """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
+        env, hp, buf = self.env, self.hp, self.buffer
+        v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
+                                                    hp.action_bound, self.gen)
+        buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v)
+        env.step(scaled.contiguous())
+        buf.store_outcome(self.t, env.reward, env.done)
+        self.t += 1
+        if self.t == hp.horizon:
+            self.update()
+            self.t = 0
+
+    def update(self):
+        env, hp, buf = self.env, self.hp, self.buffer
+        with torch.no_grad():
+            _mean, last_v = self.policy.mean_value(env.obs, env.local_goal, env.speed)   # ppo_stage1.py:94-97
+        targets, advs = ppo.generate_train_data(buf.reward, hp.gamma, buf.value, last_v, buf.done, hp.lam)
+        memory = (buf.obs, buf.goal, buf.speed, buf.action, buf.logprob, targets, buf.value, buf.reward, advs)
+        kw = dict(policy=self.policy, optimizer=self.optimizer, batch_size=hp.batch_size, memory=memory,
+                  epoch=hp.epoch, coeff_entropy=hp.coeff_entropy, clip_value=hp.clip_value, num_step=hp.horizon,
+                  num_env=env.N, frames=hp.laser_hist, obs_size=hp.obs_size, act_size=hp.act_size,
+                  value_coef=hp.value_coef, dist=self.dist, flat_grads=self.flat_grads, log=self.loss_log)
+        if self.stage2:
+            ppo.ppo_update_stage2(filter_index=ppo.get_filter_index(buf.done), **kw)
+        else:
+            ppo.ppo_update_stage1(**kw)
+        self.global_update += 1
+
+    def run(self, ticks):
+        if not self.started:
+            self.start()
+        for _ in range(ticks):
+            self.tick()
+
+
+def make_bench_step(env, mode, dist, batch_size=16384):
+    """bench.py --mode rollout|train: returns step_fn(k) doing one tick for all robots."""
+    hp = HParams(batch_size=batch_size)
+    tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0)
+    tr.started = True  # bench.py resets the env itself
+    if mode == "rollout":
+        def step_fn(_k):
+            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, env.obs, env.local_goal, env.speed,
+                                                      hp.action_bound, tr.gen)
+            env.step(scaled.contiguous())
+        return step_fn
+
+    def train_fn(_k):
+        tr.tick()
+    return train_fn
