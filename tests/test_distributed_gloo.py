@@ -1,0 +1,118 @@
+"""N>1 path on CPU: two gloo ranks, each holding half of the robots' transitions, must produce the
+same parameters as one process over the whole batch (flat-bucket gradient all-reduce + global
+advantage statistics).  Pure torch on CPU tensors -- the env is not involved: worlds are
+sharded with no data-path collective."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+import util as U  # noqa: F401  (sys.path)
+
+T, N, B = 4, 8, 512
+
+
+def _memory(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)  # noqa: E731
+    obss = r(T, N, 3, B) - 0.5
+    goals = r(T, N, 2) * 10 - 5
+    speeds = r(T, N, 2) * 2 - 1
+    actions = r(T, N, 2) * 2 - 1
+    logprobs = r(T, N, 1) * 0.2 - 2.0
+    targets = torch.randn(T, N, generator=g)
+    advs = torch.randn(T, N, generator=g) * 3 + 1
+    return obss, goals, speeds, actions, logprobs, targets, None, None, advs
+
+
+def _policy():
+    from mrca.net import CNNPolicy
+    torch.manual_seed(123)
+    return CNNPolicy(3, 2)
+
+
+def _local_batches(n_local):
+    # two epochs x two minibatches, fixed so that the union over ranks is reproducible
+    idx = torch.arange(n_local)
+    return [idx[: n_local // 2], idx[n_local // 2:]]
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mrca import ppo
+    from mrca.trainer import broadcast_parameters
+    pol = _policy()
+    if rank != 0:  # prove the broadcast: perturb non-root replicas first
+        with torch.no_grad():
+            for p in pol.parameters():
+                p.add_(0.5)
+    broadcast_parameters(pol, dist)
+    opt = torch.optim.SGD(pol.parameters(), lr=1e-2)
+    fg = ppo.FlatGrads(pol.parameters())
+    mem = _memory()
+    half = N // world
+    local = tuple(None if m is None else m[:, rank * half:(rank + 1) * half].contiguous() for m in mem)
+    ppo.ppo_update_stage1(policy=pol, optimizer=opt, batch_size=0, memory=local, epoch=2, coeff_entropy=5e-4,
+                          clip_value=0.1, num_step=T, num_env=half, frames=3, obs_size=B, act_size=2,
+                          index_batches=lambda n: _local_batches(n), dist=dist, flat_grads=fg)
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        assert torch.equal(gathered[0], gathered[1]), "replicas diverged"
+        torch.save(flat, out)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_update_equals_single_process():
+    from mrca import ppo
+    out = os.path.join(tempfile.mkdtemp(), "params.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+
+    pol = _policy()
+    opt = torch.optim.SGD(pol.parameters(), lr=1e-2)
+    mem = _memory()
+    half = N // 2
+
+    def union_batches(n):
+        # rank r's local flat index j*half + i  <->  global flat index j*N + r*half + i
+        outb = []
+        for lb in _local_batches(T * half):
+            j, i = lb // half, lb % half
+            outb.append(torch.cat([j * N + r * half + i for r in range(2)]))
+        return outb
+
+    ppo.ppo_update_stage1(policy=pol, optimizer=opt, batch_size=0, memory=mem, epoch=2, coeff_entropy=5e-4,
+                          clip_value=0.1, num_step=T, num_env=N, frames=3, obs_size=B, act_size=2,
+                          index_batches=union_batches)
+    want = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    assert float((got - want).abs().max()) < 2e-6, float((got - want).abs().max())
+    # and the update did something
+    assert float((want - torch.cat([p.detach().reshape(-1) for p in _policy().parameters()])).abs().max()) > 1e-5
+
+
+def test_flat_grads_is_one_bucket():
+    from mrca import ppo
+    pol = _policy()
+    fg = ppo.FlatGrads(pol.parameters())
+    assert fg.flat.numel() == 2172101          # 8.69 MB fp32, one all-reduce per step
+    base = fg.flat.data_ptr()
+    off = 0
+    for p in fg.params:
+        assert p.grad.data_ptr() == base + 4 * off
+        off += p.numel()

@@ -1,0 +1,80 @@
+"""GPU: the vectorised trainer (rollout buffer, HIP GAE, PPO update, checkpoint round trip)."""
+import numpy as np
+import pytest
+import torch
+
+import util as U
+from util import S, O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    from mrca import vec_env
+    return vec_env
+
+
+def test_stage1_trainer_one_update_and_gae_consistency(hip):
+    from mrca.trainer import HParams, Stage1Trainer
+    sc = S.stage1(num_worlds=4, robots_per_world=8, seed=2)
+    env = hip.VecStageWorld(sc)
+    hp = HParams(horizon=16, batch_size=128, epoch=2)
+    tr = Stage1Trainer(env, hp=hp, seed=1)
+    before = torch.cat([p.detach().reshape(-1).clone() for p in tr.policy.parameters()])
+    tr.run(15)
+    assert tr.global_update == 0
+    buf = tr.buffer
+    # what the buffer holds at t is the state the action was computed from
+    assert torch.isfinite(buf.obs[:15]).all() and float(buf.obs[:15].abs().max()) <= 0.5
+    tr.run(1)                                   # 16th tick triggers the update
+    assert tr.global_update == 1 and len(tr.loss_log) == 2 * 4     # 512 samples / 128 x 2 epochs
+    after = torch.cat([p.detach().reshape(-1) for p in tr.policy.parameters()])
+    assert float((after - before).abs().max()) > 0
+    assert all(torch.isfinite(torch.stack(x)).all() for x in tr.loss_log)
+    # GAE of the stored rollout == oracle restatement of generate_train_data (fp32, bitwise)
+    with torch.no_grad():
+        _m, last_v = tr.policy.mean_value(env.obs, env.local_goal, env.speed)
+    tg, adv = hip.gae(buf.reward, buf.value, last_v.reshape(-1).contiguous(), buf.done, hp.gamma, hp.lam)
+    t32, a32 = O.gae(buf.reward.cpu().numpy(), buf.value.cpu().numpy(), last_v.reshape(-1).cpu().numpy(),
+                     buf.done.cpu().numpy(), hp.gamma, hp.lam, np.float32)
+    assert (tg.cpu().numpy().view(np.uint32) == t32.view(np.uint32)).all()
+    env.close()
+
+
+def test_stage2_trainer_filtered_update(hip):
+    from mrca.trainer import HParams, Stage1Trainer
+    sc = S.stage2(num_worlds=2, seed=3)
+    env = hip.VecStageWorld(sc)
+    hp = HParams(horizon=24, batch_size=256, epoch=1)
+    tr = Stage1Trainer(env, hp=hp, seed=1, stage2=True)
+    tr.run(24)
+    assert tr.global_update == 1 and len(tr.loss_log) >= 1
+    env.close()
+
+
+def test_checkpoint_roundtrip_reference_keys(hip, tmp_path):
+    """policy/*.pth compatibility: a state_dict saved here has exactly the reference's keys
+    (ppo_stage1.py:122-124,185-191; model/net.py:19-33)."""
+    from mrca.net import CNNPolicy
+    pol = CNNPolicy(3, 2).cuda()
+    f = tmp_path / "stage1_test.pth"
+    torch.save(pol.state_dict(), f)
+    sd = torch.load(f)
+    want = {"logstd", "critic.weight", "critic.bias", "actor1.weight", "actor1.bias", "actor2.weight", "actor2.bias"}
+    for tw in ("act", "crt"):
+        for layer in ("fea_cv1", "fea_cv2", "fc1", "fc2"):
+            want |= {f"{tw}_{layer}.weight", f"{tw}_{layer}.bias"}
+    assert set(sd.keys()) == want
+    pol2 = CNNPolicy(3, 2).cuda()
+    pol2.load_state_dict(sd)
+    x = torch.rand(5, 3, 512, device="cuda") - 0.5
+    g, s = torch.rand(5, 2, device="cuda"), torch.rand(5, 2, device="cuda")
+    with torch.no_grad():
+        a = pol.mean_value(x, g, s)
+        b = pol2.mean_value(x, g, s)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

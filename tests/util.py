@@ -173,3 +173,20 @@ class HostView:
     def __init__(self, env, lo=0, hi=None, fields=STATE_FIELDS):
         for k in fields:
             setattr(self, k, getattr(env, k)[lo:hi].cpu().numpy())
+
+
+class OracleBackend:
+    """Checker backend for the per-index facade (tests only): the NumPy oracle behind the
+    SharedWorld backend protocol of mrca/stage_world.py."""
+
+    def __init__(self, sc, dtype=np.float32):
+        self.env = oracle_env(sc, dtype)
+
+    def reset(self, mask, poses, goals):
+        self.env.reset(mask, poses, goals)
+
+    def step(self, actions):
+        self.env.step(actions)
+
+    def field(self, name):
+        return np.asarray(getattr(self.env, name))
