@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/mrca_env.h"
+#include "mrca_host.h"
 #include "mrca_kernels.h"
 
 namespace {
@@ -37,7 +38,7 @@ struct Layout {
     size_t field_off[MRCA_F_COUNT];
     size_t field_bytes[MRCA_F_COUNT];
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
-    size_t off_beam_cos, off_beam_sin, off_map;
+    size_t off_beam_cos, off_beam_sin, off_map, off_skip;
     size_t total;
 };
 
@@ -115,6 +116,8 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_beam_cos = take(B * 4);
     L->off_beam_sin = take(B * 4);
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
+    L->off_skip = take((size_t)((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) *
+                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK));
     L->total = off;
 }
 
@@ -227,6 +230,11 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_sin, bsin.data(), B * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_map, cfg->map_bits,
                            (size_t)cfg->map_height * cfg->map_words_per_row * 4, hipMemcpyHostToDevice));
+    std::vector<uint8_t> skip;
+    int skip_cw = 0, skip_ch = 0;
+    mrca::build_skip_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &skip, &skip_cw,
+                           &skip_ch);
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
     // live = 1, t = 1 at construction (a robot exists and is idle before the first reset)
     HIP_TRY_BAIL(hipMemset(env->arena + L.field_off[MRCA_F_LIVE], 1, N));
     {
@@ -270,6 +278,12 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.beam_cos = reinterpret_cast<const float*>(a + L.off_beam_cos);
     v.beam_sin = reinterpret_cast<const float*>(a + L.off_beam_sin);
     v.map_bits = reinterpret_cast<const uint32_t*>(a + L.off_map);
+    v.skip = reinterpret_cast<const uint8_t*>(a + L.off_skip);
+    v.skip_cw = skip_cw;
+    v.skip_ch = skip_ch;
+    // blocks needed to cover the footprint's circumradius sqrt(0.22^2 + 0.19^2) = 0.2907 m (+ one
+    // cell of slack for the start cells of the outline walks)
+    v.foot_r = (int32_t)std::ceil((0.2907 + cfg->map_cell) / (mrca::kSkipK * (double)cfg->map_cell));
     v.g.x0 = cfg->map_x0;
     v.g.y0 = cfg->map_y0;
     v.g.cell = cfg->map_cell;
@@ -289,6 +303,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.tile_rc = (int32_t)std::ceil(mrca::kRangeMax * v.g.inv_cell) + 2;
     v.tile_h = 2 * v.tile_rc + 1;
     v.tile_stride = ((v.tile_h + 31) / 32 + 1) | 1;
+    v.ctile_h = v.tile_h / mrca::kSkipK + 2;
+    v.ctile_stride = v.tile_stride * (32 / mrca::kSkipK);
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (env->lds_bytes > 160 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "ray-cast tile needs %zu B of LDS (> 160 KiB): use a coarser map_cell",

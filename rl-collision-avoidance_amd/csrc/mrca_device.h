@@ -143,6 +143,120 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Same result as grid_march, far fewer steps: empty-space skipping over a coarse free-distance
+// field.  The grid is cut into kSkipK x kSkipK blocks; dist(cx,cy) = Chebyshev distance (in
+// blocks, 0 = the block holds an occupied cell) to the nearest non-empty block, so the
+// (2d-1) x (2d-1) blocks around a block with dist d >= 1 are free and the ray can jump straight
+// to the face where it leaves that box.
+//
+// Exactness: grid_march is a 2-way merge of the x-crossing events tx(b) and the y-crossing
+// events ty(b) (both monotone in b), ties -> y first.  Leaving the box through its x face Bx
+// happens iff tx(Bx) < ty(By); at that moment exactly the y events with ty(b) <= tx(Bx) have
+// been consumed (symmetrically: x events with tx(b) < ty(By)).  The next pending boundary is
+// found from an arithmetic estimate and then corrected with the SAME closed-form times, so the
+// walk resumes in precisely the cell, and with precisely the (bx, by, tx, ty), the cell-by-cell
+// walk would have -- every later comparison, and the returned entry time, are bit-identical.
+constexpr int kSkipShift = 3;
+constexpr int kSkipK = 1 << kSkipShift;
+
+struct GlobalDist {  // coarse free-distance field straight from global memory
+    const uint8_t* d;
+    int32_t cw, ch;
+    MRCA_HD int operator()(int cx, int cy) const {
+        if (cx < 0 || cy < 0 || cx >= cw || cy >= ch) return 1;  // outside the map: that block is free
+        return d[cy * cw + cx];
+    }
+};
+
+template <class Occ, class Dist>
+MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& g, float ox, float oy, float dx,
+                              float dy, float tmax) {
+    const float fx = (ox - g.x0) * g.inv_cell;
+    const float fy = (oy - g.y0) * g.inv_cell;
+    int ix = (int)floorf(fx);
+    int iy = (int)floorf(fy);
+    const float tmax_c = tmax * g.inv_cell;
+    if (occ(ix, iy)) return 0.0f;
+    if (!(tmax_c > 0.0f)) return tmax;
+    const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
+    const float inv_dx = xnz ? 1.0f / dx : kInf;
+    const float inv_dy = ynz ? 1.0f / dy : kInf;
+    const int sx = dx > 0.0f ? 1 : -1;
+    const int sy = dy > 0.0f ? 1 : -1;
+    int bx = dx > 0.0f ? ix + 1 : ix;
+    int by = dy > 0.0f ? iy + 1 : iy;
+#define MRCA_TX(b) (((float)(b)-fx) * inv_dx)
+#define MRCA_TY(b) (((float)(b)-fy) * inv_dy)
+    float tx = xnz ? MRCA_TX(bx) : kInf;
+    float ty = ynz ? MRCA_TY(by) : kInf;
+    for (;;) {
+        const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
+        const int d = dist(cx, cy);
+        if (d == 0) {
+            // cell-by-cell while inside this (non-empty) block
+            do {
+                float t;
+                if (tx < ty) {
+                    t = tx;
+                    ix += sx;
+                    bx += sx;
+                    tx = MRCA_TX(bx);
+                } else {
+                    t = ty;
+                    iy += sy;
+                    by += sy;
+                    ty = ynz ? MRCA_TY(by) : kInf;
+                }
+                if (t >= tmax_c) return tmax;
+                if (occ(ix, iy)) return t * g.cell;
+            } while ((ix >> kSkipShift) == cx && (iy >> kSkipShift) == cy);
+        } else {
+            const int Bx = sx > 0 ? ((cx + d) << kSkipShift) : ((cx - d + 1) << kSkipShift);
+            const int By = sy > 0 ? ((cy + d) << kSkipShift) : ((cy - d + 1) << kSkipShift);
+            const float tBx = xnz ? MRCA_TX(Bx) : kInf;
+            const float tBy = ynz ? MRCA_TY(By) : kInf;
+            float t;
+            if (tBx < tBy) {  // leaves the free box through its x face
+                t = tBx;
+                if (t >= tmax_c) return tmax;
+                if (ynz) {  // y events with ty(b) <= t are consumed
+                    const float yT = fy + dy * t;
+                    int b = sy > 0 ? (int)floorf(yT) + 1 : (int)ceilf(yT) - 1;
+                    b = sy > 0 ? (b < by ? by : b) : (b > by ? by : b);
+                    while (b != by && MRCA_TY(b - sy) > t) b -= sy;
+                    while (MRCA_TY(b) <= t) b += sy;
+                    by = b;
+                    ty = MRCA_TY(by);
+                    iy = sy > 0 ? by - 1 : by;
+                }
+                ix = sx > 0 ? Bx : Bx - 1;
+                bx = Bx + sx;
+                tx = MRCA_TX(bx);
+            } else {  // through its y face
+                t = tBy;
+                if (t >= tmax_c) return tmax;
+                if (xnz) {  // x events with tx(b) < t are consumed
+                    const float xT = fx + dx * t;
+                    int b = sx > 0 ? (int)floorf(xT) + 1 : (int)ceilf(xT) - 1;
+                    b = sx > 0 ? (b < bx ? bx : b) : (b > bx ? bx : b);
+                    while (b != bx && !(MRCA_TX(b - sx) < t)) b -= sx;
+                    while (MRCA_TX(b) < t) b += sx;
+                    bx = b;
+                    tx = MRCA_TX(bx);
+                    ix = sx > 0 ? bx - 1 : bx;
+                }
+                iy = sy > 0 ? By : By - 1;
+                by = By + sy;
+                ty = MRCA_TY(by);
+            }
+            if (occ(ix, iy)) return t * g.cell;
+        }
+    }
+#undef MRCA_TX
+#undef MRCA_TY
+}
+
+// ------------------------------------------------------------------------------------------
 // Robot outline (0.44 x 0.38 rectangle) against the grid: march the four edges.
 template <class Occ>
 MRCA_HD bool static_hit(const Occ& occ, const GridGeom& g, float x, float y, float s, float c) {

@@ -1,0 +1,48 @@
+// mrca_host.h -- host-side helpers of the env library (plain C++, no HIP).
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "mrca_device.h"
+
+namespace mrca {
+
+// Coarse free-distance field for grid_march_skip: blocks of kSkipK x kSkipK cells;
+// out[cy*cw+cx] = Chebyshev distance in blocks to the nearest block holding an occupied cell
+// (0 = this block is not empty), saturated at 255.  Two-pass chamfer, exact for L-infinity.
+inline void build_skip_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint8_t>* out,
+                             int* cw_out, int* ch_out) {
+    const int cw = (width + kSkipK - 1) / kSkipK, ch = (height + kSkipK - 1) / kSkipK;
+    std::vector<int> d((size_t)cw * ch, 255);
+    for (int y = 0; y < height; ++y)
+        for (int w = 0; w < wpr; ++w) {
+            uint32_t v = bits[(size_t)y * wpr + w];
+            while (v) {
+                const int b = __builtin_ctz(v);
+                v &= v - 1;
+                const int x = w * 32 + b;
+                if (x < width) d[(size_t)(y >> kSkipShift) * cw + (x >> kSkipShift)] = 0;
+            }
+        }
+    auto at = [&](int x, int y) -> int { return (x < 0 || y < 0 || x >= cw || y >= ch) ? 255 : d[(size_t)y * cw + x]; };
+    for (int y = 0; y < ch; ++y)
+        for (int x = 0; x < cw; ++x) {
+            int m = d[(size_t)y * cw + x];
+            m = std::min(m, std::min(std::min(at(x - 1, y - 1), at(x, y - 1)), std::min(at(x + 1, y - 1), at(x - 1, y))) + 1);
+            d[(size_t)y * cw + x] = std::min(m, 255);
+        }
+    for (int y = ch - 1; y >= 0; --y)
+        for (int x = cw - 1; x >= 0; --x) {
+            int m = d[(size_t)y * cw + x];
+            m = std::min(m, std::min(std::min(at(x + 1, y + 1), at(x, y + 1)), std::min(at(x - 1, y + 1), at(x + 1, y))) + 1);
+            d[(size_t)y * cw + x] = std::min(m, 255);
+        }
+    out->resize((size_t)cw * ch);
+    for (size_t i = 0; i < d.size(); ++i) (*out)[i] = (uint8_t)d[i];
+    *cw_out = cw;
+    *ch_out = ch;
+}
+
+}  // namespace mrca

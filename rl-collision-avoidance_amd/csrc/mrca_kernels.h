@@ -39,8 +39,11 @@ struct EnvView {
     // lidar beam directions in the robot frame (stageros.cpp:495-497), fp64-computed, fp32-rounded
     const float* beam_cos;
     const float* beam_sin;
-    // occupancy grid
+    // occupancy grid + coarse free-distance field (grid_march_skip)
     const uint32_t* map_bits;
+    const uint8_t* skip;
+    int32_t skip_cw, skip_ch;
+    int32_t foot_r;  // blocks that cover the robot's circumradius: dist > foot_r => footprint is free
     GridGeom g;
     // rules
     int32_t timeout;
@@ -53,6 +56,8 @@ struct EnvView {
     int32_t tile_rc;      // half extent in cells
     int32_t tile_h;       // rows = 2*rc+1
     int32_t tile_stride;  // words per LDS row (odd)
+    int32_t ctile_h;      // rows of the coarse distance tile
+    int32_t ctile_stride; // bytes per coarse row
 };
 
 size_t ray_lds_bytes(const EnvView& e);

@@ -32,6 +32,12 @@ struct TileGrid {  // occupancy lookups in the LDS tile (no bounds checks: margi
     }
 };
 
+struct TileDist {  // coarse free-distance lookups in LDS
+    const uint8_t* d;
+    int cy0, cx0, stride;
+    __device__ __forceinline__ int operator()(int cx, int cy) const { return d[(cy - cy0) * stride + (cx - cx0)]; }
+};
+
 __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
                                               float* py, float* pth, float* gx, float* gy, float* pdist,
                                               const float* pose_override, const float* goal_override) {
@@ -100,7 +106,16 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     float ns, nc;
     sincos_det(nth, &ns, &nc);
     const bool moving = valid && ((v != 0.0f) || (w != 0.0f));
-    const bool shit = valid && static_hit(occ, e.g, nx, ny, ns, nc);
+    // outline-vs-grid test; skipped (same answer: free) when the coarse free-distance field says every
+    // block within the footprint's circumradius of the provisional centre is empty
+    bool shit = false;
+    if (valid) {
+        const GlobalDist dist{e.skip, e.skip_cw, e.skip_ch};
+        const int pcx = ((int)floorf((nx - e.g.x0) * e.g.inv_cell)) >> kSkipShift;
+        const int pcy = ((int)floorf((ny - e.g.y0) * e.g.inv_cell)) >> kSkipShift;
+        const bool inside = pcx >= 0 && pcy >= 0 && pcx < e.skip_cw && pcy < e.skip_ch;
+        if (!(inside && dist(pcx, pcy) > e.foot_r)) shit = static_hit(occ, e.g, nx, ny, ns, nc);
+    }
 
     // collision pass in robot order; (x,y,s,c) always holds the lane's CURRENT pose
     bool moved = false;
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int tile_words = e.tile_h * e.tile_stride;
     float4* nb = reinterpret_cast<float4*>(lds + ((tile_words + 3) & ~3));
     int* nb_count = reinterpret_cast<int*>(nb + kWave);
+    uint8_t* ctile = reinterpret_cast<uint8_t*>(nb_count + 4);
 
     const int world = n / e.R;
     const int local = n - world * e.R;
@@ -279,6 +295,19 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         uint32_t val = 0u;
         if (gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val = e.map_bits[gy * e.g.wpr + gw];
         tile[r * e.tile_stride + wi] = val;
+    }
+    // coarse free-distance tile (bytes) over the same region; blocks outside the map are free (1)
+    const int cy0 = ty0 >> kSkipShift;
+    const int cx0 = tw0 * (32 / kSkipK);
+    const int ctw = tw * (32 / kSkipK);
+    const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
+    for (int k = tid; k < cth * ctw; k += blockDim.x) {
+        const int r = k / ctw;
+        const int ci = k - r * ctw;
+        const int gy = cy0 + r, gx = cx0 + ci;
+        uint8_t val = 1;
+        if (gy >= 0 && gy < e.skip_ch && gx >= 0 && gx < e.skip_cw) val = e.skip[gy * e.skip_cw + gx];
+        ctile[r * e.ctile_stride + ci] = val;
     }
 
     // --- first wave: compact the world's other robots within lidar reach into LDS
@@ -305,7 +334,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const float bc = e.beam_cos[tid], bs = e.beam_sin[tid];
     const float dx = c * bc - s * bs;
     const float dy = s * bc + c * bs;
-    float rng = grid_march(occ, e.g, x, y, dx, dy, kRangeMax);
+    const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
+    float rng = grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
     const int cnt = *nb_count;
     for (int k = 0; k < cnt; ++k) {
         const float4 q = nb[k];
@@ -357,7 +387,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 
 size_t ray_lds_bytes(const EnvView& e) {
     const size_t tile_words = (size_t)e.tile_h * e.tile_stride;
-    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * sizeof(float4) + 16;
+    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * sizeof(float4) + 16 + (size_t)e.ctile_h * e.ctile_stride;
 }
 
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../rl-collision-avoidance_amd/csrc/mrca_device.h"
+#include "../../rl-collision-avoidance_amd/csrc/mrca_host.h"
 
 using namespace mrca;
 
@@ -85,6 +86,10 @@ static void begin_episode(const EmulEnv* e, int n, int local, float curx, float 
 void emul_raycast(const EmulEnv* e, int only_fresh) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
+    std::vector<uint8_t> skipf;
+    int scw, sch;
+    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch);
+    const GlobalDist dist{skipf.data(), scw, sch};
     for (int n = 0; n < e->N; ++n) {
         const bool fresh = e->fresh[n] != 0;
         if (only_fresh && !fresh) continue;
@@ -107,7 +112,7 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
             const float bc = e->beam_cos[b], bs = e->beam_sin[b];
             const float dx = c * bc - s * bs;
             const float dy = s * bc + c * bs;
-            float rng = grid_march(occ, g, x, y, dx, dy, kRangeMax);
+            float rng = grid_march_skip(occ, dist, g, x, y, dx, dy, kRangeMax);
             for (size_t k = 0; k < nb.size(); k += 4) {
                 const float t = ray_box(x, y, dx, dy, nb[k], nb[k + 1], nb[k + 2], nb[k + 3]);
                 rng = t < rng ? t : rng;
@@ -149,6 +154,11 @@ void emul_step(const EmulEnv* e, const float* actions) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
     const int R = e->R;
+    std::vector<uint8_t> skipf;
+    int scw, sch;
+    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch);
+    const GlobalDist dist{skipf.data(), scw, sch};
+    const int foot_r = (int)ceil((0.2907 + (double)e->cell) / (kSkipK * (double)e->cell));
     std::vector<float> x(R), y(R), th(R), s(R), c(R), nx(R), ny(R), nth(R), ns(R), nc(R), v(R), w(R);
     std::vector<char> moving(R), shit(R), moved(R), livev(R), done_now(R);
     for (int world = 0; world < e->W; ++world) {
@@ -165,7 +175,13 @@ void emul_step(const EmulEnv* e, const float* actions) {
             nth[l] = wrap_angle(th[l] + w[l] * kDt);
             sincos_det(nth[l], &ns[l], &nc[l]);
             moving[l] = (v[l] != 0.0f) || (w[l] != 0.0f);
-            shit[l] = static_hit(occ, g, nx[l], ny[l], ns[l], nc[l]);
+            {
+                const int pcx = ((int)floorf((nx[l] - g.x0) * g.inv_cell)) >> kSkipShift;
+                const int pcy = ((int)floorf((ny[l] - g.y0) * g.inv_cell)) >> kSkipShift;
+                const bool inside = pcx >= 0 && pcy >= 0 && pcx < scw && pcy < sch;
+                shit[l] = 0;
+                if (!(inside && dist(pcx, pcy) > foot_r)) shit[l] = static_hit(occ, g, nx[l], ny[l], ns[l], nc[l]);
+            }
             moved[l] = 0;
         }
         for (int i = 0; i < R; ++i) {
@@ -239,6 +255,29 @@ void emul_step(const EmulEnv* e, const float* actions) {
         }
     }
     emul_raycast(e, 0);
+}
+
+// plain vs skipping march on arbitrary rays (returns the number of coarse blocks for sizing)
+int emul_skip_field(const EmulEnv* e, uint8_t* out, int cap) {
+    std::vector<uint8_t> f;
+    int cw, ch;
+    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch);
+    if ((int)f.size() <= cap) memcpy(out, f.data(), f.size());
+    return (cw << 16) | ch;
+}
+
+void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const float* dx, const float* dy,
+                const float* tmax, float* out_plain, float* out_skip) {
+    const GridGeom g = geom(e);
+    const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
+    std::vector<uint8_t> f;
+    int cw, ch;
+    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch);
+    const GlobalDist dist{f.data(), cw, ch};
+    for (int i = 0; i < n; ++i) {
+        out_plain[i] = grid_march(occ, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
+        out_skip[i] = grid_march_skip(occ, dist, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
+    }
 }
 
 void emul_sincos(const float* th, int n, float* s, float* c) {
