@@ -153,6 +153,9 @@ const char* mrca_last_error(void);
  * recorded launches in milliseconds and clears the ring. */
 int mrca_enable_timing(mrca_env* env, int32_t on);
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
+/* Profiling ablations ONLY (results are wrong while any flag is set): 1 = skip robot-robot lidar
+ * tests, 2 = skip the grid march, 4 = skip tile staging (implies 2).  0 restores the product path. */
+int mrca_set_debug_flags(mrca_env* env, int32_t flags);
 
 #ifdef __cplusplus
 }

@@ -305,7 +305,17 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.tile_stride = ((v.tile_h + 31) / 32 + 1) | 1;
     v.ctile_h = v.tile_h / mrca::kSkipK + 2;
     v.ctile_stride = v.tile_stride * (32 / mrca::kSkipK);
+    v.tile_lg = 0;
+    while ((1 << v.tile_lg) < v.tile_stride) ++v.tile_lg;
+    v.ctile_lg = 0;
+    while ((1 << v.ctile_lg) < v.ctile_stride) ++v.ctile_lg;
+    v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
+    v.debug_flags = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
+    if (mrca::move_lds_bytes(v) > 64 * 1024 || (1 << v.ctile_lg) > cfg->beams ||
+        (1 << v.tile_lg) > cfg->beams)
+        return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
+                         (double)cfg->map_cell));
     if (env->lds_bytes > 160 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "ray-cast tile needs %zu B of LDS (> 160 KiB): use a coarser map_cell",
                          env->lds_bytes));
@@ -377,6 +387,12 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
     }
     env->timing = on != 0;
     env->ev_used = 0;
+    return MRCA_OK;
+}
+
+int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    env->view.debug_flags = flags;
     return MRCA_OK;
 }
 

@@ -317,6 +317,30 @@ MRCA_HD float ray_box(float ox, float oy, float dx, float dy, float xj, float yj
     return hit ? (tin > 0.0f ? tin : 0.0f) : kInf;
 }
 
+// Conservative set of beams that can touch another robot: the rectangle lies inside its
+// circumscribed circle (radius 0.2907 m), so only beams within asin(r/dist) of the bearing of its
+// centre can hit it.  Two beam widths + 1 mm of slack absorb every rounding in here (atan2f/asinf
+// are only used for this cull, never for a reported value); culled beams provably miss, so the
+// minimum over the kept tests equals the minimum over all of them.
+MRCA_HD void beam_interval(float lx, float ly, int beams, int* lo, int* hi) {
+    const float dist = sqrtf(lx * lx + ly * ly);
+    if (dist <= 0.30f) {
+        *lo = 0;
+        *hi = beams - 1;
+        return;
+    }
+    const float step = kPi / (float)(beams - 1);
+    const float ratio = 0.2917f / dist;
+    const float alpha = asinf(ratio < 1.0f ? ratio : 1.0f) + 2.0f * step;
+    const float phi = atan2f(ly, lx);
+    const float inv_step = (float)(beams - 1) / kPi;
+    const float flo = (phi - alpha + 0.5f * kPi) * inv_step;
+    const float fhi = (phi + alpha + 0.5f * kPi) * inv_step;
+    int l = (int)floorf(flo), h = (int)ceilf(fhi);
+    *lo = l < 0 ? 0 : l;
+    *hi = h > beams - 1 ? beams - 1 : h;
+}
+
 // ------------------------------------------------------------------------------------------
 // reset_pose / generate_goal_point
 MRCA_HD void region_xy(float ua, float ub, float* x, float* y) {  // stage_world2.py:252-257

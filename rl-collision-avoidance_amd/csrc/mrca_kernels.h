@@ -58,9 +58,14 @@ struct EnvView {
     int32_t tile_stride;  // words per LDS row (odd)
     int32_t ctile_h;      // rows of the coarse distance tile
     int32_t ctile_stride; // bytes per coarse row
+    int32_t tile_lg;      // log2 of the staging column pitch (>= tile_stride)
+    int32_t ctile_lg;     // same for the coarse tile
+    int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
+    int32_t debug_flags;  // profiling ablations only: 1 no neighbour tests, 2 no march, 4 no staging
 };
 
 size_t ray_lds_bytes(const EnvView& e);
+size_t move_lds_bytes(const EnvView& e);
 
 void launch_move(const EnvView& e, const float* actions, hipStream_t s);
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s);

@@ -83,13 +83,24 @@ __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local
     e.init_pose[n * 3 + 2] = th;
 }
 
+struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
+    const uint32_t* t;
+    int y0, w0, stride;
+    __device__ __forceinline__ bool operator()(int ix, int iy) const {
+        return (t[(iy - y0) * stride + ((ix >> 5) - w0)] >> (ix & 31)) & 1u;
+    }
+};
+
+__device__ __forceinline__ float bcast(float v, int lane) {  // lane is wave-uniform: v_readlane_b32
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __restrict__ actions) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
     const int world = blockIdx.x;
     const int lane = threadIdx.x;
     const bool valid = lane < e.R;
     const int n = world * e.R + (valid ? lane : 0);
-
-    const GlobalGrid occ{e.map_bits, e.g.width, e.g.height, e.g.wpr};
 
     float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
     const bool live = e.live[n] != 0;
@@ -114,17 +125,39 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         const int pcx = ((int)floorf((nx - e.g.x0) * e.g.inv_cell)) >> kSkipShift;
         const int pcy = ((int)floorf((ny - e.g.y0) * e.g.inv_cell)) >> kSkipShift;
         const bool inside = pcx >= 0 && pcy >= 0 && pcx < e.skip_cw && pcy < e.skip_ch;
-        if (!(inside && dist(pcx, pcy) > e.foot_r)) shit = static_hit(occ, e.g, nx, ny, ns, nc);
+        if (!(inside && dist(pcx, pcy) > e.foot_r)) {
+            // pull the (2*hc+1)-row patch under the footprint into LDS with independent loads (one
+            // latency round trip instead of ~40 dependent ones), then walk the outline in LDS
+            const int hc = e.foot_hc;
+            const int rows = 2 * hc + 1;
+            const int words = (rows + 31) / 32 + 1;
+            const int pix = (int)floorf((nx - e.g.x0) * e.g.inv_cell);
+            const int piy = (int)floorf((ny - e.g.y0) * e.g.inv_cell);
+            const int y0 = piy - hc;
+            const int w0 = (pix - hc) >> 5;
+            uint32_t* mt = mini + lane * rows * words;
+            for (int r = 0; r < rows; ++r) {
+                const int gy = y0 + r;
+                for (int wi = 0; wi < words; ++wi) {
+                    const int gw = w0 + wi;
+                    uint32_t val = 0u;
+                    if (gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val = e.map_bits[gy * e.g.wpr + gw];
+                    mt[r * words + wi] = val;
+                }
+            }
+            const MiniGrid mg{mt, y0, w0, words};
+            shit = static_hit(mg, e.g, nx, ny, ns, nc);
+        }
     }
 
     // collision pass in robot order; (x,y,s,c) always holds the lane's CURRENT pose
     bool moved = false;
     uint8_t crashed = e.crashed[n];
     for (int i = 0; i < e.R; ++i) {
-        const float xi = __shfl(nx, i, kWave);
-        const float yi = __shfl(ny, i, kWave);
-        const float si = __shfl(ns, i, kWave);
-        const float ci = __shfl(nc, i, kWave);
+        const float xi = bcast(nx, i);
+        const float yi = bcast(ny, i);
+        const float si = bcast(ns, i);
+        const float ci = bcast(nc, i);
         const bool ov = valid && (lane != i) && obb_overlap(xi, yi, si, ci, x, y, s, c);
         const unsigned long long m = __ballot(ov);
         if (lane == i && moving) {
@@ -272,7 +305,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     uint32_t* tile = lds;
     const int tile_words = e.tile_h * e.tile_stride;
     float4* nb = reinterpret_cast<float4*>(lds + ((tile_words + 3) & ~3));
-    int* nb_count = reinterpret_cast<int*>(nb + kWave);
+    int2* nbi = reinterpret_cast<int2*>(nb + kWave);
+    int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     uint8_t* ctile = reinterpret_cast<uint8_t*>(nb_count + 4);
 
     const int world = n / e.R;
@@ -281,66 +315,79 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     float s, c;
     sincos_det(th, &s, &c);
 
-    // --- stage the occupancy tile around the robot
+    // --- stage the occupancy tile around the robot: thread -> (row, word) by shifts, no division
     const int ix0 = (int)floorf((x - e.g.x0) * e.g.inv_cell);
     const int iy0 = (int)floorf((y - e.g.y0) * e.g.inv_cell);
     const int ty0 = iy0 - e.tile_rc;
     const int tw0 = (ix0 - e.tile_rc) >> 5;
     const int tw = ((ix0 + e.tile_rc) >> 5) - tw0 + 1;
-    for (int k = tid; k < e.tile_h * tw; k += blockDim.x) {
-        const int r = k / tw;
-        const int wi = k - r * tw;
-        const int gy = ty0 + r;
-        const int gw = tw0 + wi;
-        uint32_t val = 0u;
-        if (gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val = e.map_bits[gy * e.g.wpr + gw];
-        tile[r * e.tile_stride + wi] = val;
-    }
-    // coarse free-distance tile (bytes) over the same region; blocks outside the map are free (1)
     const int cy0 = ty0 >> kSkipShift;
     const int cx0 = tw0 * (32 / kSkipK);
     const int ctw = tw * (32 / kSkipK);
     const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
-    for (int k = tid; k < cth * ctw; k += blockDim.x) {
-        const int r = k / ctw;
-        const int ci = k - r * ctw;
-        const int gy = cy0 + r, gx = cx0 + ci;
-        uint8_t val = 1;
-        if (gy >= 0 && gy < e.skip_ch && gx >= 0 && gx < e.skip_cw) val = e.skip[gy * e.skip_cw + gx];
-        ctile[r * e.ctile_stride + ci] = val;
+    if (!(e.debug_flags & 4)) {
+        const int wi = tid & ((1 << e.tile_lg) - 1);
+        const int gw = tw0 + wi;
+        const bool colok = wi < tw && gw >= 0 && gw < e.g.wpr;
+        for (int r = tid >> e.tile_lg; r < e.tile_h; r += blockDim.x >> e.tile_lg) {
+            const int gy = ty0 + r;
+            uint32_t val = 0u;
+            if (colok && gy >= 0 && gy < e.g.height) val = e.map_bits[gy * e.g.wpr + gw];
+            if (wi < tw) tile[r * e.tile_stride + wi] = val;
+        }
+        // coarse free-distance tile (bytes) over the same region; blocks outside the map are free (1)
+        const int ci = tid & ((1 << e.ctile_lg) - 1);
+        const int gx = cx0 + ci;
+        const bool ccolok = ci < ctw && gx >= 0 && gx < e.skip_cw;
+        for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
+            const int gy = cy0 + r;
+            uint8_t val = 1;
+            if (ccolok && gy >= 0 && gy < e.skip_ch) val = e.skip[gy * e.skip_cw + gx];
+            if (ci < ctw) ctile[r * e.ctile_stride + ci] = val;
+        }
     }
 
-    // --- first wave: compact the world's other robots within lidar reach into LDS
+    // --- first wave: compact the world's other robots within lidar reach into LDS, each with the
+    //     (conservative) interval of beams that can touch it
     if (tid < kWave) {
         const bool cand = (tid < e.R) && (tid != local);
         const int j = world * e.R + (cand ? tid : local);
         const float xj = e.pose[j * 3 + 0], yj = e.pose[j * 3 + 1], thj = e.pose[j * 3 + 2];
         const float ddx = xj - x, ddy = yj - y;
         // conservative cull: a hit below 6 m needs the centre within 6 + circumradius(0.2907) m
-        const bool keep = cand && (ddx * ddx + ddy * ddy <= 39.69f);
+        bool keep = cand && (ddx * ddx + ddy * ddy <= 39.69f);
+        int lo = 0, hi = -1;
+        if (keep) {
+            beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, &lo, &hi);
+            keep = lo <= hi;
+        }
         const unsigned long long m = __ballot(keep);
         if (keep) {
             float sj, cj;
             sincos_det(thj, &sj, &cj);
             const int idx = __popcll(m & ((1ull << tid) - 1ull));
             nb[idx] = make_float4(xj, yj, sj, cj);
+            nbi[idx] = make_int2(lo, hi);
         }
-        if (tid == 0) *nb_count = __popcll(m);
+        if (tid == 0) *nb_count = (e.debug_flags & 1) ? 0 : __popcll(m);
     }
     __syncthreads();
 
     // --- one beam per thread
     const TileGrid occ{tile, ty0, tw0, e.tile_stride};
+    const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
     const float bc = e.beam_cos[tid], bs = e.beam_sin[tid];
     const float dx = c * bc - s * bs;
     const float dy = s * bc + c * bs;
-    const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
-    float rng = grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+    float rng = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
     const int cnt = *nb_count;
     for (int k = 0; k < cnt; ++k) {
-        const float4 q = nb[k];
-        const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
-        rng = t < rng ? t : rng;
+        const int2 iv = nbi[k];
+        if (tid >= iv.x && tid <= iv.y) {
+            const float4 q = nb[k];
+            const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
+            rng = t < rng ? t : rng;
+        }
     }
     rng = rng < kRangeMax ? rng : kRangeMax;
 
@@ -387,11 +434,18 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 
 size_t ray_lds_bytes(const EnvView& e) {
     const size_t tile_words = (size_t)e.tile_h * e.tile_stride;
-    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * sizeof(float4) + 16 + (size_t)e.ctile_h * e.ctile_stride;
+    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * (sizeof(float4) + sizeof(int2)) + 16 +
+           (size_t)e.ctile_h * e.ctile_stride;
+}
+
+size_t move_lds_bytes(const EnvView& e) {
+    const int rows = 2 * e.foot_hc + 1;
+    const int words = (rows + 31) / 32 + 1;
+    return (size_t)kWave * rows * words * 4;
 }
 
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
-    hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), 0, s, e, actions);
+    hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), move_lds_bytes(e), s, e, actions);
 }
 
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s) {

@@ -16,7 +16,8 @@ FIELDS = [  # order = enum mrca_field
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
-           "mrca_step", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing"]
+           "mrca_step", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
+           "mrca_set_debug_flags"]
 
 
 class MrcaConfig(C.Structure):
@@ -59,6 +60,7 @@ def load():
     lib.mrca_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
+    lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]
     lib.mrca_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.mrca_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libmrca_env.so ABI {lib.mrca_abi_version()} != binding ABI {ABI_VERSION}")

@@ -117,6 +117,11 @@ class VecStageWorld:
     def enable_timing(self, on=True):
         _lib.check(self.lib.mrca_enable_timing(self._h, int(on)), "mrca_enable_timing")
 
+    def set_debug_flags(self, flags):
+        """Profiling ablations only (results are wrong while set): 1 no robot-robot lidar tests,
+        2 no grid march, 4 no tile staging."""
+        _lib.check(self.lib.mrca_set_debug_flags(self._h, int(flags)), "mrca_set_debug_flags")
+
     def read_timing(self):
         mv, ry, n = C.c_float(), C.c_float(), C.c_int32()
         _lib.check(self.lib.mrca_read_timing(self._h, C.byref(mv), C.byref(ry), C.byref(n)), "mrca_read_timing")

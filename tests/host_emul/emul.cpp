@@ -98,15 +98,20 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
         float s, c;
         sincos_det(th, &s, &c);
         std::vector<float> nb;
+        std::vector<int> nbi;
         for (int j = 0; j < e->R; ++j) {
             if (j == local) continue;
             const int m = world * e->R + j;
             const float xj = e->pose[m * 3], yj = e->pose[m * 3 + 1];
             const float ddx = xj - x, ddy = yj - y;
             if (!(ddx * ddx + ddy * ddy <= 39.69f)) continue;
+            int lo, hi;
+            beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e->B, &lo, &hi);
+            if (lo > hi) continue;
             float sj, cj;
             sincos_det(e->pose[m * 3 + 2], &sj, &cj);
             nb.insert(nb.end(), {xj, yj, sj, cj});
+            nbi.insert(nbi.end(), {lo, hi});
         }
         for (int b = 0; b < e->B; ++b) {
             const float bc = e->beam_cos[b], bs = e->beam_sin[b];
@@ -114,6 +119,7 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
             const float dy = s * bc + c * bs;
             float rng = grid_march_skip(occ, dist, g, x, y, dx, dy, kRangeMax);
             for (size_t k = 0; k < nb.size(); k += 4) {
+                if (b < nbi[k / 2] || b > nbi[k / 2 + 1]) continue;
                 const float t = ray_box(x, y, dx, dy, nb[k], nb[k + 1], nb[k + 2], nb[k + 3]);
                 rng = t < rng ? t : rng;
             }

@@ -53,3 +53,25 @@ def test_explicit_reset_mask_and_overrides():
     e.reset(mask, poses, goals)
     U.assert_state_equal(e, o, what="masked reset")
     assert (o.pose[[0, 2, 5], 0] == poses[[0, 2, 5], 0]).all()
+
+
+def test_dense_world_beam_culling_is_conservative():
+    """64 robots in a 14 m arena: many neighbours at every range.  The product culls robot-robot
+    lidar tests by bearing interval, the oracle tests every pair: results must stay bit-identical."""
+    g = U.small_grid(cell=0.05, size=14.0, blocks=[(-0.6, -0.6, 0.6, 0.6)])
+    sc = S.stage1(num_worlds=1, robots_per_world=64, seed=31, grid=g)
+    o = U.oracle_env(sc)
+    e = U.EmulEnv(sc)
+    rng = np.random.default_rng(5)
+    poses = np.stack([rng.uniform(-6, 6, 64), rng.uniform(-6, 6, 64), rng.uniform(-np.pi, np.pi, 64)], 1).astype(np.float32)
+    poses[:8, :2] = [[2.0 + 0.5 * k, 2.0] for k in range(8)]          # a tight row: near-touching neighbours
+    goals = rng.uniform(-6, 6, (64, 2)).astype(np.float32)
+    o.reset(None, poses, goals)
+    e.reset(None, poses, goals)
+    U.assert_state_equal(e, o, what="dense reset")
+    for k in range(12):
+        a = U.random_actions(rng, 64)
+        o.step(a)
+        e.step(a)
+        U.assert_state_equal(e, o, what=f"dense step {k}")
+    assert (o.scan < 1.0).mean() > 0.01

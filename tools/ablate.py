@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""GPU ablation of the ray-cast kernel (profiling only): times the tick with parts switched off via
+mrca_set_debug_flags so the cost split march / neighbours / staging / writes is known."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rl-collision-avoidance_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import __graft_entry__ as G  # noqa: E402
+
+G.build()
+from mrca import scenario as S  # noqa: E402
+from mrca.vec_env import VecStageWorld  # noqa: E402
+
+for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32, seed=1)),
+                 ("stage2 187x44", S.stage2(num_worlds=187, seed=1))):
+    env = VecStageWorld(sc)
+    N = sc.num_robots
+    gen = torch.Generator(device=env.device).manual_seed(1)
+    pool = [torch.stack([torch.rand(N, generator=gen, device=env.device),
+                         torch.rand(N, generator=gen, device=env.device) * 2 - 1], 1).contiguous() for _ in range(8)]
+    env.reset()
+    for k in range(50):
+        env.step(pool[k % 8])
+    for flags, label in ((0, "full"), (1, "no neighbour tests"), (2, "no march"), (3, "no march, no neighbours"),
+                         (7, "no staging/march/neighbours (writes only)"), (0, "full again")):
+        env.set_debug_flags(flags)
+        for k in range(20):
+            env.step(pool[k % 8])
+        torch.cuda.synchronize()
+        env.enable_timing(True)
+        for k in range(300):
+            env.step(pool[k % 8])
+        mv, ry, n = env.read_timing()
+        env.enable_timing(False)
+        print(f"{name:<14} flags={flags} {label:<44} ray {ry / n * 1e3:8.1f} us   move {mv / n * 1e3:7.1f} us")
+    env.set_debug_flags(0)
+    env.close()
