@@ -348,58 +348,65 @@ MRCA_HD void region_xy(float ua, float ub, float* x, float* y) {  // stage_world
     *y = (ub <= 0.4f) ? -(ub * 10.0f + 1.0f) : -(ub * 10.0f + 9.0f);
 }
 
-// mode: 1 disc (stage_world1.py:251-260), 2 region (stage_world2.py:250-268)
-MRCA_HD void sample_pose(int mode, uint32_t gid, uint32_t episode, uint32_t k0, uint32_t k1, float curx, float cury,
-                         float* px, float* py, float* pth) {
-    for (int k = 0; k < kMaxTriesPose; ++k) {
-        const U4 r = philox4x32_10(gid, episode, (uint32_t)k, kStreamPose, k0, k1);
-        const float ua = u01(r.x), ub = u01(r.y), uc = u01(r.z);
-        float x, y;
-        bool ok;
-        if (mode == 1) {
-            x = -9.0f + 18.0f * ua;
-            y = -9.0f + 18.0f * ub;
-            ok = sqrtf(x * x + y * y) <= 9.0f;
-        } else {
-            region_xy(ua, ub, &x, &y);
-            const float ddx = x - curx, ddy = y - cury;
-            ok = !(sqrtf(ddx * ddx + ddy * ddy) < 7.0f);
-        }
-        if (ok || k == kMaxTriesPose - 1) {
-            *px = x;
-            *py = y;
-            *pth = wrap_angle(kTwoPi * uc);
-            return;
-        }
+// One rejection-sampling attempt k of reset_pose.  mode: 1 disc (stage_world1.py:251-260),
+// 2 region (stage_world2.py:250-268).  Returns whether the draw is acceptable; the sampled pose is
+// the FIRST acceptable k, or k = kMaxTriesPose-1 if none is (bounded loop).
+MRCA_HD bool pose_try(int mode, uint32_t gid, uint32_t episode, uint32_t k, uint32_t k0, uint32_t k1, float curx,
+                      float cury, float* px, float* py, float* pth) {
+    const U4 r = philox4x32_10(gid, episode, k, kStreamPose, k0, k1);
+    const float ua = u01(r.x), ub = u01(r.y), uc = u01(r.z);
+    float x, y;
+    bool ok;
+    if (mode == 1) {
+        x = -9.0f + 18.0f * ua;
+        y = -9.0f + 18.0f * ub;
+        ok = sqrtf(x * x + y * y) <= 9.0f;
+    } else {
+        region_xy(ua, ub, &x, &y);
+        const float ddx = x - curx, ddy = y - cury;
+        ok = !(sqrtf(ddx * ddx + ddy * ddy) < 7.0f);
     }
+    *px = x;
+    *py = y;
+    *pth = wrap_angle(kTwoPi * uc);
+    return ok;
 }
 
-// mode: 1 disc with 8..10 m from the robot (stage_world1.py:262-274), 2 region (stage_world2.py:270-287)
+// One attempt k of generate_goal_point.  mode: 1 disc with 8..10 m from the robot
+// (stage_world1.py:262-274), 2 region (stage_world2.py:270-287).
+MRCA_HD bool goal_try(int mode, uint32_t gid, uint32_t episode, uint32_t k, uint32_t k0, uint32_t k1, float curx,
+                      float cury, float* gx, float* gy) {
+    const U4 r = philox4x32_10(gid, episode, k, kStreamGoal, k0, k1);
+    const float ua = u01(r.x), ub = u01(r.y);
+    float x, y;
+    bool ok;
+    if (mode == 1) {
+        x = -9.0f + 18.0f * ua;
+        y = -9.0f + 18.0f * ub;
+        const float d_o = sqrtf(x * x + y * y);
+        const float ex = x - curx, ey = y - cury;
+        const float d_g = sqrtf(ex * ex + ey * ey);
+        ok = !((d_o > 9.0f) || (d_g > 10.0f) || (d_g < 8.0f));
+    } else {
+        region_xy(ua, ub, &x, &y);
+        const float ex = x - curx, ey = y - cury;
+        ok = !(sqrtf(ex * ex + ey * ey) < 7.0f);
+    }
+    *gx = x;
+    *gy = y;
+    return ok;
+}
+
+MRCA_HD void sample_pose(int mode, uint32_t gid, uint32_t episode, uint32_t k0, uint32_t k1, float curx, float cury,
+                         float* px, float* py, float* pth) {
+    for (int k = 0; k < kMaxTriesPose; ++k)
+        if (pose_try(mode, gid, episode, (uint32_t)k, k0, k1, curx, cury, px, py, pth) || k == kMaxTriesPose - 1) return;
+}
+
 MRCA_HD void sample_goal(int mode, uint32_t gid, uint32_t episode, uint32_t k0, uint32_t k1, float curx, float cury,
                          float* gx, float* gy) {
-    for (int k = 0; k < kMaxTriesGoal; ++k) {
-        const U4 r = philox4x32_10(gid, episode, (uint32_t)k, kStreamGoal, k0, k1);
-        const float ua = u01(r.x), ub = u01(r.y);
-        float x, y;
-        bool ok;
-        if (mode == 1) {
-            x = -9.0f + 18.0f * ua;
-            y = -9.0f + 18.0f * ub;
-            const float d_o = sqrtf(x * x + y * y);
-            const float ex = x - curx, ey = y - cury;
-            const float d_g = sqrtf(ex * ex + ey * ey);
-            ok = !((d_o > 9.0f) || (d_g > 10.0f) || (d_g < 8.0f));
-        } else {
-            region_xy(ua, ub, &x, &y);
-            const float ex = x - curx, ey = y - cury;
-            ok = !(sqrtf(ex * ex + ey * ey) < 7.0f);
-        }
-        if (ok || k == kMaxTriesGoal - 1) {
-            *gx = x;
-            *gy = y;
-            return;
-        }
-    }
+    for (int k = 0; k < kMaxTriesGoal; ++k)
+        if (goal_try(mode, gid, episode, (uint32_t)k, k0, k1, curx, cury, gx, gy) || k == kMaxTriesGoal - 1) return;
 }
 
 }  // namespace mrca

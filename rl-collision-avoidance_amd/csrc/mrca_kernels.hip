@@ -83,6 +83,48 @@ __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local
     e.init_pose[n * 3 + 2] = th;
 }
 
+// Wave-parallel rejection sampling: the 64 lanes evaluate 64 consecutive attempts k at once and the
+// lowest acceptable k wins -- the same draw the one-lane loop (sample_pose / sample_goal) returns,
+// without a wavefront waiting on one unlucky robot's long tail.  All arguments are wave-uniform.
+__device__ __forceinline__ int ibcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float fbcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ void wave_sample_pose(int lane, int mode, uint32_t gid, uint32_t ep, uint32_t k0,
+                                                 uint32_t k1, float curx, float cury, float* px, float* py,
+                                                 float* pth) {
+    for (int base = 0; base < kMaxTriesPose; base += kWave) {
+        float x, y, th;
+        const bool ok = pose_try(mode, gid, ep, (uint32_t)(base + lane), k0, k1, curx, cury, &x, &y, &th);
+        const bool last = base + kWave >= kMaxTriesPose;
+        const unsigned long long m = __ballot(ok || (last && lane == kMaxTriesPose - 1 - base));
+        if (m) {
+            const int w = __ffsll((long long)m) - 1;
+            *px = fbcast(x, w);
+            *py = fbcast(y, w);
+            *pth = fbcast(th, w);
+            return;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_sample_goal(int lane, int mode, uint32_t gid, uint32_t ep, uint32_t k0,
+                                                 uint32_t k1, float curx, float cury, float* gx, float* gy) {
+    for (int base = 0; base < kMaxTriesGoal; base += kWave) {
+        float x, y;
+        const bool ok = goal_try(mode, gid, ep, (uint32_t)(base + lane), k0, k1, curx, cury, &x, &y);
+        const bool last = base + kWave >= kMaxTriesGoal;
+        const unsigned long long m = __ballot(ok || (last && lane == kMaxTriesGoal - 1 - base));
+        if (m) {
+            const int w = __ffsll((long long)m) - 1;
+            *gx = fbcast(x, w);
+            *gy = fbcast(y, w);
+            return;
+        }
+    }
+}
+
 struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
     const uint32_t* t;
     int y0, w0, stride;
@@ -125,7 +167,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         const int pcx = ((int)floorf((nx - e.g.x0) * e.g.inv_cell)) >> kSkipShift;
         const int pcy = ((int)floorf((ny - e.g.y0) * e.g.inv_cell)) >> kSkipShift;
         const bool inside = pcx >= 0 && pcy >= 0 && pcx < e.skip_cw && pcy < e.skip_ch;
-        if (!(inside && dist(pcx, pcy) > e.foot_r)) {
+        if (!(inside && dist(pcx, pcy) > e.foot_r) && !(e.debug_flags & 8)) {
             // pull the (2*hc+1)-row patch under the footprint into LDS with independent loads (one
             // latency round trip instead of ~40 dependent ones), then walk the outline in LDS
             const int hc = e.foot_hc;
@@ -153,7 +195,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     // collision pass in robot order; (x,y,s,c) always holds the lane's CURRENT pose
     bool moved = false;
     uint8_t crashed = e.crashed[n];
-    for (int i = 0; i < e.R; ++i) {
+    for (int i = 0; i < ((e.debug_flags & 16) ? 0 : e.R); ++i) {
         const float xi = bcast(nx, i);
         const float yi = bcast(ny, i);
         const float si = bcast(ns, i);
@@ -225,13 +267,51 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         }
     }
     float spv = v, spw = w, ovgt = vgt, owgt = wgt;
-    if (fresh) {
-        e.episode[n] += 1;
-        begin_episode(e, n, lane, x, y, &x, &y, &th, &gx, &gy, &pdist, nullptr, nullptr);
-        t = 1;
-        crashed = 0;
-        lv = 1;
-        spv = spw = ovgt = owgt = 0.0f;
+    if (e.debug_flags & 32) fresh = false;
+    // new episodes, one robot at a time with the whole wave sampling for it
+    int ep = e.episode[n];
+    const int rmode = valid ? e.reset_mode[lane] : 0;
+    const int gmode = valid ? e.goal_mode[lane] : 0;
+    unsigned long long need = __ballot(fresh);
+    while (need) {
+        const int src = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int nsrc = world * e.R + src;
+        const uint32_t eps = (uint32_t)(ibcast(ep, src) + 1);
+        const int rm = ibcast(rmode, src), gm = ibcast(gmode, src);
+        float px, py, pth, qx, qy;
+        if (rm == 0) {
+            px = e.init_table[src * 3 + 0];
+            py = e.init_table[src * 3 + 1];
+            pth = wrap_angle(e.init_table[src * 3 + 2]);
+        } else {
+            wave_sample_pose(lane, rm, (uint32_t)nsrc, eps, e.key0, e.key1, fbcast(x, src), fbcast(y, src), &px, &py,
+                             &pth);
+        }
+        if (gm == 0) {
+            qx = e.goal_table[src * 2 + 0];
+            qy = e.goal_table[src * 2 + 1];
+        } else {
+            wave_sample_goal(lane, gm, (uint32_t)nsrc, eps, e.key0, e.key1, px, py, &qx, &qy);
+        }
+        if (lane == src) {
+            ep = (int)eps;
+            x = px;
+            y = py;
+            th = pth;
+            gx = qx;
+            gy = qy;
+            const float ex = qx - px, ey = qy - py;
+            const float d0 = sqrtf(ex * ex + ey * ey);
+            pdist = e.pre_dist_zero ? 0.0f : d0;
+            e.init_pose[n * 3 + 0] = px;
+            e.init_pose[n * 3 + 1] = py;
+            e.init_pose[n * 3 + 2] = pth;
+            t = 1;
+            crashed = 0;
+            lv = 1;
+            spv = spw = ovgt = owgt = 0.0f;
+        }
     }
 
     if (valid) {
@@ -252,6 +332,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         e.first_result[n] = first;
         e.crashed[n] = crashed;
         e.live[n] = lv;
+        e.episode[n] = ep;
         e.fresh[n] = fresh ? 1 : 0;
     }
 }
