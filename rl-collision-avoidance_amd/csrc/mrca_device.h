@@ -156,7 +156,7 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 // found from an arithmetic estimate and then corrected with the SAME closed-form times, so the
 // walk resumes in precisely the cell, and with precisely the (bx, by, tx, ty), the cell-by-cell
 // walk would have -- every later comparison, and the returned entry time, are bit-identical.
-constexpr int kSkipShift = 3;
+constexpr int kSkipShift = 2;
 constexpr int kSkipK = 1 << kSkipShift;
 
 struct GlobalDist {  // coarse free-distance field straight from global memory
@@ -168,6 +168,11 @@ struct GlobalDist {  // coarse free-distance field straight from global memory
     }
 };
 
+// Flat, branch-poor form (one loop, one "event" per iteration, x/y handled by selects) so the 64
+// rays of a wavefront stay in lock step: an iteration is either a jump to the face of the free box
+// (d >= 1) or a single cell step (d == 0, the "box" is the current cell).  No (tx, ty) state is
+// carried -- boundary times are always re-derived from the closed form, which is what makes every
+// path through here produce the same numbers as grid_march.
 template <class Occ, class Dist>
 MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& g, float ox, float oy, float dx,
                               float dy, float tmax) {
@@ -183,77 +188,49 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
     const float inv_dy = ynz ? 1.0f / dy : kInf;
     const int sx = dx > 0.0f ? 1 : -1;
     const int sy = dy > 0.0f ? 1 : -1;
-    int bx = dx > 0.0f ? ix + 1 : ix;
+    int bx = dx > 0.0f ? ix + 1 : ix;  // next pending boundary on each axis
     int by = dy > 0.0f ? iy + 1 : iy;
-#define MRCA_TX(b) (((float)(b)-fx) * inv_dx)
-#define MRCA_TY(b) (((float)(b)-fy) * inv_dy)
-    float tx = xnz ? MRCA_TX(bx) : kInf;
-    float ty = ynz ? MRCA_TY(by) : kInf;
     for (;;) {
         const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
         const int d = dist(cx, cy);
-        if (d == 0) {
-            // cell-by-cell while inside this (non-empty) block
-            do {
-                float t;
-                if (tx < ty) {
-                    t = tx;
-                    ix += sx;
-                    bx += sx;
-                    tx = MRCA_TX(bx);
-                } else {
-                    t = ty;
-                    iy += sy;
-                    by += sy;
-                    ty = ynz ? MRCA_TY(by) : kInf;
-                }
-                if (t >= tmax_c) return tmax;
-                if (occ(ix, iy)) return t * g.cell;
-            } while ((ix >> kSkipShift) == cx && (iy >> kSkipShift) == cy);
-        } else {
-            const int Bx = sx > 0 ? ((cx + d) << kSkipShift) : ((cx - d + 1) << kSkipShift);
-            const int By = sy > 0 ? ((cy + d) << kSkipShift) : ((cy - d + 1) << kSkipShift);
-            const float tBx = xnz ? MRCA_TX(Bx) : kInf;
-            const float tBy = ynz ? MRCA_TY(By) : kInf;
-            float t;
-            if (tBx < tBy) {  // leaves the free box through its x face
-                t = tBx;
-                if (t >= tmax_c) return tmax;
-                if (ynz) {  // y events with ty(b) <= t are consumed
-                    const float yT = fy + dy * t;
-                    int b = sy > 0 ? (int)floorf(yT) + 1 : (int)ceilf(yT) - 1;
-                    b = sy > 0 ? (b < by ? by : b) : (b > by ? by : b);
-                    while (b != by && MRCA_TY(b - sy) > t) b -= sy;
-                    while (MRCA_TY(b) <= t) b += sy;
-                    by = b;
-                    ty = MRCA_TY(by);
-                    iy = sy > 0 ? by - 1 : by;
-                }
-                ix = sx > 0 ? Bx : Bx - 1;
-                bx = Bx + sx;
-                tx = MRCA_TX(bx);
-            } else {  // through its y face
-                t = tBy;
-                if (t >= tmax_c) return tmax;
-                if (xnz) {  // x events with tx(b) < t are consumed
-                    const float xT = fx + dx * t;
-                    int b = sx > 0 ? (int)floorf(xT) + 1 : (int)ceilf(xT) - 1;
-                    b = sx > 0 ? (b < bx ? bx : b) : (b > bx ? bx : b);
-                    while (b != bx && !(MRCA_TX(b - sx) < t)) b -= sx;
-                    while (MRCA_TX(b) < t) b += sx;
-                    bx = b;
-                    tx = MRCA_TX(bx);
-                    ix = sx > 0 ? bx - 1 : bx;
-                }
-                iy = sy > 0 ? By : By - 1;
-                by = By + sy;
-                ty = MRCA_TY(by);
-            }
-            if (occ(ix, iy)) return t * g.cell;
+        // faces of the region known to be free: the (2d-1)^2-block box, or just this cell
+        const int Bx = d ? (sx > 0 ? ((cx + d) << kSkipShift) : ((cx - d + 1) << kSkipShift)) : bx;
+        const int By = d ? (sy > 0 ? ((cy + d) << kSkipShift) : ((cy - d + 1) << kSkipShift)) : by;
+        const float tBx = xnz ? ((float)Bx - fx) * inv_dx : kInf;
+        const float tBy = ynz ? ((float)By - fy) * inv_dy : kInf;
+        const bool xe = tBx < tBy;  // leaves through the x face (ties: y first)
+        const float t = xe ? tBx : tBy;
+        if (t >= tmax_c) return tmax;
+        // the other ("secondary") axis: which of its crossings were consumed before time t?
+        // x exit: y crossings with ty(b) <= t;  y exit: x crossings with tx(b) < t.
+        const float fS = xe ? fy : fx;
+        const float invS = xe ? inv_dy : inv_dx;
+        const int sS = xe ? sy : sx;
+        const int bS0 = xe ? by : bx;
+        int bS = bS0;
+        if (d && (xe ? ynz : xnz)) {
+            const float pT = fS + (xe ? dy : dx) * t;  // estimate only; corrected exactly below
+            int b = sS > 0 ? (int)floorf(pT) + 1 : (int)ceilf(pT) - 1;
+            b = sS > 0 ? (b < bS0 ? bS0 : b) : (b > bS0 ? bS0 : b);
+#define MRCA_CONSUMED(bb) (xe ? ((((float)(bb)-fS) * invS) <= t) : ((((float)(bb)-fS) * invS) < t))
+            while (b != bS0 && !MRCA_CONSUMED(b - sS)) b -= sS;
+            while (MRCA_CONSUMED(b)) b += sS;
+#undef MRCA_CONSUMED
+            bS = b;
         }
+        if (xe) {
+            by = bS;
+            iy = sy > 0 ? by - 1 : by;
+            ix = sx > 0 ? Bx : Bx - 1;
+            bx = Bx + sx;
+        } else {
+            bx = bS;
+            ix = sx > 0 ? bx - 1 : bx;
+            iy = sy > 0 ? By : By - 1;
+            by = By + sy;
+        }
+        if (occ(ix, iy)) return t * g.cell;
     }
-#undef MRCA_TX
-#undef MRCA_TY
 }
 
 // ------------------------------------------------------------------------------------------
