@@ -161,10 +161,10 @@ constexpr int kSkipK = 1 << kSkipShift;
 
 struct GlobalDist {  // coarse free-distance field straight from global memory
     const uint8_t* d;
-    int32_t cw, ch, pitch;
+    int32_t cw, ch;
     MRCA_HD int operator()(int cx, int cy) const {
         if (cx < 0 || cy < 0 || cx >= cw || cy >= ch) return 1;  // outside the map: that block is free
-        return d[cy * pitch + cx];
+        return d[cy * cw + cx];
     }
 };
 
@@ -190,22 +190,16 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
     const int sy = dy > 0.0f ? 1 : -1;
     int bx = dx > 0.0f ? ix + 1 : ix;  // next pending boundary on each axis
     int by = dy > 0.0f ? iy + 1 : iy;
-    float t = 0.0f;        // entry time of the current cell
-    bool first = true;     // the start cell was tested above
     for (;;) {
         const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
         const int d = dist(cx, cy);
-        // the cell just entered can only be occupied if its block is not empty (one lookup saved
-        // for every event in free space)
-        if (!first && d == 0 && occ(ix, iy)) return t * g.cell;
-        first = false;
         // faces of the region known to be free: the (2d-1)^2-block box, or just this cell
         const int Bx = d ? (sx > 0 ? ((cx + d) << kSkipShift) : ((cx - d + 1) << kSkipShift)) : bx;
         const int By = d ? (sy > 0 ? ((cy + d) << kSkipShift) : ((cy - d + 1) << kSkipShift)) : by;
         const float tBx = xnz ? ((float)Bx - fx) * inv_dx : kInf;
         const float tBy = ynz ? ((float)By - fy) * inv_dy : kInf;
         const bool xe = tBx < tBy;  // leaves through the x face (ties: y first)
-        t = xe ? tBx : tBy;
+        const float t = xe ? tBx : tBy;
         if (t >= tmax_c) return tmax;
         // the other ("secondary") axis: which of its crossings were consumed before time t?
         // x exit: y crossings with ty(b) <= t;  y exit: x crossings with tx(b) < t.
@@ -235,6 +229,7 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
             iy = sy > 0 ? By : By - 1;
             by = By + sy;
         }
+        if (occ(ix, iy)) return t * g.cell;
     }
 }
 
