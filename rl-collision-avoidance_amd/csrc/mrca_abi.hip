@@ -116,7 +116,7 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_beam_cos = take(B * 4);
     L->off_beam_sin = take(B * 4);
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
-    L->off_skip = take((size_t)((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) *
+    L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 3) & ~3) *
                        ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK));
     L->total = off;
 }
@@ -231,9 +231,9 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_map, cfg->map_bits,
                            (size_t)cfg->map_height * cfg->map_words_per_row * 4, hipMemcpyHostToDevice));
     std::vector<uint8_t> skip;
-    int skip_cw = 0, skip_ch = 0;
+    int skip_cw = 0, skip_ch = 0, skip_pitch = 0;
     mrca::build_skip_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &skip, &skip_cw,
-                           &skip_ch);
+                           &skip_ch, &skip_pitch);
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
     // live = 1, t = 1 at construction (a robot exists and is idle before the first reset)
     HIP_TRY_BAIL(hipMemset(env->arena + L.field_off[MRCA_F_LIVE], 1, N));
@@ -281,6 +281,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.skip = reinterpret_cast<const uint8_t*>(a + L.off_skip);
     v.skip_cw = skip_cw;
     v.skip_ch = skip_ch;
+    v.skip_pitch = skip_pitch;
     // blocks needed to cover the footprint's circumradius sqrt(0.22^2 + 0.19^2) = 0.2907 m (+ one
     // cell of slack for the start cells of the outline walks)
     v.foot_r = (int32_t)std::ceil((0.2907 + cfg->map_cell) / (mrca::kSkipK * (double)cfg->map_cell));
@@ -308,7 +309,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.tile_lg = 0;
     while ((1 << v.tile_lg) < v.tile_stride) ++v.tile_lg;
     v.ctile_lg = 0;
-    while ((1 << v.ctile_lg) < v.ctile_stride) ++v.ctile_lg;
+    while ((1 << v.ctile_lg) < v.ctile_stride / 4) ++v.ctile_lg;  // staged as 32-bit words
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.debug_flags = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);

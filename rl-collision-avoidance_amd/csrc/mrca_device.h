@@ -161,10 +161,10 @@ constexpr int kSkipK = 1 << kSkipShift;
 
 struct GlobalDist {  // coarse free-distance field straight from global memory
     const uint8_t* d;
-    int32_t cw, ch;
+    int32_t cw, ch, pitch;
     MRCA_HD int operator()(int cx, int cy) const {
         if (cx < 0 || cy < 0 || cx >= cw || cy >= ch) return 1;  // outside the map: that block is free
-        return d[cy * cw + cx];
+        return d[cy * pitch + cx];
     }
 };
 

@@ -12,8 +12,10 @@ namespace mrca {
 // Coarse free-distance field for grid_march_skip: blocks of kSkipK x kSkipK cells;
 // out[cy*cw+cx] = Chebyshev distance in blocks to the nearest block holding an occupied cell
 // (0 = this block is not empty), saturated at 255.  Two-pass chamfer, exact for L-infinity.
+// Rows are padded to a multiple of 4 blocks with the value 1 ("that block is free") so that a
+// kernel can fetch four blocks per 32-bit load; *pitch_out is the padded row length.
 inline void build_skip_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint8_t>* out,
-                             int* cw_out, int* ch_out) {
+                             int* cw_out, int* ch_out, int* pitch_out = nullptr) {
     const int cw = (width + kSkipK - 1) / kSkipK, ch = (height + kSkipK - 1) / kSkipK;
     std::vector<int> d((size_t)cw * ch, 255);
     for (int y = 0; y < height; ++y)
@@ -39,10 +41,13 @@ inline void build_skip_field(const uint32_t* bits, int width, int height, int wp
             m = std::min(m, std::min(std::min(at(x + 1, y + 1), at(x, y + 1)), std::min(at(x - 1, y + 1), at(x + 1, y))) + 1);
             d[(size_t)y * cw + x] = std::min(m, 255);
         }
-    out->resize((size_t)cw * ch);
-    for (size_t i = 0; i < d.size(); ++i) (*out)[i] = (uint8_t)d[i];
+    const int pitch = pitch_out ? ((cw + 3) & ~3) : cw;
+    out->assign((size_t)pitch * ch, 1);
+    for (int y = 0; y < ch; ++y)
+        for (int x = 0; x < cw; ++x) (*out)[(size_t)y * pitch + x] = (uint8_t)d[(size_t)y * cw + x];
     *cw_out = cw;
     *ch_out = ch;
+    if (pitch_out) *pitch_out = pitch;
 }
 
 }  // namespace mrca

@@ -42,7 +42,7 @@ struct EnvView {
     // occupancy grid + coarse free-distance field (grid_march_skip)
     const uint32_t* map_bits;
     const uint8_t* skip;
-    int32_t skip_cw, skip_ch;
+    int32_t skip_cw, skip_ch, skip_pitch;  // pitch: padded row length (multiple of 4)
     int32_t foot_r;  // blocks that cover the robot's circumradius: dist > foot_r => footprint is free
     GridGeom g;
     // rules

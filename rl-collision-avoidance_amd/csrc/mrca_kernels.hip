@@ -159,60 +159,110 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     float ns, nc;
     sincos_det(nth, &ns, &nc);
     const bool moving = valid && ((v != 0.0f) || (w != 0.0f));
-    // outline-vs-grid test; skipped (same answer: free) when the coarse free-distance field says every
-    // block within the footprint's circumradius of the provisional centre is empty
-    bool shit = false;
-    if (valid) {
-        const GlobalDist dist{e.skip, e.skip_cw, e.skip_ch};
-        const int pcx = ((int)floorf((nx - e.g.x0) * e.g.inv_cell)) >> kSkipShift;
-        const int pcy = ((int)floorf((ny - e.g.y0) * e.g.inv_cell)) >> kSkipShift;
+
+    // --- outline-vs-grid test.  Skipped (same answer: free) when the coarse free-distance field says
+    //     every block within the footprint's circumradius of the provisional centre is empty.  For the
+    //     others the (2*hc+1)-row patch under the footprint is pulled into LDS by the WHOLE wave, four
+    //     robots' loads in flight at a time, and each robot then walks its outline in LDS.
+    const int hc = e.foot_hc;
+    const int prow = 2 * hc + 1;
+    const int pwords = (prow + 31) / 32 + 1;
+    const int psize = prow * pwords;
+    const int pix = (int)floorf((nx - e.g.x0) * e.g.inv_cell);
+    const int piy = (int)floorf((ny - e.g.y0) * e.g.inv_cell);
+    const int py0 = piy - hc;
+    const int pw0 = (pix - hc) >> 5;
+    bool need = false;
+    if (valid && !(e.debug_flags & 8)) {
+        const GlobalDist dist{e.skip, e.skip_cw, e.skip_ch, e.skip_pitch};
+        const int pcx = pix >> kSkipShift, pcy = piy >> kSkipShift;
         const bool inside = pcx >= 0 && pcy >= 0 && pcx < e.skip_cw && pcy < e.skip_ch;
-        if (!(inside && dist(pcx, pcy) > e.foot_r) && !(e.debug_flags & 8)) {
-            // pull the (2*hc+1)-row patch under the footprint into LDS with independent loads (one
-            // latency round trip instead of ~40 dependent ones), then walk the outline in LDS
-            const int hc = e.foot_hc;
-            const int rows = 2 * hc + 1;
-            const int words = (rows + 31) / 32 + 1;
-            const int pix = (int)floorf((nx - e.g.x0) * e.g.inv_cell);
-            const int piy = (int)floorf((ny - e.g.y0) * e.g.inv_cell);
-            const int y0 = piy - hc;
-            const int w0 = (pix - hc) >> 5;
-            uint32_t* mt = mini + lane * rows * words;
-            for (int r = 0; r < rows; ++r) {
-                const int gy = y0 + r;
-                for (int wi = 0; wi < words; ++wi) {
-                    const int gw = w0 + wi;
-                    uint32_t val = 0u;
-                    if (gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val = e.map_bits[gy * e.g.wpr + gw];
-                    mt[r * words + wi] = val;
-                }
+        need = !(inside && dist(pcx, pcy) > e.foot_r);
+    }
+    {
+        unsigned long long todo = __ballot(need);
+        while (todo) {
+            int src[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                src[q] = todo ? (__ffsll((long long)todo) - 1) : -1;
+                if (todo) todo &= todo - 1;
             }
-            const MiniGrid mg{mt, y0, w0, words};
-            shit = static_hit(mg, e.g, nx, ny, ns, nc);
+            for (int k0 = 0; k0 < psize; k0 += kWave) {
+                const int k = k0 + lane;
+                const int r = k / pwords, wi = k - r * pwords;
+                uint32_t val[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    val[q] = 0u;
+                    if (src[q] >= 0 && k < psize) {
+                        const int gy = ibcast(py0, src[q]) + r;
+                        const int gw = ibcast(pw0, src[q]) + wi;
+                        if (gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val[q] = e.map_bits[gy * e.g.wpr + gw];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (src[q] >= 0 && k < psize) mini[src[q] * psize + k] = val[q];
+            }
         }
     }
+    __syncthreads();  // one wave per block: orders the cooperative LDS writes before the per-lane reads
+    bool shit = false;
+    if (need) {
+        const MiniGrid mg{mini + lane * psize, py0, pw0, pwords};
+        shit = static_hit(mg, e.g, nx, ny, ns, nc);
+    }
 
-    // collision pass in robot order; (x,y,s,c) always holds the lane's CURRENT pose
-    bool moved = false;
+    // --- collision pass in robot order (Stage's sequential model loop).  Broad phase first: robot i
+    //     can only touch robot j if its provisional centre comes within 2 x circumradius of j's old or
+    //     new centre, so only the (few) robots with such a neighbour take a turn in the ordered pass;
+    //     everybody else commits straight away -- their outcome does not depend on the order.
+    bool involved = false;
+    if (!(e.debug_flags & 16)) {
+        for (int j = 0; j < e.R; ++j) {
+            const float ax = nx - bcast(x, j), ay = ny - bcast(y, j);
+            const float bx2 = nx - bcast(nx, j), by2 = ny - bcast(ny, j);
+            const float d_old = ax * ax + ay * ay, d_new = bx2 * bx2 + by2 * by2;
+            if (j != lane && (d_old <= 0.3392f || d_new <= 0.3392f)) involved = true;  // (2*0.2907 + 0.001)^2
+        }
+        involved = involved && valid;
+    }
+    // committed pose of a robot that is not involved: moves unless the map stops it
+    const float ox_ = x, oy_ = y, os_ = s, oc_ = c;  // pose at tick start
+    bool moved = moving && !involved && !shit;
     uint8_t crashed = e.crashed[n];
-    for (int i = 0; i < ((e.debug_flags & 16) ? 0 : e.R); ++i) {
-        const float xi = bcast(nx, i);
-        const float yi = bcast(ny, i);
-        const float si = bcast(ns, i);
-        const float ci = bcast(nc, i);
-        const bool ov = valid && (lane != i) && obb_overlap(xi, yi, si, ci, x, y, s, c);
-        const unsigned long long m = __ballot(ov);
-        if (lane == i && moving) {
-            const bool hit = shit || (m != 0ull);
-            if (!hit) {
-                x = nx;
-                y = ny;
-                th = nth;
-                s = ns;
-                c = nc;
-                moved = true;
+    if (moving && !involved) crashed = shit ? 1 : 0;
+    if (moved) {
+        x = nx;
+        y = ny;
+        th = nth;
+        s = ns;
+        c = nc;
+    }
+    {
+        unsigned long long turn = __ballot(involved);
+        while (turn) {
+            const int i = __ffsll((long long)turn) - 1;
+            turn &= turn - 1;
+            const float xi = bcast(nx, i), yi = bcast(ny, i), si = bcast(ns, i), ci = bcast(nc, i);
+            // robots after i in the order have not moved yet when i is tested
+            const bool later = lane > i;
+            const float cx_ = later ? ox_ : x, cy_ = later ? oy_ : y, cs_ = later ? os_ : s, cc_ = later ? oc_ : c;
+            const bool ov = valid && (lane != i) && obb_overlap(xi, yi, si, ci, cx_, cy_, cs_, cc_);
+            const unsigned long long m = __ballot(ov);
+            if (lane == i && moving) {
+                const bool hit = shit || (m != 0ull);
+                if (!hit) {
+                    x = nx;
+                    y = ny;
+                    th = nth;
+                    s = ns;
+                    c = nc;
+                    moved = true;
+                }
+                crashed = hit ? 1 : 0;
             }
-            crashed = hit ? 1 : 0;
         }
     }
 
@@ -272,10 +322,10 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     int ep = e.episode[n];
     const int rmode = valid ? e.reset_mode[lane] : 0;
     const int gmode = valid ? e.goal_mode[lane] : 0;
-    unsigned long long need = __ballot(fresh);
-    while (need) {
-        const int src = __ffsll((long long)need) - 1;
-        need &= need - 1;
+    unsigned long long pending = __ballot(fresh);
+    while (pending) {
+        const int src = __ffsll((long long)pending) - 1;
+        pending &= pending - 1;
         const int nsrc = world * e.R + src;
         const uint32_t eps = (uint32_t)(ibcast(ep, src) + 1);
         const int rm = ibcast(rmode, src), gm = ibcast(gmode, src);
@@ -388,7 +438,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     float4* nb = reinterpret_cast<float4*>(lds + ((tile_words + 3) & ~3));
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
-    uint8_t* ctile = reinterpret_cast<uint8_t*>(nb_count + 4);
+    float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
+    uint8_t* ctile = reinterpret_cast<uint8_t*>(rbuf + e.B);
 
     const int world = n / e.R;
     const int local = n - world * e.R;
@@ -416,15 +467,18 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             if (colok && gy >= 0 && gy < e.g.height) val = e.map_bits[gy * e.g.wpr + gw];
             if (wi < tw) tile[r * e.tile_stride + wi] = val;
         }
-        // coarse free-distance tile (bytes) over the same region; blocks outside the map are free (1)
-        const int ci = tid & ((1 << e.ctile_lg) - 1);
-        const int gx = cx0 + ci;
-        const bool ccolok = ci < ctw && gx >= 0 && gx < e.skip_cw;
+        // coarse free-distance tile over the same region, four blocks per 32-bit load (cx0 and the
+        // field's row pitch are multiples of 4); blocks outside the map are free (1)
+        const int cwi = tid & ((1 << e.ctile_lg) - 1);
+        const int gx = cx0 + 4 * cwi;
+        const bool ccolok = 4 * cwi < ctw && gx >= 0 && gx < e.skip_pitch;
+        const uint32_t* skip32 = reinterpret_cast<const uint32_t*>(e.skip);
+        uint32_t* ctile32 = reinterpret_cast<uint32_t*>(ctile);
         for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
             const int gy = cy0 + r;
-            uint8_t val = 1;
-            if (ccolok && gy >= 0 && gy < e.skip_ch) val = e.skip[gy * e.skip_cw + gx];
-            if (ci < ctw) ctile[r * e.ctile_stride + ci] = val;
+            uint32_t val = 0x01010101u;
+            if (ccolok && gy >= 0 && gy < e.skip_ch) val = skip32[(gy * e.skip_pitch + gx) >> 2];
+            if (4 * cwi < ctw) ctile32[r * (e.ctile_stride >> 2) + cwi] = val;
         }
     }
 
@@ -472,15 +526,22 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     }
     rng = rng < kRangeMax ? rng : kRangeMax;
 
-    // --- scan, normalised observation (stage_world1.py:140), frame stack (ppo_stage1.py:59-60,87-89)
-    e.scan[(size_t)n * e.B + tid] = rng;
-    const float o = rng / 6.0f - 0.5f;
-    float* ob = e.obs + (size_t)n * e.F * e.B + tid;
-    if (fresh) {
-        for (int f = 0; f < e.F; ++f) ob[f * e.B] = o;
-    } else {
-        for (int f = 0; f + 1 < e.F; ++f) ob[f * e.B] = ob[(f + 1) * e.B];
-        ob[(e.F - 1) * e.B] = o;
+    // --- scan, normalised observation (stage_world1.py:140), frame stack (ppo_stage1.py:59-60,87-89):
+    //     ranges go through LDS so that a quarter of the threads can move 16 bytes each
+    rbuf[tid] = rng;
+    __syncthreads();
+    if (tid < (e.B >> 2)) {
+        const float4 r4 = reinterpret_cast<const float4*>(rbuf)[tid];
+        const float4 o4 = make_float4(r4.x / 6.0f - 0.5f, r4.y / 6.0f - 0.5f, r4.z / 6.0f - 0.5f, r4.w / 6.0f - 0.5f);
+        reinterpret_cast<float4*>(e.scan + (size_t)n * e.B)[tid] = r4;
+        float4* ob = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B) + tid;
+        const int fstride = e.B >> 2;
+        if (fresh) {
+            for (int f = 0; f < e.F; ++f) ob[f * fstride] = o4;
+        } else {
+            for (int f = 0; f + 1 < e.F; ++f) ob[f * fstride] = ob[(f + 1) * fstride];
+            ob[(e.F - 1) * fstride] = o4;
+        }
     }
     if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
         const float gx = e.goal[n * 2 + 0] - x, gy = e.goal[n * 2 + 1] - y;
@@ -515,7 +576,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 
 size_t ray_lds_bytes(const EnvView& e) {
     const size_t tile_words = (size_t)e.tile_h * e.tile_stride;
-    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * (sizeof(float4) + sizeof(int2)) + 16 +
+    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 4 +
            (size_t)e.ctile_h * e.ctile_stride;
 }
 

@@ -89,7 +89,7 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
     std::vector<uint8_t> skipf;
     int scw, sch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch);
-    const GlobalDist dist{skipf.data(), scw, sch};
+    const GlobalDist dist{skipf.data(), scw, sch, scw};
     for (int n = 0; n < e->N; ++n) {
         const bool fresh = e->fresh[n] != 0;
         if (only_fresh && !fresh) continue;
@@ -163,7 +163,7 @@ void emul_step(const EmulEnv* e, const float* actions) {
     std::vector<uint8_t> skipf;
     int scw, sch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch);
-    const GlobalDist dist{skipf.data(), scw, sch};
+    const GlobalDist dist{skipf.data(), scw, sch, scw};
     const int foot_r = (int)ceil((0.2907 + (double)e->cell) / (kSkipK * (double)e->cell));
     std::vector<float> x(R), y(R), th(R), s(R), c(R), nx(R), ny(R), nth(R), ns(R), nc(R), v(R), w(R);
     std::vector<char> moving(R), shit(R), moved(R), livev(R), done_now(R);
@@ -279,7 +279,7 @@ void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const
     std::vector<uint8_t> f;
     int cw, ch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch);
-    const GlobalDist dist{f.data(), cw, ch};
+    const GlobalDist dist{f.data(), cw, ch, cw};
     for (int i = 0; i < n; ++i) {
         out_plain[i] = grid_march(occ, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
         out_skip[i] = grid_march_skip(occ, dist, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
