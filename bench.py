@@ -28,11 +28,27 @@ for p in (os.path.join(ROOT, "rl-collision-avoidance_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# MIOpen's exhaustive first-call search costs tens of seconds per new conv shape (profiles/
+# r01_f_ppo_update_profile.txt); the fast find mode keeps the policy legs of this bench within minutes.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_AGENT_STEP = 10332   # SURVEY 8(d) B_env_stack: 2140 + frame-stack shift (4096 read + 4096 write)
+
+
+def pmc_traffic(robots):
+    """HBM bytes per raycast_kernel launch from the committed rocprofv3 PMC passes (profiles/
+    pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in KiB per launch at the profiled robot count,
+    FETCH doubled per MI355X_MICROARCH.md's gfx950 correction), scaled linearly to `robots`."""
+    f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    per_robot = (2.0 * d["fetch_kib"] + d["write_kib"]) * 1024.0 / d["robots"]
+    return per_robot * robots
 
 
 def cpu_baseline(robots_per_world, seconds_target=12.0):
@@ -116,6 +132,12 @@ def main():
         from mrca.trainer import make_bench_step
         step_fn = make_bench_step(env, args.mode, dist)
 
+    if args.mode == "train":
+        # warm-up must cover whole horizons so that MIOpen tuning / allocator growth of the FIRST update
+        # happen outside the timed region, and the timed region holds whole updates only
+        hz = 128
+        args.warmup = max(hz, (args.warmup + hz - 1) // hz * hz)
+        args.steps = max(hz, (args.steps + hz - 1) // hz * hz)
     env.reset()
     for k in range(args.warmup):
         step_fn(k)
@@ -150,7 +172,9 @@ def main():
                                    f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}",
                        "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode},
             "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(N),
+                         "traffic_note": "bytes/launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; "
+                                         "2*FETCH_SIZE + WRITE_SIZE)",
                          "bytes_per_agent_step": BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
                          "launches_timed": launches,
