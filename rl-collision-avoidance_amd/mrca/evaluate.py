@@ -1,0 +1,94 @@
+"""Circle-test evaluator: the reference's ``circle_test.py`` demo loop (``enjoy``, :36-83) for any
+number of independent 50-robot circles, with the success metric the reference never computes.
+
+Success rate (decision 12): fraction of robots whose FIRST terminal event since reset is
+"Reach Goal" -- latched on the device in ``first_result`` (the reference does not latch,
+circle_test.py:64-70).  Also reported: crash rate, unfinished rate, mean ticks-to-goal of the
+successful robots and their mean path length ratio vs the 50 m straight line.
+"""
+import argparse
+import json
+import math
+
+import torch
+
+from . import ppo, scenario
+from .net import CNNPolicy
+
+ACTION_BOUND = ((0.0, -1.0), (1.0, 1.0))     # circle_test.py:92
+
+
+def go_to_goal_policy(obs, local_goal, speed):
+    """Stand-in controller (no learning): drive at the goal, turn towards it, slow down when the
+    lidar sees something close ahead.  Used where ``policy/stage2.pth`` is unavailable."""
+    lx, ly = local_goal[:, 0], local_goal[:, 1]
+    bearing = torch.atan2(ly, lx)
+    ahead = (obs[:, -1, 192:320].min(dim=1).values + 0.5) * 6.0      # nearest return in the front 45 degrees
+    v = torch.clamp(0.4 * ahead, 0.0, 1.0) * (bearing.abs() < 1.0).float()
+    w = torch.clamp(2.0 * bearing, -1.0, 1.0)
+    return torch.stack([v, w], dim=1)
+
+
+def cnn_policy_fn(policy):
+    def fn(obs, local_goal, speed):
+        _mean, scaled = ppo.generate_action_no_sampling(policy, obs, local_goal, speed, ACTION_BOUND)
+        return scaled
+    return fn
+
+
+def circle_test(env, policy_fn, max_ticks=1200):
+    """Runs the circle scenario on ``env`` (any object with the VecStageWorld surface) and returns
+    the metrics dict.  Mirrors circle_test.py:52-80: deterministic action, and a robot whose last
+    ``get_reward_and_terminate`` said terminal gets v = 0 (``real_action[0] = 0``, :64-65)."""
+    env.reset()
+    N = env.N
+    dev = env.obs.device
+    ticks_to_goal = torch.zeros(N, device=dev)
+    path = torch.zeros(N, device=dev)
+    last_terminal = torch.zeros(N, dtype=torch.bool, device=dev)
+    for k in range(max_ticks):
+        a = policy_fn(env.obs, env.local_goal, env.speed).float().clone()
+        a[:, 0] = torch.where(last_terminal, torch.zeros_like(a[:, 0]), a[:, 0])
+        pending = env.first_result == 0
+        env.step(a.contiguous())
+        last_terminal = env.done.bool().clone()
+        path += torch.where(pending, env.speed_gt[:, 0] * 0.1, torch.zeros_like(path))
+        ticks_to_goal += pending.float()
+        if bool((env.first_result != 0).all()):
+            break
+    fr = env.first_result
+    reach = fr == 1
+    n_reach = int(reach.sum())
+    return {
+        "robots": N, "ticks_run": k + 1,
+        "success_rate": n_reach / N,
+        "crash_rate": float((fr == 2).float().mean()),
+        "timeout_rate": float((fr == 3).float().mean()),
+        "unfinished_rate": float((fr == 0).float().mean()),
+        "mean_ticks_to_goal": float(ticks_to_goal[reach].mean()) if n_reach else None,
+        "mean_path_ratio": float((path[reach] / 50.0).mean()) if n_reach else None,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser(description="circle test (circle_test.py) at scale on the MI355X env")
+    ap.add_argument("--circles", type=int, default=1, help="independent 50-robot circles (50 -> 50 000 robots: 1000)")
+    ap.add_argument("--policy", default=None, help="state_dict file with the reference's keys (policy/stage2.pth)")
+    ap.add_argument("--max-ticks", type=int, default=1200)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    from .vec_env import VecStageWorld
+    env = VecStageWorld(scenario.circle(num_worlds=a.circles, seed=a.seed))
+    if a.policy:
+        pol = CNNPolicy(3, 2).to(env.device)
+        pol.load_state_dict(torch.load(a.policy, map_location=env.device))
+        fn, name = cnn_policy_fn(pol), a.policy
+    else:
+        fn, name = go_to_goal_policy, "go-to-goal stand-in (no checkpoint given)"
+    out = circle_test(env, fn, a.max_ticks)
+    out["policy"] = name
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
