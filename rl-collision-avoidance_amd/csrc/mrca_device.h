@@ -168,11 +168,11 @@ struct GlobalDist {  // coarse free-distance field straight from global memory
     }
 };
 
-// Flat, branch-poor form (one loop, one "event" per iteration, x/y handled by selects) so the 64
-// rays of a wavefront stay in lock step: an iteration is either a jump to the face of the free box
-// (d >= 1) or a single cell step (d == 0, the "box" is the current cell).  No (tx, ty) state is
-// carried -- boundary times are always re-derived from the closed form, which is what makes every
-// path through here produce the same numbers as grid_march.
+// Flat, branch-poor form (one loop, one "event" per iteration, x/y handled by selects and sign
+// arithmetic) so the 64 rays of a wavefront stay in lock step: an iteration is either a jump to
+// the face of the free box (d >= 1) or a single cell step (d == 0, the "box" is the current cell).
+// No (tx, ty) state is carried -- boundary times are always re-derived from the closed form, which
+// is what makes every path through here produce the same numbers as grid_march.
 template <class Occ, class Dist>
 MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& g, float ox, float oy, float dx,
                               float dy, float tmax) {
@@ -186,18 +186,26 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
     const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
     const float inv_dx = xnz ? 1.0f / dx : kInf;
     const float inv_dy = ynz ? 1.0f / dy : kInf;
-    const int sx = dx > 0.0f ? 1 : -1;
-    const int sy = dy > 0.0f ? 1 : -1;
-    int bx = dx > 0.0f ? ix + 1 : ix;  // next pending boundary on each axis
-    int by = dy > 0.0f ? iy + 1 : iy;
+    const bool xpos = dx > 0.0f, ypos = dy > 0.0f;
+    const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
+    const int mx = xpos ? 0 : -1, my = ypos ? 0 : -1;      // (v ^ m) - m  ==  s * v
+    const int facex = xpos ? 0 : kSkipK, facey = ypos ? 0 : kSkipK;  // box face = (c << K) + s*(d << K) + face
+    int bx = ix + (xpos ? 1 : 0);  // next pending boundary on each axis; cell = boundary + m once crossed
+    int by = iy + (ypos ? 1 : 0);
     for (;;) {
         const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
         const int d = dist(cx, cy);
+        const bool jump = d != 0;
+        const int dk = d << kSkipShift;
         // faces of the region known to be free: the (2d-1)^2-block box, or just this cell
-        const int Bx = d ? (sx > 0 ? ((cx + d) << kSkipShift) : ((cx - d + 1) << kSkipShift)) : bx;
-        const int By = d ? (sy > 0 ? ((cy + d) << kSkipShift) : ((cy - d + 1) << kSkipShift)) : by;
-        const float tBx = xnz ? ((float)Bx - fx) * inv_dx : kInf;
-        const float tBy = ynz ? ((float)By - fy) * inv_dy : kInf;
+        const int boxx = (cx << kSkipShift) + ((dk ^ mx) - mx) + facex;
+        const int boxy = (cy << kSkipShift) + ((dk ^ my) - my) + facey;
+        const int Bx = jump ? boxx : bx;
+        const int By = jump ? boxy : by;
+        const float rawx = ((float)Bx - fx) * inv_dx;
+        const float rawy = ((float)By - fy) * inv_dy;
+        const float tBx = xnz ? rawx : kInf;
+        const float tBy = ynz ? rawy : kInf;
         const bool xe = tBx < tBy;  // leaves through the x face (ties: y first)
         const float t = xe ? tBx : tBy;
         if (t >= tmax_c) return tmax;
@@ -208,27 +216,33 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
         const int sS = xe ? sy : sx;
         const int bS0 = xe ? by : bx;
         int bS = bS0;
-        if (d && (xe ? ynz : xnz)) {
+        if (jump & (xe ? ynz : xnz)) {
             const float pT = fS + (xe ? dy : dx) * t;  // estimate only; corrected exactly below
-            int b = sS > 0 ? (int)floorf(pT) + 1 : (int)ceilf(pT) - 1;
+            int b = (int)floorf(pT) + (sS > 0 ? 1 : 0);
             b = sS > 0 ? (b < bS0 ? bS0 : b) : (b > bS0 ? bS0 : b);
-#define MRCA_CONSUMED(bb) (xe ? ((((float)(bb)-fS) * invS) <= t) : ((((float)(bb)-fS) * invS) < t))
-            while (b != bS0 && !MRCA_CONSUMED(b - sS)) b -= sS;
-            while (MRCA_CONSUMED(b)) b += sS;
-#undef MRCA_CONSUMED
+            // consumed(bb): crossing bb happened before the exit event (ties decided by xe)
+            for (;;) {  // step back while the previous crossing was NOT consumed
+                const float tp = ((float)(b - sS) - fS) * invS;
+                const bool cons = (tp < t) | ((tp == t) & xe);
+                if ((b == bS0) | cons) break;
+                b -= sS;
+            }
+            for (;;) {  // step forward while this crossing WAS consumed
+                const float tc = ((float)b - fS) * invS;
+                const bool cons = (tc < t) | ((tc == t) & xe);
+                if (!cons) break;
+                b += sS;
+            }
             bS = b;
         }
-        if (xe) {
-            by = bS;
-            iy = sy > 0 ? by - 1 : by;
-            ix = sx > 0 ? Bx : Bx - 1;
-            bx = Bx + sx;
-        } else {
-            bx = bS;
-            ix = sx > 0 ? bx - 1 : bx;
-            iy = sy > 0 ? By : By - 1;
-            by = By + sy;
-        }
+        // new cell and pending boundaries (for the secondary axis "cell = boundary + m" restates the
+        // invariant, for the exit axis the boundary is crossed)
+        const int nbx = xe ? Bx + sx : bS;
+        const int nby = xe ? bS : By + sy;
+        ix = (xe ? Bx : nbx - sx) + mx;   // xe: cell just across Bx;  else: cell before pending bx
+        iy = (xe ? nby - sy : By) + my;
+        bx = nbx;
+        by = nby;
         if (occ(ix, iy)) return t * g.cell;
     }
 }

@@ -28,14 +28,16 @@ struct TileGrid {  // occupancy lookups in the LDS tile (no bounds checks: margi
     const uint32_t* tile;
     int y0, w0, stride;
     __device__ __forceinline__ bool operator()(int ix, int iy) const {
-        return (tile[(iy - y0) * stride + ((ix >> 5) - w0)] >> (ix & 31)) & 1u;
+        return (tile[__mul24(iy - y0, stride) + ((ix >> 5) - w0)] >> (ix & 31)) & 1u;
     }
 };
 
 struct TileDist {  // coarse free-distance lookups in LDS
     const uint8_t* d;
     int cy0, cx0, stride;
-    __device__ __forceinline__ int operator()(int cx, int cy) const { return d[(cy - cy0) * stride + (cx - cx0)]; }
+    __device__ __forceinline__ int operator()(int cx, int cy) const {
+        return d[__mul24(cy - cy0, stride) + (cx - cx0)];
+    }
 };
 
 __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
@@ -433,6 +435,16 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const bool fresh = e.fresh[n] != 0;
     if (only_fresh && !fresh) return;  // block-uniform
 
+    // the two frames that will be shifted down are fetched now, long before they are stored again
+    float4 keep1 = make_float4(0.f, 0.f, 0.f, 0.f), keep2 = keep1;
+    const bool wide = tid < (e.B >> 2);
+    const int fstride = e.B >> 2;
+    float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B) + tid;
+    if (wide && !fresh && e.F == 3) {
+        keep1 = ob4[fstride];
+        keep2 = ob4[2 * fstride];
+    }
+
     uint32_t* tile = lds;
     const int tile_words = e.tile_h * e.tile_stride;
     float4* nb = reinterpret_cast<float4*>(lds + ((tile_words + 3) & ~3));
@@ -482,6 +494,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
     }
 
+    __syncthreads();  // tile staged
+
     // --- first wave: compact the world's other robots within lidar reach into LDS, each with the
     //     (conservative) interval of beams that can touch it
     if (tid < kWave) {
@@ -506,8 +520,6 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
         if (tid == 0) *nb_count = (e.debug_flags & 1) ? 0 : __popcll(m);
     }
-    __syncthreads();
-
     // --- one beam per thread
     const TileGrid occ{tile, ty0, tw0, e.tile_stride};
     const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
@@ -515,6 +527,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const float dx = c * bc - s * bs;
     const float dy = s * bc + c * bs;
     float rng = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+    __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
     const int cnt = *nb_count;
     for (int k = 0; k < cnt; ++k) {
         const int2 iv = nbi[k];
@@ -530,14 +543,17 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     //     ranges go through LDS so that a quarter of the threads can move 16 bytes each
     rbuf[tid] = rng;
     __syncthreads();
-    if (tid < (e.B >> 2)) {
+    if (wide) {
         const float4 r4 = reinterpret_cast<const float4*>(rbuf)[tid];
         const float4 o4 = make_float4(r4.x / 6.0f - 0.5f, r4.y / 6.0f - 0.5f, r4.z / 6.0f - 0.5f, r4.w / 6.0f - 0.5f);
         reinterpret_cast<float4*>(e.scan + (size_t)n * e.B)[tid] = r4;
-        float4* ob = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B) + tid;
-        const int fstride = e.B >> 2;
+        float4* ob = ob4;
         if (fresh) {
             for (int f = 0; f < e.F; ++f) ob[f * fstride] = o4;
+        } else if (e.F == 3) {
+            ob[0] = keep1;
+            ob[fstride] = keep2;
+            ob[2 * fstride] = o4;
         } else {
             for (int f = 0; f + 1 < e.F; ++f) ob[f * fstride] = ob[(f + 1) * fstride];
             ob[(e.F - 1) * fstride] = o4;
