@@ -92,12 +92,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda is unavailable and there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    # test hooks (tests/test_gpu_bench_multirank.py): several ranks on ONE GPU over gloo, to exercise the
+    # multi-rank code path on a 1-GPU box; production is one rank per GPU over RCCL
+    same_device = os.environ.get("MRCA_BENCH_SAME_DEVICE") == "1"
+    backend = os.environ.get("MRCA_BENCH_BACKEND", "nccl")
+    dev_index = 0 if same_device else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world_size and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world_size}; using {world_size}", file=sys.stderr)
 

@@ -1,0 +1,55 @@
+"""GPU: bench.py's multi-rank path (barrier, max-over-ranks, whole-job aggregate) exercised with two
+ranks sharing the single GPU of the test box over gloo (test hook; production = one rank per GPU, RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_same_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MRCA_BENCH_SAME_DEVICE="1", MRCA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "50",
+           "--warmup", "10", "--worlds", "16", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 50 and j["scaling"] == "weak"
+    assert j["config"]["robots_per_gpu"] == 16 * 32
+    # whole-job aggregate: robots on all ranks x steps / max-rank time
+    assert abs(j["value"] - 2 * 16 * 32 * 50 / (j["ms_per_step"] * 1e-3 * 50)) / j["value"] < 1e-6
+
+
+def test_bench_single_rank_json_contract():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = subprocess.run([sys.executable, os.path.join(U.ROOT, "bench.py"), "--steps", "40", "--warmup", "5",
+                          "--worlds", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert j["vs_baseline"] is None and j["data"] == "synthetic" and "workload" in j["config"]
