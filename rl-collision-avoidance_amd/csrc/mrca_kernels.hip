@@ -520,28 +520,37 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
         if (tid == 0) *nb_count = (e.debug_flags & 1) ? 0 : __popcll(m);
     }
-    // --- one beam per thread
+    // --- beams: thread t takes beams t, t + blockDim, ... (one each in the default launch)
     const TileGrid occ{tile, ty0, tw0, e.tile_stride};
     const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
-    const float bc = e.beam_cos[tid], bs = e.beam_sin[tid];
-    const float dx = c * bc - s * bs;
-    const float dy = s * bc + c * bs;
-    float rng = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+    for (int b = tid; b < e.B; b += blockDim.x) {
+        const float bc = e.beam_cos[b], bs = e.beam_sin[b];
+        const float dx = c * bc - s * bs;
+        const float dy = s * bc + c * bs;
+        rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+    }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
     const int cnt = *nb_count;
-    for (int k = 0; k < cnt; ++k) {
-        const int2 iv = nbi[k];
-        if (tid >= iv.x && tid <= iv.y) {
-            const float4 q = nb[k];
-            const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
-            rng = t < rng ? t : rng;
+    for (int b = tid; b < e.B; b += blockDim.x) {
+        float rng = rbuf[b];
+        if (cnt > 0) {
+            const float bc = e.beam_cos[b], bs = e.beam_sin[b];
+            const float dx = c * bc - s * bs;
+            const float dy = s * bc + c * bs;
+            for (int k = 0; k < cnt; ++k) {
+                const int2 iv = nbi[k];
+                if (b >= iv.x && b <= iv.y) {
+                    const float4 q = nb[k];
+                    const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
+                    rng = t < rng ? t : rng;
+                }
+            }
         }
+        rbuf[b] = rng < kRangeMax ? rng : kRangeMax;
     }
-    rng = rng < kRangeMax ? rng : kRangeMax;
 
     // --- scan, normalised observation (stage_world1.py:140), frame stack (ppo_stage1.py:59-60,87-89):
     //     ranges go through LDS so that a quarter of the threads can move 16 bytes each
-    rbuf[tid] = rng;
     __syncthreads();
     if (wide) {
         const float4 r4 = reinterpret_cast<const float4*>(rbuf)[tid];
@@ -612,7 +621,8 @@ void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, con
 }
 
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
-    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B), ray_lds_bytes(e), s, e, only_fresh);
+    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B >> ((e.debug_flags >> 8) & 3)), ray_lds_bytes(e), s, e,
+                       only_fresh);
 }
 
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
