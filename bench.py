@@ -28,10 +28,6 @@ for p in (os.path.join(ROOT, "rl-collision-avoidance_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# MIOpen's exhaustive first-call search costs tens of seconds per new conv shape (profiles/
-# r01_f_ppo_update_profile.txt); the fast find mode keeps the policy legs of this bench within minutes.
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
-
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -312,9 +312,13 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     while ((1 << v.ctile_lg) < v.ctile_stride / 4) ++v.ctile_lg;  // staged as 32-bit words
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.debug_flags = 0;
+    // 256 threads per 512-beam robot (2 beams each): 8 resident workgroups per CU instead of 4 hide the
+    // per-robot latency chain (pose -> tile -> march -> store) better; measured 54.5 vs 62.0 us at 4096
+    // robots (profiles/r01_h_ablation.txt)
+    v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
-    if (mrca::move_lds_bytes(v) > 64 * 1024 || (1 << v.ctile_lg) > cfg->beams ||
-        (1 << v.tile_lg) > cfg->beams)
+    if (mrca::move_lds_bytes(v) > 64 * 1024 || (1 << v.ctile_lg) > (cfg->beams >> v.ray_shift) ||
+        (1 << v.tile_lg) > (cfg->beams >> v.ray_shift))
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
                          (double)cfg->map_cell));
     if (env->lds_bytes > 160 * 1024)
@@ -393,7 +397,16 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
-    env->view.debug_flags = flags;
+    env->view.debug_flags = flags & 0xFF;
+    const int knob = (flags >> 8) & 7;  // 0 keeps the default; k > 0 selects beams >> (k-1) threads per robot
+    if (knob) {
+        const int shift = knob - 1;
+        const int threads = env->cfg.beams >> shift;
+        if (threads < 64 || threads < (env->cfg.beams >> 2) || threads < (1 << env->view.ctile_lg) ||
+            threads < (1 << env->view.tile_lg))
+            return fail(MRCA_ERR_INVALID, "threads-per-robot knob %d out of range", knob);
+        env->view.ray_shift = shift;
+    }
     return MRCA_OK;
 }
 

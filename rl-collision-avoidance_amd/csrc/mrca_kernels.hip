@@ -621,7 +621,7 @@ void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, con
 }
 
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
-    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B >> ((e.debug_flags >> 8) & 3)), ray_lds_bytes(e), s, e,
+    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e,
                        only_fresh);
 }
 
