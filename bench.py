@@ -47,27 +47,41 @@ def pmc_traffic(robots):
     return per_robot * robots
 
 
-def cpu_baseline(robots_per_world, seconds_target=12.0):
-    """NumPy oracle, fp32 mode, one core, a bounded sample of the same Stage-1 workload."""
+def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
+    """The CPU port of the path timed on this box's host cores: the plain-C restatement of the oracle
+    (oracle/mrca_oracle_c.c, OpenMP over worlds and robots, all cores) on the SAME workload, for a
+    bounded number of ticks; the NumPy oracle's single-core figure is reported alongside."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util as U
     from mrca import scenario as S
-    worlds = 8
-    sc = S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=0)
-    ora = U.oracle_env(sc, np.float32)
-    ora.reset()
+    sc = S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=0) if sc_name == "stage1" else \
+        S.stage2(num_worlds=worlds, seed=0)
+    env = U.COracleEnv(sc)
+    threads = int(env.lib.oc_max_threads())
+    env.reset()
     rng = np.random.default_rng(1)
-    ora.step(U.random_actions(rng, sc.num_robots))
+    env.step(U.random_actions(rng, sc.num_robots))
     t0 = time.perf_counter()
     ticks = 0
-    while time.perf_counter() - t0 < seconds_target and ticks < 200:
-        ora.step(U.random_actions(rng, sc.num_robots))
+    while time.perf_counter() - t0 < seconds_target and ticks < 500:
+        env.step(U.random_actions(rng, sc.num_robots))
         ticks += 1
     dt = time.perf_counter() - t0
-    return {"value": sc.num_robots * ticks / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": f"NumPy oracle (fp32 mode), {worlds} Stage-1 rinks x {robots_per_world} robots x 512 beams, "
-                      f"{ticks} ticks in {dt:.1f} s on 1 host core"}
+    out = {"value": sc.num_robots * ticks / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+           "sample": f"C/OpenMP port of the oracle, {sc_name}: {worlds} worlds x {sc.robots_per_world} robots x 512 "
+                     f"beams (the GPU workload), {ticks} ticks in {dt:.1f} s on {threads} host threads"}
+    # NumPy oracle, one core, small sample
+    sc_s = S.stage1(num_worlds=4, robots_per_world=32, seed=0)
+    ora = U.oracle_env(sc_s, np.float32)
+    ora.reset()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 4.0:
+        ora.step(U.random_actions(rng, sc_s.num_robots))
+        n += 1
+    out["numpy_oracle_1core"] = sc_s.num_robots * n / (time.perf_counter() - t0)
+    return out
 
 
 def main():
@@ -185,7 +199,7 @@ def main():
                          "note": "HBM is the nominal roof (SURVEY 8d); the ray march is LDS/VALU bound, see DESIGN.md"},
         }
         if not args.no_cpu_baseline and world_size == 1:
-            out["cpu_baseline"] = cpu_baseline(sc.robots_per_world if args.scenario == "stage1" else 32)
+            out["cpu_baseline"] = cpu_baseline(args.scenario, args.worlds, args.robots_per_world)
             out["cpu_baseline"]["reference_structural_cap"] = "240 agent-steps/s (24 robots x 10 Hz, stageros.cpp:819-828)"
         out.update(extra)
         print(json.dumps(out))

@@ -216,3 +216,26 @@ def test_error_behaviour(hip):
     with pytest.raises(ValueError):
         env.step(torch.zeros(3, 2, device="cuda"))
     env.close()
+
+
+@pytest.mark.parametrize("name,worlds,R,steps", [("stage1", 128, 32, 24), ("stage2", 187, 44, 12)])
+def test_full_batch_bit_exact_vs_c_oracle(hip, name, worlds, R, steps):
+    """BASELINE configs[1]/[2] at FULL size, every robot, every field, bit-for-bit against the plain-C
+    restatement of the oracle (itself bit-identical to the NumPy oracle: tests/test_oracle_c.py)."""
+    sc = S.stage1(num_worlds=worlds, robots_per_world=R, seed=123) if name == "stage1" else S.stage2(num_worlds=worlds, seed=123)
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    env.reset()
+    ora.reset()
+    torch.cuda.synchronize()
+    U.assert_state_equal(U.HostView(env), ora, what=f"{name} full reset")
+    g = torch.Generator(device="cpu").manual_seed(2)
+    N = sc.num_robots
+    for k in range(steps):
+        a = torch.stack([torch.rand(N, generator=g), torch.rand(N, generator=g) * 2 - 1], 1).float()
+        env.step(a.cuda())
+        ora.step(a.numpy())
+        if k % 4 == 3 or k == steps - 1:
+            torch.cuda.synchronize()
+            U.assert_state_equal(U.HostView(env), ora, what=f"{name} full step {k}")
+    env.close()

@@ -190,3 +190,51 @@ class OracleBackend:
 
     def field(self, name):
         return np.asarray(getattr(self.env, name))
+
+
+# ------------------------------------------------------------------------------------------------
+class _OcEnvStruct(C.Structure):
+    _fields_ = _EmulEnvStruct._fields_ + [("first_world", C.c_int32)]
+
+
+_oc_lib = None
+
+
+def oracle_c_lib():
+    """oracle/libmrca_oracle_c.so (plain-C restatement of the oracle, OpenMP)."""
+    global _oc_lib
+    if _oc_lib is None:
+        d = os.path.join(ROOT, "oracle")
+        so = os.path.join(d, "libmrca_oracle_c.so")
+        src = os.path.join(d, "mrca_oracle_c.c")
+        if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", d])
+        _oc_lib = C.CDLL(so)
+        _oc_lib.oc_max_threads.restype = C.c_int
+    return _oc_lib
+
+
+class COracleEnv(EmulEnv):
+    """The C oracle behind the same numpy-array state as EmulEnv."""
+
+    def __init__(self, sc, first_world=0):
+        self.lib = oracle_c_lib()
+        EmulEnv.__init__(self, sc)
+        self.lib = oracle_c_lib()
+        st = _OcEnvStruct()
+        for name, _t in _EmulEnvStruct._fields_:
+            setattr(st, name, getattr(self._st, name))
+        st.first_world = first_world
+        self._st = st
+
+    def reset(self, mask=None, poses=None, goals=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        p = None if poses is None else np.ascontiguousarray(poses, np.float32)
+        g = None if goals is None else np.ascontiguousarray(goals, np.float32)
+        self.lib.oc_reset(C.byref(self._st), C.c_void_p(m.ctypes.data) if m is not None else None,
+                          C.c_void_p(p.ctypes.data) if p is not None else None,
+                          C.c_void_p(g.ctypes.data) if g is not None else None)
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, np.float32)
+        self.lib.oc_step(C.byref(self._st), C.c_void_p(a.ctypes.data))
