@@ -1,0 +1,148 @@
+"""Command-line trainer: the `__main__` blocks of ppo_stage1.py:137-204 / ppo_stage2.py:144-215 for the
+batched device env.
+
+    python -m mrca.train --stage 1 --worlds 128 --robots-per-world 32 --updates 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m mrca.train --stage 2 --worlds 187
+
+Kept from the reference: the three log streams under ./log/<hostname>/ (output.log episode lines,
+cal.log episode rewards, ppo.log "policy_loss, value_loss, entropy" per minibatch; ppo_stage1.py:
+140-162, model/ppo.py:10-19), checkpoints `policy/Stage1_{n}` / `policy/stage2_{n}.pth` every 20
+updates with the reference's state_dict keys (ppo_stage1.py:122-124), resume from
+`policy/stage1_2.pth` / `policy/stage2.pth` when present (ppo_stage1.py:185-191).
+Added: optimizer / step / RNG state next to each checkpoint (`*.state`) for exact resume, and
+agent-steps/s, success / crash / timeout rates per update.
+"""
+import argparse
+import logging
+import os
+import socket
+import sys
+import time
+
+import torch
+
+from . import scenario
+from .trainer import HParams, Stage1Trainer
+
+
+def _loggers(rank):
+    host = socket.gethostname()
+    d = os.path.join(".", "log", host)
+    os.makedirs(d, exist_ok=True)
+    fmt = logging.Formatter("%(asctime)s - %(levelname)s - %(message)s")
+    out = logging.getLogger("mylogger")
+    out.setLevel(logging.INFO)
+    if not out.handlers:
+        fh = logging.FileHandler(os.path.join(d, "output.log"), mode="a")
+        fh.setFormatter(fmt)
+        out.addHandler(fh)
+        if rank == 0:
+            out.addHandler(logging.StreamHandler(sys.stdout))
+    cal = logging.getLogger("loggercal")
+    cal.setLevel(logging.INFO)
+    if not cal.handlers:
+        cal.addHandler(logging.FileHandler(os.path.join(d, "cal.log"), mode="a"))
+    ppo_log = logging.getLogger("loggerppo")
+    ppo_log.setLevel(logging.INFO)
+    if not ppo_log.handlers:
+        ppo_log.addHandler(logging.FileHandler(os.path.join(d, "ppo.log"), mode="a"))
+    return out, cal, ppo_log
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--stage", type=int, default=1, choices=[1, 2])
+    ap.add_argument("--worlds", type=int, default=128, help="worlds per GPU")
+    ap.add_argument("--robots-per-world", type=int, default=24, help="stage 1 only (NUM_ENV, ppo_stage1.py:32)")
+    ap.add_argument("--updates", type=int, default=100)
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--policy-dir", default="policy")
+    ap.add_argument("--save-every", type=int, default=20)       # ppo_stage1.py:123
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    out, cal, ppo_log = _loggers(rank)
+
+    from .vec_env import VecStageWorld
+    if a.stage == 1:
+        sc = scenario.stage1(num_worlds=a.worlds, robots_per_world=a.robots_per_world, seed=a.seed * 1000 + rank)
+        hp = HParams()                                         # ppo_stage1.py:22-35
+        resume, pattern = "stage1_2.pth", "Stage1_{}"
+    else:
+        sc = scenario.stage2(num_worlds=a.worlds, seed=a.seed * 1000 + rank)
+        hp = HParams(batch_size=512, epoch=4)                  # ppo_stage2.py:28-29
+        resume, pattern = "stage2.pth", "stage2_{}.pth"
+    if a.batch_size:
+        hp.batch_size = a.batch_size
+    elif sc.num_robots * world_size > 64:
+        # the reference's 1024 / 512 assume 24 / 44 robots; keep ~3 minibatches per epoch per 3072 samples
+        hp.batch_size = max(hp.batch_size, sc.num_robots * world_size * hp.horizon // 64)
+    env = VecStageWorld(sc)
+    tr = Stage1Trainer(env, hp=hp, dist=dist, seed=a.seed, stage2=(a.stage == 2))
+    os.makedirs(a.policy_dir, exist_ok=True)
+    f = os.path.join(a.policy_dir, resume)
+    if os.path.exists(f):
+        out.info("############Loading Model########### %s", f)
+        tr.policy.load_state_dict(torch.load(f, map_location=env.device))
+        st = f + ".state"
+        if os.path.exists(st):
+            extra = torch.load(st, map_location=env.device)
+            tr.optimizer.load_state_dict(extra["optimizer"])
+            tr.global_update = extra["global_update"]
+            tr.gen.set_state(extra["generator"].cpu())
+    else:
+        out.info("############Start Training###########")
+
+    tr.start()
+    n_logged = 0
+    for _ in range(a.updates):
+        t0 = time.perf_counter()
+        ep_done = torch.zeros(3, device=env.device)
+        ep_reward = torch.zeros(env.N, device=env.device)
+        finished = []
+        for _t in range(hp.horizon):
+            tr.tick()
+            ep_reward += env.reward
+            d = env.done.bool()
+            if bool(d.any()):
+                finished.append(ep_reward[d].clone())
+                ep_reward[d] = 0
+                r = env.result[d]
+                ep_done += torch.stack([(r == 1).sum(), (r == 2).sum(), (r == 3).sum()]).float()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dist.all_reduce(ep_done)
+        tot = max(float(ep_done.sum()), 1.0)
+        for row in tr.loss_log[n_logged:]:
+            ppo_log.info("{}, {}, {}".format(*[float(x) for x in row]))
+        n_logged = len(tr.loss_log)
+        for rew in finished[-1:]:
+            for v in rew[:8].tolist():
+                cal.info(v)
+        out.info("update %05d  %.0f agent-steps/s  episodes %d  reach %.3f  crash %.3f  timeout %.3f",
+                 tr.global_update, env.N * world_size * hp.horizon / dt, int(tot), float(ep_done[0]) / tot,
+                 float(ep_done[1]) / tot, float(ep_done[2]) / tot)
+        if rank == 0 and tr.global_update % a.save_every == 0:
+            p = os.path.join(a.policy_dir, pattern.format(tr.global_update))
+            torch.save(tr.policy.state_dict(), p)
+            torch.save({"optimizer": tr.optimizer.state_dict(), "global_update": tr.global_update,
+                        "generator": tr.gen.get_state()}, p + ".state")
+            out.info("########################## model saved when update %d times#########################",
+                     tr.global_update)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

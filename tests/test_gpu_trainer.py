@@ -78,3 +78,26 @@ def test_checkpoint_roundtrip_reference_keys(hip, tmp_path):
         a = pol.mean_value(x, g, s)
         b = pol2.mean_value(x, g, s)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_train_cli_checkpoint_and_resume(hip, tmp_path, monkeypatch):
+    """python -m mrca.train: log streams, reference-named checkpoints, exact resume state."""
+    import os
+    from mrca import train
+    monkeypatch.chdir(tmp_path)
+    args = ["--stage", "1", "--worlds", "2", "--robots-per-world", "6", "--updates", "2", "--save-every", "1",
+            "--batch-size", "256"]
+    train.main(args)
+    assert os.path.exists(tmp_path / "policy" / "Stage1_1") and os.path.exists(tmp_path / "policy" / "Stage1_2.state")
+    logs = os.listdir(tmp_path / "log")
+    d = tmp_path / "log" / logs[0]
+    assert {"output.log", "cal.log", "ppo.log"} <= set(os.listdir(d))
+    lines = [ln for ln in open(d / "ppo.log").read().splitlines() if ln.strip()]
+    assert len(lines) == 2 * 2 * 6          # 2 updates x 2 epochs x ceil(1536/256)
+    assert all(len(ln.split(",")) == 3 for ln in lines)
+    # resume: the reference looks for policy/stage1_2.pth (ppo_stage1.py:185)
+    os.replace(tmp_path / "policy" / "Stage1_2", tmp_path / "policy" / "stage1_2.pth")
+    os.replace(tmp_path / "policy" / "Stage1_2.state", tmp_path / "policy" / "stage1_2.pth.state")
+    train.main(["--stage", "1", "--worlds", "2", "--robots-per-world", "6", "--updates", "1", "--save-every", "1",
+                "--batch-size", "256"])
+    assert os.path.exists(tmp_path / "policy" / "Stage1_3")      # global_update continued from 2
