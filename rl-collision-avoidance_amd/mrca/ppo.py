@@ -81,6 +81,14 @@ def get_filter_index(dones):
     return N * j + i
 
 
+def get_group_terminal(terminal_list, index, refer=(0, 6, 10, 15, 19, 24, 34, 44)):
+    """model/utils.py:81-87: True when every robot of `index`'s scenario group has terminated.  (The
+    batched env applies the same rule on the device: MRCA_AUTO_GROUP, move_kernel's group ballots.)"""
+    import bisect
+    r = bisect.bisect(list(refer), index)
+    return all(bool(t) for t in terminal_list[refer[r - 1]: refer[r]])
+
+
 # ---------------------------------------------------------------------------------------------
 class FlatGrads:
     """All parameter gradients as views of ONE contiguous bucket: a single RCCL all-reduce of

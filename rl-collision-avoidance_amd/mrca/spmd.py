@@ -38,6 +38,10 @@ class Runtime:
         self.coll_result = None
         self.alive = size
         self.errors = []
+        # ranks start one after another: rank r+1 begins when rank r first blocks (or exits), so the
+        # scripts' racy start-up code (os.makedirs, logging handlers) runs serially like it does when
+        # mpiexec staggers process start-up
+        self.first_block = [threading.Event() for _ in range(size)]
 
     # ---- quiescence / ticking (call with self.cv held)
     def _maybe_tick(self):
@@ -52,6 +56,7 @@ class Runtime:
 
     def sleep(self, needs_tick):
         """rospy.sleep: with a latched command, wait for the tick that consumes it."""
+        self.first_block[rank()].set()
         with self.cv:
             if self.shutdown:
                 raise KeyboardInterrupt
@@ -70,6 +75,7 @@ class Runtime:
 
     def collective(self, rank, value, combine):
         """All-rank rendezvous; ``combine(list_of_values)`` runs once, every rank gets its result."""
+        self.first_block[rank].set()
         with self.cv:
             if self.shutdown:
                 raise KeyboardInterrupt
@@ -102,6 +108,7 @@ class Runtime:
 
     def rank_exit(self, err=None):
         """A rank left its script: the remaining ranks' rendezvous / tick conditions shrink."""
+        self.first_block[rank()].set()
         with self.cv:
             self.alive -= 1
             if err is not None:
@@ -167,7 +174,14 @@ def run_script(path, nprocs, max_ticks=None, extra_argv=(), chdir=None):
     sys.path[:0] = [dropin, script_dir]
     for shadowed in ("rospy", "tf", "mpi4py", "mpi4py.MPI", "stage_world1", "stage_world2", "circle_world"):
         sys.modules.pop(shadowed, None)
+    for name in list(sys.modules):   # the reference's own package: import it afresh, like a new process would
+        if name == "model" or name.startswith("model."):   # (model/ppo.py:10-19 sets up ./log on import)
+            sys.modules.pop(name, None)
     sys.argv = [path, *extra_argv]
+    import builtins
+    import functools
+    if not hasattr(builtins, "reduce"):      # model/utils.py:85 calls the Python-2 builtin
+        builtins.reduce = functools.reduce
     if chdir:
         os.chdir(chdir)
     _runtime = rt = Runtime(nprocs, max_ticks)
@@ -175,6 +189,8 @@ def run_script(path, nprocs, max_ticks=None, extra_argv=(), chdir=None):
     def body(r):
         _tls.rank = r
         err = None
+        if r > 0:
+            rt.first_block[r - 1].wait()
         try:
             runpy.run_path(path, run_name="__main__")
         except SystemExit:

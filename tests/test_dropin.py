@@ -85,3 +85,29 @@ def test_mini_script_hip_backend_matches_oracle_backend():
     for a, b in zip(ref, got):
         assert len(a) > 10 and len(b) > 10
         assert {row[4] for row in b} <= {"0", "Reach Goal", "Crashed", "Time out"}
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ppo_stage2.py")), reason="reference checkout absent")
+def test_unchanged_ppo_stage2_runs(monkeypatch):
+    """44 ranks of the UNCHANGED ppo_stage2.py (group-synchronous episodes, liveflag, bcast,
+    get_group_terminal with the py2 `reduce`) on the drop-ins."""
+    from mrca import spmd, stage_world
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    stage_world.set_backend_factory(U.OracleBackend)
+    tmp = tempfile.mkdtemp()
+    try:
+        errs = spmd.run_script(os.path.join(REF, "ppo_stage2.py"), 44, max_ticks=30, chdir=tmp)
+    finally:
+        stage_world.set_backend_factory(None)
+    assert not errs, errs
+
+
+def test_get_group_terminal_matches_reference_rule():
+    from mrca import ppo
+    t = [False] * 44
+    for i in range(6, 10):
+        t[i] = True
+    assert ppo.get_group_terminal(t, 7) and not ppo.get_group_terminal(t, 3) and not ppo.get_group_terminal(t, 12)
+    t[5] = True
+    assert not ppo.get_group_terminal(t, 0)
