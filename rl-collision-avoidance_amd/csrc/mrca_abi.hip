@@ -38,7 +38,7 @@ struct Layout {
     size_t field_off[MRCA_F_COUNT];
     size_t field_bytes[MRCA_F_COUNT];
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
-    size_t off_beam_cos, off_beam_sin, off_map, off_skip;
+    size_t off_beam_cos, off_beam_sin, off_map, off_skip, off_cellfield;
     size_t total;
 };
 
@@ -118,6 +118,7 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
     L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 3) & ~3) *
                        ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK));
+    L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->total = off;
 }
 
@@ -235,6 +236,11 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     mrca::build_skip_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &skip, &skip_cw,
                            &skip_ch, &skip_pitch);
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<uint8_t> cf;
+        mrca::build_cell_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &cf);
+        HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_cellfield, cf.data(), cf.size(), hipMemcpyHostToDevice));
+    }
     // live = 1, t = 1 at construction (a robot exists and is idle before the first reset)
     HIP_TRY_BAIL(hipMemset(env->arena + L.field_off[MRCA_F_LIVE], 1, N));
     {
@@ -282,6 +288,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.skip_cw = skip_cw;
     v.skip_ch = skip_ch;
     v.skip_pitch = skip_pitch;
+    v.cellfield = reinterpret_cast<const uint8_t*>(a + L.off_cellfield);
     // blocks needed to cover the footprint's circumradius sqrt(0.22^2 + 0.19^2) = 0.2907 m (+ one
     // cell of slack for the start cells of the outline walks)
     v.foot_r = (int32_t)std::ceil((0.2907 + cfg->map_cell) / (mrca::kSkipK * (double)cfg->map_cell));

@@ -192,9 +192,9 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
     const int facex = xpos ? 0 : kSkipK, facey = ypos ? 0 : kSkipK;  // box face = (c << K) + s*(d << K) + face
     int bx = ix + (xpos ? 1 : 0);  // next pending boundary on each axis; cell = boundary + m once crossed
     int by = iy + (ypos ? 1 : 0);
+    int d = dist(ix >> kSkipShift, iy >> kSkipShift);  // carried: one field lookup per event
     for (;;) {
         const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
-        const int d = dist(cx, cy);
         const bool jump = d != 0;
         const int dk = d << kSkipShift;
         // faces of the region known to be free: the (2d-1)^2-block box, or just this cell
@@ -217,21 +217,29 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
         const int bS0 = xe ? by : bx;
         int bS = bS0;
         if (jump & (xe ? ynz : xnz)) {
-            const float pT = fS + (xe ? dy : dx) * t;  // estimate only; corrected exactly below
-            int b = (int)floorf(pT) + (sS > 0 ? 1 : 0);
+            // position on the secondary axis at time t.  The consumed crossings are exactly those on
+            // the near side of p* = fS + t*dS*(1 +- 2.4e-7) (rounding of 1/dS and of the closed form),
+            // and pT differs from p* by < 1e-4 cells (|t*dS| <= 170, |fS| <= 2^11).  So when pT is
+            // not within 0.01 of an integer the first pending boundary is floor(pT) (+1 going up) with
+            // no further checks; otherwise it is corrected with the closed-form times themselves.
+            const float pT = fS + (xe ? dy : dx) * t;
+            const float fl = floorf(pT);
+            const float fr = pT - fl;
+            int b = (int)fl + (sS > 0 ? 1 : 0);
             b = sS > 0 ? (b < bS0 ? bS0 : b) : (b > bS0 ? bS0 : b);
-            // consumed(bb): crossing bb happened before the exit event (ties decided by xe)
-            for (;;) {  // step back while the previous crossing was NOT consumed
-                const float tp = ((float)(b - sS) - fS) * invS;
-                const bool cons = (tp < t) | ((tp == t) & xe);
-                if ((b == bS0) | cons) break;
-                b -= sS;
-            }
-            for (;;) {  // step forward while this crossing WAS consumed
-                const float tc = ((float)b - fS) * invS;
-                const bool cons = (tc < t) | ((tc == t) & xe);
-                if (!cons) break;
-                b += sS;
+            if (!(fr >= 0.01f && fr <= 0.99f)) {
+                for (;;) {  // step back while the previous crossing was NOT consumed
+                    const float tp = ((float)(b - sS) - fS) * invS;
+                    const bool cons = (tp < t) | ((tp == t) & xe);
+                    if ((b == bS0) | cons) break;
+                    b -= sS;
+                }
+                for (;;) {  // step forward while this crossing WAS consumed
+                    const float tc = ((float)b - fS) * invS;
+                    const bool cons = (tc < t) | ((tc == t) & xe);
+                    if (!cons) break;
+                    b += sS;
+                }
             }
             bS = b;
         }
@@ -243,7 +251,8 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
         iy = (xe ? nby - sy : By) + my;
         bx = nbx;
         by = nby;
-        if (occ(ix, iy)) return t * g.cell;
+        d = dist(ix >> kSkipShift, iy >> kSkipShift);
+        if (d == 0 && occ(ix, iy)) return t * g.cell;  // a cell of an empty block cannot be occupied
     }
 }
 

@@ -50,4 +50,27 @@ inline void build_skip_field(const uint32_t* bits, int width, int height, int wp
     if (pitch_out) *pitch_out = pitch;
 }
 
+// Per-cell Chebyshev distance (in cells, saturated at 255) to the nearest occupied cell; 0 = occupied.
+// Lets the move kernel prove "nothing within the footprint's reach" with one byte load.
+inline void build_cell_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint8_t>* out) {
+    std::vector<uint8_t>& d = *out;
+    d.assign((size_t)width * height, 255);
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x)
+            if ((bits[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u) d[(size_t)y * width + x] = 0;
+    auto at = [&](int x, int y) -> int { return (x < 0 || y < 0 || x >= width || y >= height) ? 255 : d[(size_t)y * width + x]; };
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            int m = d[(size_t)y * width + x];
+            m = std::min(m, std::min(std::min(at(x - 1, y - 1), at(x, y - 1)), std::min(at(x + 1, y - 1), at(x - 1, y))) + 1);
+            d[(size_t)y * width + x] = (uint8_t)std::min(m, 255);
+        }
+    for (int y = height - 1; y >= 0; --y)
+        for (int x = width - 1; x >= 0; --x) {
+            int m = d[(size_t)y * width + x];
+            m = std::min(m, std::min(std::min(at(x + 1, y + 1), at(x, y + 1)), std::min(at(x - 1, y + 1), at(x + 1, y))) + 1);
+            d[(size_t)y * width + x] = (uint8_t)std::min(m, 255);
+        }
+}
+
 }  // namespace mrca

@@ -43,6 +43,7 @@ struct EnvView {
     const uint32_t* map_bits;
     const uint8_t* skip;
     int32_t skip_cw, skip_ch, skip_pitch;  // pitch: padded row length (multiple of 4)
+    const uint8_t* cellfield;  // per-cell Chebyshev distance to the nearest occupied cell [map_h][map_w]
     int32_t foot_r;  // blocks that cover the robot's circumradius: dist > foot_r => footprint is free
     GridGeom g;
     // rules

@@ -176,10 +176,10 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     const int pw0 = (pix - hc) >> 5;
     bool need = false;
     if (valid && !(e.debug_flags & 8)) {
-        const GlobalDist dist{e.skip, e.skip_cw, e.skip_ch, e.skip_pitch};
-        const int pcx = pix >> kSkipShift, pcy = piy >> kSkipShift;
-        const bool inside = pcx >= 0 && pcy >= 0 && pcx < e.skip_cw && pcy < e.skip_ch;
-        need = !(inside && dist(pcx, pcy) > e.foot_r);
+        // nothing occupied within hc cells (Chebyshev) of the centre cell => every cell the outline walk
+        // could visit is free => no hit, without touching the bitmap
+        const bool inside = pix >= 0 && piy >= 0 && pix < e.g.width && piy < e.g.height;
+        need = !(inside && e.cellfield[(size_t)piy * e.g.width + pix] > hc);
     }
     {
         unsigned long long todo = __ballot(need);
