@@ -258,21 +258,24 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
 
 // ------------------------------------------------------------------------------------------
 // Robot outline (0.44 x 0.38 rectangle) against the grid: march the four edges.
+// Edge k of the footprint (corner k -> corner k+1, corners (+,+),(-,+),(-,-),(+,-)): does the walk
+// along it meet an occupied cell?
+template <class Occ>
+MRCA_HD bool static_edge_hit(const Occ& occ, const GridGeom& g, float x, float y, float s, float c, int k) {
+    const float hx = (k == 0 || k == 3) ? kHalfLen : -kHalfLen;
+    const float hy = (k < 2) ? kHalfWid : -kHalfWid;
+    const float ex = (k == 0) ? -c : (k == 1) ? s : (k == 2) ? c : -s;
+    const float ey = (k == 0) ? -s : (k == 1) ? -c : (k == 2) ? s : c;
+    const float el = (k & 1) ? 2.0f * kHalfWid : 2.0f * kHalfLen;
+    const float cx = x + (hx * c - hy * s);
+    const float cy = y + (hx * s + hy * c);
+    return grid_march(occ, g, cx, cy, ex, ey, el) < el;
+}
+
 template <class Occ>
 MRCA_HD bool static_hit(const Occ& occ, const GridGeom& g, float x, float y, float s, float c) {
-    const float hx[4] = {kHalfLen, -kHalfLen, -kHalfLen, kHalfLen};
-    const float hy[4] = {kHalfWid, kHalfWid, -kHalfWid, -kHalfWid};
-    const float ex[4] = {-c, s, c, -s};
-    const float ey[4] = {-s, -c, s, c};
-    const float el[4] = {2.0f * kHalfLen, 2.0f * kHalfWid, 2.0f * kHalfLen, 2.0f * kHalfWid};
     bool hit = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float cx = x + (hx[k] * c - hy[k] * s);
-        const float cy = y + (hx[k] * s + hy[k] * c);
-        const float t = grid_march(occ, g, cx, cy, ex[k], ey[k], el[k]);
-        hit = hit || (t < el[k]);
-    }
+    for (int k = 0; k < 4; ++k) hit = static_edge_hit(occ, g, x, y, s, c, k) || hit;
     return hit;
 }
 

@@ -209,12 +209,29 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
             }
         }
     }
-    __syncthreads();  // one wave per block: orders the cooperative LDS writes before the per-lane reads
-    bool shit = false;
-    if (need) {
-        const MiniGrid mg{mini + lane * psize, py0, pw0, pwords};
-        shit = static_hit(mg, e.g, nx, ny, ns, nc);
+    // outline walks, four lanes per robot (one per edge, 16 robots per pass): a walk is a chain of
+    // dependent LDS reads, so spreading the edges over lanes cuts the chain by four
+    int* need_list = reinterpret_cast<int*>(mini + kWave * psize);   // [64] lanes that need the walk
+    int* hit_flag = need_list + kWave;                               // [64] result per robot lane
+    const unsigned long long need_mask = __ballot(need);
+    if (need) need_list[__popcll(need_mask & ((1ull << lane) - 1ull))] = lane;
+    hit_flag[lane] = 0;
+    __syncthreads();  // one wave per block: orders the cooperative LDS writes before the reads below
+    const int n_need = __popcll(need_mask);
+    for (int base = 0; base < n_need; base += 16) {
+        const int q = base + (lane >> 2);
+        const bool act = q < n_need;
+        const int src = act ? need_list[q] : 0;
+        const float sx_ = __shfl(nx, src, kWave), sy_ = __shfl(ny, src, kWave);
+        const float ss_ = __shfl(ns, src, kWave), sc_ = __shfl(nc, src, kWave);
+        const int sy0 = __shfl(py0, src, kWave), sw0 = __shfl(pw0, src, kWave);
+        if (act) {
+            const MiniGrid mg{mini + src * psize, sy0, sw0, pwords};
+            if (static_edge_hit(mg, e.g, sx_, sy_, ss_, sc_, lane & 3)) hit_flag[src] = 1;
+        }
     }
+    __syncthreads();
+    const bool shit = need && hit_flag[lane] != 0;
 
     // --- collision pass in robot order (Stage's sequential model loop).  Broad phase first: robot i
     //     can only touch robot j if its provisional centre comes within 2 x circumradius of j's old or
@@ -451,7 +468,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
-    uint8_t* ctile = reinterpret_cast<uint8_t*>(rbuf + e.B);
+    unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(rbuf + e.B);   // [B] neighbours per beam
+    uint8_t* ctile = reinterpret_cast<uint8_t*>(nbmask + e.B);
 
     const int world = n / e.R;
     const int local = n - world * e.R;
@@ -469,6 +487,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int cx0 = tw0 * (32 / kSkipK);
     const int ctw = tw * (32 / kSkipK);
     const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
+    for (int b = tid; b < e.B; b += blockDim.x) nbmask[b] = 0ull;
     if (!(e.debug_flags & 4)) {
         const int wi = tid & ((1 << e.tile_lg) - 1);
         const int gw = tw0 + wi;
@@ -518,7 +537,14 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             nb[idx] = make_float4(xj, yj, sj, cj);
             nbi[idx] = make_int2(lo, hi);
         }
-        if (tid == 0) *nb_count = (e.debug_flags & 1) ? 0 : __popcll(m);
+        const int cnt0 = (e.debug_flags & 1) ? 0 : __popcll(m);
+        if (tid == 0) *nb_count = cnt0;
+        // scatter: bit k of nbmask[b] = "neighbour k can touch beam b".  One wave, program order: the
+        // read-modify-writes of successive k never race, and within one k the lanes hit distinct beams.
+        for (int k = 0; k < cnt0; ++k) {
+            const int2 iv = nbi[k];
+            for (int b = iv.x + tid; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
+        }
     }
     // --- beams: thread t takes beams t, t + blockDim, ... (one each in the default launch)
     const TileGrid occ{tile, ty0, tw0, e.tile_stride};
@@ -533,17 +559,17 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int cnt = *nb_count;
     for (int b = tid; b < e.B; b += blockDim.x) {
         float rng = rbuf[b];
-        if (cnt > 0) {
+        unsigned long long m = cnt > 0 ? nbmask[b] : 0ull;
+        if (m) {
             const float bc = e.beam_cos[b], bs = e.beam_sin[b];
             const float dx = c * bc - s * bs;
             const float dy = s * bc + c * bs;
-            for (int k = 0; k < cnt; ++k) {
-                const int2 iv = nbi[k];
-                if (b >= iv.x && b <= iv.y) {
-                    const float4 q = nb[k];
-                    const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
-                    rng = t < rng ? t : rng;
-                }
+            while (m) {
+                const int k = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float4 q = nb[k];
+                const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
+                rng = t < rng ? t : rng;
             }
         }
         rbuf[b] = rng < kRangeMax ? rng : kRangeMax;
@@ -601,14 +627,14 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 
 size_t ray_lds_bytes(const EnvView& e) {
     const size_t tile_words = (size_t)e.tile_h * e.tile_stride;
-    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 4 +
+    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 +
            (size_t)e.ctile_h * e.ctile_stride;
 }
 
 size_t move_lds_bytes(const EnvView& e) {
     const int rows = 2 * e.foot_hc + 1;
     const int words = (rows + 31) / 32 + 1;
-    return (size_t)kWave * rows * words * 4;
+    return (size_t)kWave * rows * words * 4 + 2 * kWave * sizeof(int);
 }
 
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
