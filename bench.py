@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--worlds", type=int, default=128)
     ap.add_argument("--robots-per-world", type=int, default=32)
     ap.add_argument("--scenario", default="stage1", choices=["stage1", "stage2"])
+    ap.add_argument("--policy-dtype", default="f32", choices=["f32", "bf16"],
+                    help="rollout/train: dtype of the policy INFERENCE pass (update stays fp32); f32 = the reference's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the rollout/train side figures")
     args = ap.parse_args()
@@ -148,7 +150,8 @@ def main():
         step_fn = lambda k: env.step(pool[k % len(pool)])  # noqa: E731
     else:
         from mrca.trainer import make_bench_step
-        step_fn = make_bench_step(env, args.mode, dist)
+        step_fn = make_bench_step(env, args.mode, dist,
+                                  inference_dtype=torch.bfloat16 if args.policy_dtype == "bf16" else None)
 
     if args.mode == "train":
         # warm-up must cover whole horizons so that MIOpen tuning / allocator growth of the FIRST update
@@ -188,7 +191,8 @@ def main():
             "config": {"workload": f"{args.scenario}: {args.worlds} worlds x {sc.robots_per_world} robots = {N} "
                                    f"robots/GPU, 512 beams, 3 frames, cell {sc.grid.cell} m, auto-reset, "
                                    f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}",
-                       "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode},
+                       "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode,
+                       "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None},
             "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(N),
                          "traffic_note": "bytes/launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; "

@@ -472,6 +472,7 @@ class OracleEnv:
         cfg = self.cfg
         N, R = self.N, cfg.R
         act = np.asarray(actions, dtype=f).reshape(N, 2)
+        act = np.where(np.isfinite(act), act, f(0.0)).astype(f)   # a non-finite command idles the robot
         live = self.live.astype(bool)
         v = np.where(live, act[:, 0], f(0.0)).astype(f)
         w = np.where(live, act[:, 1], f(0.0)).astype(f)

@@ -274,6 +274,8 @@ void oc_step(const oc_env* e, const float* actions) {
             lv[l] = e->live[n] != 0;
             v[l] = lv[l] ? actions[n * 2] : 0.0f;
             w[l] = lv[l] ? actions[n * 2 + 1] : 0.0f;
+            if (!isfinite(v[l])) v[l] = 0.0f; /* a non-finite command idles the robot */
+            if (!isfinite(w[l])) w[l] = 0.0f;
             oc_sincos(th[l], &s[l], &c[l]);
             const float d = v[l] * DT;
             nx[l] = x[l] + d * c[l];

@@ -38,6 +38,7 @@ constexpr int kMaxTriesPose = 64;
 constexpr int kMaxTriesGoal = 256;
 constexpr uint32_t kStreamPose = 0u, kStreamGoal = 1u;
 constexpr float kInf = __builtin_huge_valf();
+constexpr int kMaxMarchSteps = 1 << 14;   // termination guard of the grid walks (never reached on finite in-map input)
 
 // ------------------------------------------------------------------------------------------
 // sincos: Cody-Waite reduction by pi/2 + Cephes single-precision minimax polynomials.
@@ -52,6 +53,9 @@ MRCA_HD void sincos_det(float th, float* sn, float* cs) {
     *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
     *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
+
+// A non-finite command (a diverged policy) is treated as 0: the robot idles instead of poisoning the state.
+MRCA_HD float sane_cmd(float a) { return (a - a == 0.0f) ? a : 0.0f; }
 
 // (-pi, pi]: the GT yaw after the quaternion round trip (stageros.cpp:575-583, stage_world1.py:88-91)
 MRCA_HD float wrap_angle(float th) {
@@ -124,7 +128,9 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
     int by = dy > 0.0f ? iy + 1 : iy;
     float tx = xnz ? ((float)bx - fx) * inv_dx : kInf;
     float ty = ynz ? ((float)by - fy) * inv_dy : kInf;
-    for (;;) {
+    // a walk of tmax metres enters fewer than 2*tmax/cell + 2 cells; the cap only ever triggers on
+    // non-finite / absurd inputs and guarantees termination on the GPU
+    for (int guard = 0; guard < kMaxMarchSteps; ++guard) {
         float t;
         if (tx < ty) {
             t = tx;
@@ -140,6 +146,7 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
         if (t >= tmax_c) return tmax;
         if (occ(ix, iy)) return t * g.cell;
     }
+    return tmax;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -193,7 +200,7 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
     int bx = ix + (xpos ? 1 : 0);  // next pending boundary on each axis; cell = boundary + m once crossed
     int by = iy + (ypos ? 1 : 0);
     int d = dist(ix >> kSkipShift, iy >> kSkipShift);  // carried: one field lookup per event
-    for (;;) {
+    for (int guard = 0; guard < kMaxMarchSteps; ++guard) {
         const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
         const bool jump = d != 0;
         const int dk = d << kSkipShift;
@@ -254,6 +261,7 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
         d = dist(ix >> kSkipShift, iy >> kSkipShift);
         if (d == 0 && occ(ix, iy)) return t * g.cell;  // a cell of an empty block cannot be occupied
     }
+    return tmax;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -148,8 +148,8 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
 
     float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
     const bool live = e.live[n] != 0;
-    const float v = live ? actions[n * 2 + 0] : 0.0f;
-    const float w = live ? actions[n * 2 + 1] : 0.0f;
+    const float v = live ? sane_cmd(actions[n * 2 + 0]) : 0.0f;
+    const float w = live ? sane_cmd(actions[n * 2 + 1]) : 0.0f;
 
     // integrate: explicit Euler with the heading at tick start
     float s, c;

@@ -11,11 +11,22 @@ from . import vec_env
 
 
 # ---------------------------------------------------------------------------------------------
-def generate_action(policy, obs, goal, speed, action_bound, generator=None):
+def generate_action(policy, obs, goal, speed, action_bound, generator=None, autocast_dtype=None):
     """model/ppo.py:57-82: sample a ~ N(mean, std); the UNclipped action and its logprob are what
-    the buffer stores, the clipped one drives the robot."""
+    the buffer stores, the clipped one drives the robot.  ``autocast_dtype=torch.bfloat16`` runs the
+    towers on the bf16 MFMA path (opt-in; the reference and the default here are fp32)."""
     with torch.no_grad():
-        v, a, logprob, _mean = policy(obs, goal, speed, generator=generator)
+        if autocast_dtype is not None:
+            with torch.autocast(obs.device.type, dtype=autocast_dtype):
+                mean, v = policy.mean_value(obs, goal, speed)
+            mean, v = mean.float(), v.float()
+            logstd = policy.logstd.expand_as(mean)
+            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+            a = mean + torch.exp(logstd) * noise
+            from .net import gaussian_logprob
+            logprob = gaussian_logprob(a, mean, logstd)
+        else:
+            v, a, logprob, _mean = policy(obs, goal, speed, generator=generator)
         lo = torch.as_tensor(action_bound[0], device=a.device, dtype=a.dtype)
         hi = torch.as_tensor(action_bound[1], device=a.device, dtype=a.dtype)
         scaled = torch.minimum(torch.maximum(a, lo), hi)

@@ -30,6 +30,7 @@ class HParams:
     act_size: int = 2
     value_coef: float = 20.0          # model/ppo.py:185
     action_bound: tuple = ((0.0, -1.0), (1.0, 1.0))   # ppo_stage1.py:170
+    inference_dtype: object = None    # None = fp32 like the reference; torch.bfloat16 = opt-in fast rollouts
 
 
 def broadcast_parameters(module, dist):
@@ -68,7 +69,7 @@ class Stage1Trainer:
         """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
         env, hp, buf = self.env, self.hp, self.buffer
         v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
-                                                    hp.action_bound, self.gen)
+                                                    hp.action_bound, self.gen, hp.inference_dtype)
         buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v)
         env.step(scaled.contiguous())
         buf.store_outcome(self.t, env.reward, env.done)
@@ -100,15 +101,15 @@ class Stage1Trainer:
             self.tick()
 
 
-def make_bench_step(env, mode, dist, batch_size=16384):
+def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None):
     """bench.py --mode rollout|train: returns step_fn(k) doing one tick for all robots."""
-    hp = HParams(batch_size=batch_size)
+    hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0)
     tr.started = True  # bench.py resets the env itself
     if mode == "rollout":
         def step_fn(_k):
             _v, _a, _lp, scaled = ppo.generate_action(tr.policy, env.obs, env.local_goal, env.speed,
-                                                      hp.action_bound, tr.gen)
+                                                      hp.action_bound, tr.gen, hp.inference_dtype)
             env.step(scaled.contiguous())
         return step_fn
 

@@ -172,8 +172,8 @@ void emul_step(const EmulEnv* e, const float* actions) {
             const int n = world * R + l;
             x[l] = e->pose[n * 3]; y[l] = e->pose[n * 3 + 1]; th[l] = e->pose[n * 3 + 2];
             livev[l] = e->live[n] != 0;
-            v[l] = livev[l] ? actions[n * 2] : 0.0f;
-            w[l] = livev[l] ? actions[n * 2 + 1] : 0.0f;
+            v[l] = livev[l] ? sane_cmd(actions[n * 2]) : 0.0f;
+            w[l] = livev[l] ? sane_cmd(actions[n * 2 + 1]) : 0.0f;
             sincos_det(th[l], &s[l], &c[l]);
             const float d = v[l] * kDt;
             nx[l] = x[l] + d * c[l];

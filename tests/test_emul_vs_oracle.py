@@ -75,3 +75,18 @@ def test_dense_world_beam_culling_is_conservative():
         e.step(a)
         U.assert_state_equal(e, o, what=f"dense step {k}")
     assert (o.scan < 1.0).mean() > 0.01
+
+
+def test_non_finite_actions_idle_the_robot():
+    sc = S.stage1(num_worlds=1, robots_per_world=4, seed=2)
+    o, e, c = U.oracle_env(sc), U.EmulEnv(sc), U.COracleEnv(sc)
+    for env in (o, e, c):
+        env.reset()
+    a = np.array([[np.nan, 0.5], [0.5, np.inf], [-np.inf, np.nan], [0.3, 0.2]], np.float32)
+    before = o.pose.copy()
+    for env in (o, e, c):
+        env.step(a)
+    U.assert_state_equal(e, o, what="nan actions (emul)")
+    U.assert_state_equal(c, o, what="nan actions (C oracle)")
+    assert np.isfinite(o.pose).all() and np.isfinite(o.scan).all() and np.isfinite(o.reward).all()
+    assert (o.pose[2] == before[2]).all()       # both components non-finite -> (0, 0): no motion
