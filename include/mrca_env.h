@@ -151,7 +151,7 @@ const char* mrca_last_error(void);
  * (event, move kernel, event, ray-cast kernel, event), up to 1024 steps between reads.
  * mrca_read_timing synchronises on the last recorded event, returns the summed durations of the
  * recorded launches in milliseconds and clears the ring. */
-int mrca_enable_timing(mrca_env* env, int32_t on);
+int mrca_enable_timing(mrca_env* env, int32_t on); /* on = n > 0: time every n-th step; 0: off */
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
 /* Profiling ablations ONLY (results are wrong while any flag is set): 1 = skip robot-robot lidar
  * tests, 2 = skip the grid march, 4 = skip tile staging (implies 2).  0 restores the product path. */

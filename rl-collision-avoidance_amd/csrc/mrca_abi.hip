@@ -134,7 +134,8 @@ struct mrca_env {
     mrca::EnvView view;
     size_t lds_bytes = 0;
     // timing
-    bool timing = false;
+    int timing = 0;      // 0 off, n > 0: record events on every n-th step
+    int step_count = 0;
     std::vector<hipEvent_t> ev;  // 3 per recorded step: before move, before ray, after ray
     int ev_used = 0;
 };
@@ -366,7 +367,8 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     if (!actions_dev) return fail(MRCA_ERR_INVALID, "actions_dev is NULL");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool rec = env->timing && env->ev_used + 3 <= (int)env->ev.size();
+    const bool rec = env->timing > 0 && (env->step_count++ % env->timing) == 0 &&
+                     env->ev_used + 3 <= (int)env->ev.size();
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 0], s));
     mrca::launch_move(env->view, actions_dev, s);
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
@@ -397,7 +399,8 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
         env->ev.resize(3 * kTimingRing);
         for (auto& e : env->ev) HIP_TRY(hipEventCreate(&e));
     }
-    env->timing = on != 0;
+    env->timing = on > 0 ? on : 0;
+    env->step_count = 0;
     env->ev_used = 0;
     return MRCA_OK;
 }

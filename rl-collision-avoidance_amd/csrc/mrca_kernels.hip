@@ -492,7 +492,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         const int wi = tid & ((1 << e.tile_lg) - 1);
         const int gw = tw0 + wi;
         const bool colok = wi < tw && gw >= 0 && gw < e.g.wpr;
-        for (int r = tid >> e.tile_lg; r < e.tile_h; r += blockDim.x >> e.tile_lg) {
+        for (int r = tid >> e.tile_lg; r < ((e.debug_flags & 64) ? 0 : e.tile_h); r += blockDim.x >> e.tile_lg) {
             const int gy = ty0 + r;
             uint32_t val = 0u;
             if (colok && gy >= 0 && gy < e.g.height) val = e.map_bits[gy * e.g.wpr + gw];
@@ -553,7 +553,12 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         const float bc = e.beam_cos[b], bs = e.beam_sin[b];
         const float dx = c * bc - s * bs;
         const float dy = s * bc + c * bs;
-        rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+        if (e.debug_flags & 64) {  // experiment: occupancy bits straight from L2, no fine tile in LDS
+            const GlobalGrid gocc{e.map_bits, e.g.width, e.g.height, e.g.wpr};
+            rbuf[b] = grid_march_skip(gocc, dist, e.g, x, y, dx, dy, kRangeMax);
+        } else {
+            rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+        }
     }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
     const int cnt = *nb_count;
