@@ -6,12 +6,13 @@
 //                  pose, every lane runs the rectangle SAT against its own current pose and a
 //                  wavefront ballot decides revert+stall.  Reward / terminal / episode
 //                  bookkeeping (Philox resets, group-synchronous episodes) follow in-lane.
-//   raycast_kernel one workgroup per robot, one thread per beam (512 threads = 8 waves).
-//                  The (2*rc+1)-row occupancy tile around the robot is staged bit-packed into
-//                  LDS, the other robots of the world within lidar reach are compacted into
-//                  LDS by the first wave (ballot + popcount), then every beam walks the tile
-//                  and slab-tests the neighbours.  Scan, normalised observation and the frame
-//                  stack shift are written coalesced (thread = beam = column).
+//   raycast_kernel one 256-thread workgroup per robot, two beams per thread.  The coarse
+//                  free-distance tile (4x4-cell blocks) around the robot is staged into LDS,
+//                  the other robots of the world within lidar reach are compacted into LDS by
+//                  the first wave (ballot + popcount) with the beams each can touch, then every
+//                  beam runs the exact skipping march (occupancy bits of non-empty blocks come
+//                  from the L2-resident bitmap) and slab-tests its neighbours.  Scan,
+//                  normalised observation and the frame-stack shift leave as 16-byte stores.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
 //   gae_kernel     reverse GAE scan, thread per robot, coalesced over N.
 //
@@ -23,14 +24,6 @@ namespace mrca {
 namespace {
 
 constexpr int kWave = 64;
-
-struct TileGrid {  // occupancy lookups in the LDS tile (no bounds checks: margin by construction)
-    const uint32_t* tile;
-    int y0, w0, stride;
-    __device__ __forceinline__ bool operator()(int ix, int iy) const {
-        return (tile[__mul24(iy - y0, stride) + ((ix >> 5) - w0)] >> (ix & 31)) & 1u;
-    }
-};
 
 struct TileDist {  // coarse free-distance lookups in LDS
     const uint8_t* d;
@@ -462,9 +455,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         keep2 = ob4[2 * fstride];
     }
 
-    uint32_t* tile = lds;
-    const int tile_words = e.tile_h * e.tile_stride;
-    float4* nb = reinterpret_cast<float4*>(lds + ((tile_words + 3) & ~3));
+    float4* nb = reinterpret_cast<float4*>(lds);
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
@@ -489,15 +480,6 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
     for (int b = tid; b < e.B; b += blockDim.x) nbmask[b] = 0ull;
     if (!(e.debug_flags & 4)) {
-        const int wi = tid & ((1 << e.tile_lg) - 1);
-        const int gw = tw0 + wi;
-        const bool colok = wi < tw && gw >= 0 && gw < e.g.wpr;
-        for (int r = tid >> e.tile_lg; r < ((e.debug_flags & 64) ? 0 : e.tile_h); r += blockDim.x >> e.tile_lg) {
-            const int gy = ty0 + r;
-            uint32_t val = 0u;
-            if (colok && gy >= 0 && gy < e.g.height) val = e.map_bits[gy * e.g.wpr + gw];
-            if (wi < tw) tile[r * e.tile_stride + wi] = val;
-        }
         // coarse free-distance tile over the same region, four blocks per 32-bit load (cx0 and the
         // field's row pitch are multiples of 4); blocks outside the map are free (1)
         const int cwi = tid & ((1 << e.ctile_lg) - 1);
@@ -547,18 +529,15 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
     }
     // --- beams: thread t takes beams t, t + blockDim, ... (one each in the default launch)
-    const TileGrid occ{tile, ty0, tw0, e.tile_stride};
+    // occupancy bits are only consulted inside non-empty 4x4 blocks (~1-2 lookups per ray): they come
+    // straight from the L2-resident bitmap, only the coarse free-distance tile lives in LDS
+    const GlobalGrid occ{e.map_bits, e.g.width, e.g.height, e.g.wpr};
     const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
     for (int b = tid; b < e.B; b += blockDim.x) {
         const float bc = e.beam_cos[b], bs = e.beam_sin[b];
         const float dx = c * bc - s * bs;
         const float dy = s * bc + c * bs;
-        if (e.debug_flags & 64) {  // experiment: occupancy bits straight from L2, no fine tile in LDS
-            const GlobalGrid gocc{e.map_bits, e.g.width, e.g.height, e.g.wpr};
-            rbuf[b] = grid_march_skip(gocc, dist, e.g, x, y, dx, dy, kRangeMax);
-        } else {
-            rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
-        }
+        rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
     }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
     const int cnt = *nb_count;
@@ -631,9 +610,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 }  // namespace
 
 size_t ray_lds_bytes(const EnvView& e) {
-    const size_t tile_words = (size_t)e.tile_h * e.tile_stride;
-    return ((tile_words + 3) & ~(size_t)3) * 4 + kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 +
-           (size_t)e.ctile_h * e.ctile_stride;
+    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 + (size_t)e.ctile_h * e.ctile_stride;
 }
 
 size_t move_lds_bytes(const EnvView& e) {
