@@ -111,3 +111,24 @@ def test_get_group_terminal_matches_reference_rule():
     assert ppo.get_group_terminal(t, 7) and not ppo.get_group_terminal(t, 3) and not ppo.get_group_terminal(t, 12)
     t[5] = True
     assert not ppo.get_group_terminal(t, 0)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "circle_test.py")), reason="reference checkout absent")
+def test_unchanged_circle_test_with_our_checkpoint(monkeypatch):
+    """50 ranks of the UNCHANGED circle_test.py; it loads policy/stage2.pth (missing from the reference
+    checkout), so a checkpoint SAVED BY THIS REPO's CNNPolicy is put there: the reference's own
+    CNNPolicy.load_state_dict must accept it (checkpoint compatibility in the reference -> direction)."""
+    from mrca import spmd, stage_world
+    from mrca.net import CNNPolicy
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "policy"))
+    torch.manual_seed(5)
+    torch.save(CNNPolicy(3, 2).state_dict(), os.path.join(tmp, "policy", "stage2.pth"))
+    stage_world.set_backend_factory(U.OracleBackend)
+    try:
+        errs = spmd.run_script(os.path.join(REF, "circle_test.py"), 50, max_ticks=12, chdir=tmp)
+    finally:
+        stage_world.set_backend_factory(None)
+    assert not errs, errs
