@@ -150,36 +150,39 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Same result as grid_march, far fewer steps: empty-space skipping over a coarse free-distance
-// field.  The grid is cut into kSkipK x kSkipK blocks; dist(cx,cy) = Chebyshev distance (in
-// blocks, 0 = the block holds an occupied cell) to the nearest non-empty block, so the
-// (2d-1) x (2d-1) blocks around a block with dist d >= 1 are free and the ray can jump straight
-// to the face where it leaves that box.
+// Same result as grid_march, far fewer steps: empty-space skipping over a coarse field of FREE
+// RECTANGLES.  The grid is cut into kSkipK x kSkipK-cell blocks; for every empty block the field
+// stores a rectangle of empty blocks around it -- 4-bit extents (left, right, down, up), so the
+// blocks [cx-L, cx+R] x [cy-D, cy+U] hold no occupied cell -- and kBlockFull for a block that is not
+// empty.  A ray in an empty block jumps straight to the face where it leaves that rectangle (in a
+// corridor the rectangle runs the length of the corridor); in a non-empty block it steps cell by cell.
 //
-// Exactness: grid_march is a 2-way merge of the x-crossing events tx(b) and the y-crossing
-// events ty(b) (both monotone in b), ties -> y first.  Leaving the box through its x face Bx
-// happens iff tx(Bx) < ty(By); at that moment exactly the y events with ty(b) <= tx(Bx) have
-// been consumed (symmetrically: x events with tx(b) < ty(By)).  The next pending boundary is
-// found from an arithmetic estimate and then corrected with the SAME closed-form times, so the
-// walk resumes in precisely the cell, and with precisely the (bx, by, tx, ty), the cell-by-cell
-// walk would have -- every later comparison, and the returned entry time, are bit-identical.
+// Exactness: grid_march is a 2-way merge of the x-crossing events tx(b) and the y-crossing events
+// ty(b) (both monotone in b), ties -> y first.  Leaving the rectangle through its x face Bx happens
+// iff tx(Bx) < ty(By); at that moment exactly the y events with ty(b) <= tx(Bx) have been consumed
+// (symmetrically: x events with tx(b) < ty(By)).  The next pending boundary is found from an
+// arithmetic estimate, corrected with the SAME closed-form times whenever the estimate is within
+// 0.01 cell of a boundary, so the walk resumes in precisely the cell, and with precisely the pending
+// boundaries, the cell-by-cell walk would have -- every later comparison, and the returned entry
+// time, are bit-identical.
 constexpr int kSkipShift = 2;
 constexpr int kSkipK = 1 << kSkipShift;
+constexpr int kBlockFull = 0xFFFF;
 
-struct GlobalDist {  // coarse free-distance field straight from global memory
-    const uint8_t* d;
+struct GlobalDist {  // free-rectangle field straight from global memory
+    const uint16_t* d;
     int32_t cw, ch, pitch;
     MRCA_HD int operator()(int cx, int cy) const {
-        if (cx < 0 || cy < 0 || cx >= cw || cy >= ch) return 1;  // outside the map: that block is free
+        if (cx < 0 || cy < 0 || cx >= cw || cy >= ch) return 0;  // outside the map: that block alone is free
         return d[cy * pitch + cx];
     }
 };
 
-// Flat, branch-poor form (one loop, one "event" per iteration, x/y handled by selects and sign
-// arithmetic) so the 64 rays of a wavefront stay in lock step: an iteration is either a jump to
-// the face of the free box (d >= 1) or a single cell step (d == 0, the "box" is the current cell).
-// No (tx, ty) state is carried -- boundary times are always re-derived from the closed form, which
-// is what makes every path through here produce the same numbers as grid_march.
+// Flat, branch-poor form (one loop, one "event" per iteration, x/y handled by selects) so the 64 rays
+// of a wavefront stay in lock step: an iteration is either a jump to the face of the free rectangle
+// or a single cell step (non-empty block: the "rectangle" is the current cell).  No (tx, ty) state is
+// carried -- boundary times are always re-derived from the closed form, which is what makes every
+// path through here produce the same numbers as grid_march.
 template <class Occ, class Dist>
 MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& g, float ox, float oy, float dx,
                               float dy, float tmax) {
@@ -195,18 +198,18 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
     const float inv_dy = ynz ? 1.0f / dy : kInf;
     const bool xpos = dx > 0.0f, ypos = dy > 0.0f;
     const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
-    const int mx = xpos ? 0 : -1, my = ypos ? 0 : -1;      // (v ^ m) - m  ==  s * v
-    const int facex = xpos ? 0 : kSkipK, facey = ypos ? 0 : kSkipK;  // box face = (c << K) + s*(d << K) + face
-    int bx = ix + (xpos ? 1 : 0);  // next pending boundary on each axis; cell = boundary + m once crossed
+    const int mx = xpos ? 0 : -1, my = ypos ? 0 : -1;  // cell = boundary + m once the boundary is crossed
+    const int shx = xpos ? 4 : 0, shy = ypos ? 12 : 8;  // which extent nibble faces the direction of travel
+    int bx = ix + (xpos ? 1 : 0);  // next pending boundary on each axis
     int by = iy + (ypos ? 1 : 0);
-    int d = dist(ix >> kSkipShift, iy >> kSkipShift);  // carried: one field lookup per event
+    int v = dist(ix >> kSkipShift, iy >> kSkipShift);  // carried: one field lookup per event
     for (int guard = 0; guard < kMaxMarchSteps; ++guard) {
         const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
-        const bool jump = d != 0;
-        const int dk = d << kSkipShift;
-        // faces of the region known to be free: the (2d-1)^2-block box, or just this cell
-        const int boxx = (cx << kSkipShift) + ((dk ^ mx) - mx) + facex;
-        const int boxy = (cy << kSkipShift) + ((dk ^ my) - my) + facey;
+        const bool jump = v != kBlockFull;
+        // faces of the region known to be free: the stored rectangle of blocks, or just this cell
+        const int ex = (v >> shx) & 15, ey = (v >> shy) & 15;
+        const int boxx = (cx + ((ex ^ mx) - mx) + (xpos ? 1 : 0)) << kSkipShift;  // (c + e + 1) or (c - e)
+        const int boxy = (cy + ((ey ^ my) - my) + (ypos ? 1 : 0)) << kSkipShift;
         const int Bx = jump ? boxx : bx;
         const int By = jump ? boxy : by;
         const float rawx = ((float)Bx - fx) * inv_dx;
@@ -258,8 +261,8 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
         iy = (xe ? nby - sy : By) + my;
         bx = nbx;
         by = nby;
-        d = dist(ix >> kSkipShift, iy >> kSkipShift);
-        if (d == 0 && occ(ix, iy)) return t * g.cell;  // a cell of an empty block cannot be occupied
+        v = dist(ix >> kSkipShift, iy >> kSkipShift);
+        if (v == kBlockFull && occ(ix, iy)) return t * g.cell;  // a cell of an empty block cannot be occupied
     }
     return tmax;
 }

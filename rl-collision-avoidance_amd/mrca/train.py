@@ -111,9 +111,10 @@ def main(argv=None):
         ep_reward = torch.zeros(env.N, device=env.device)
         finished = []
         for _t in range(hp.horizon):
+            was_live = env.live.bool().clone()   # stage 2: a finished robot keeps done=1 until its group restarts
             tr.tick()
-            ep_reward += env.reward
-            d = env.done.bool()
+            ep_reward += torch.where(was_live, env.reward, torch.zeros_like(env.reward))
+            d = env.done.bool() & was_live       # count each terminal event once
             if bool(d.any()):
                 finished.append(ep_reward[d].clone())
                 ep_reward[d] = 0
