@@ -116,8 +116,8 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_beam_cos = take(B * 4);
     L->off_beam_sin = take(B * 4);
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
-    L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 3) & ~3) *
-                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK));
+    L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 1) & ~1) *
+                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK) * sizeof(uint16_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->total = off;
 }
@@ -232,11 +232,11 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_sin, bsin.data(), B * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_map, cfg->map_bits,
                            (size_t)cfg->map_height * cfg->map_words_per_row * 4, hipMemcpyHostToDevice));
-    std::vector<uint8_t> skip;
+    std::vector<uint16_t> skip;
     int skip_cw = 0, skip_ch = 0, skip_pitch = 0;
     mrca::build_skip_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &skip, &skip_cw,
                            &skip_ch, &skip_pitch);
-    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     {
         std::vector<uint8_t> cf;
         mrca::build_cell_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &cf);
@@ -285,14 +285,11 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.beam_cos = reinterpret_cast<const float*>(a + L.off_beam_cos);
     v.beam_sin = reinterpret_cast<const float*>(a + L.off_beam_sin);
     v.map_bits = reinterpret_cast<const uint32_t*>(a + L.off_map);
-    v.skip = reinterpret_cast<const uint8_t*>(a + L.off_skip);
+    v.skip = reinterpret_cast<const uint16_t*>(a + L.off_skip);
     v.skip_cw = skip_cw;
     v.skip_ch = skip_ch;
     v.skip_pitch = skip_pitch;
     v.cellfield = reinterpret_cast<const uint8_t*>(a + L.off_cellfield);
-    // blocks needed to cover the footprint's circumradius sqrt(0.22^2 + 0.19^2) = 0.2907 m (+ one
-    // cell of slack for the start cells of the outline walks)
-    v.foot_r = (int32_t)std::ceil((0.2907 + cfg->map_cell) / (mrca::kSkipK * (double)cfg->map_cell));
     v.g.x0 = cfg->map_x0;
     v.g.y0 = cfg->map_y0;
     v.g.cell = cfg->map_cell;
@@ -317,7 +314,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.tile_lg = 0;
     while ((1 << v.tile_lg) < v.tile_stride) ++v.tile_lg;
     v.ctile_lg = 0;
-    while ((1 << v.ctile_lg) < v.ctile_stride / 4) ++v.ctile_lg;  // staged as 32-bit words
+    while ((1 << v.ctile_lg) < v.ctile_stride / 2) ++v.ctile_lg;  // staged as 32-bit words (2 blocks each)
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.debug_flags = 0;
     // 256 threads per 512-beam robot (2 beams each): 8 resident workgroups per CU instead of 4 hide the

@@ -9,15 +9,17 @@
 
 namespace mrca {
 
-// Coarse free-distance field for grid_march_skip: blocks of kSkipK x kSkipK cells;
-// out[cy*cw+cx] = Chebyshev distance in blocks to the nearest block holding an occupied cell
-// (0 = this block is not empty), saturated at 255.  Two-pass chamfer, exact for L-infinity.
-// Rows are padded to a multiple of 4 blocks with the value 1 ("that block is free") so that a
-// kernel can fetch four blocks per 32-bit load; *pitch_out is the padded row length.
-inline void build_skip_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint8_t>* out,
+// Free-rectangle field for grid_march_skip: blocks of kSkipK x kSkipK cells.  For an EMPTY block the
+// entry packs four 4-bit extents L | R<<4 | D<<8 | U<<12 of a rectangle of empty blocks
+// [cx-L, cx+R] x [cy-D, cy+U] around it (blocks outside the map are empty); a block holding an
+// occupied cell gets kBlockFull.  The rectangle is grown greedily, one side at a time in the order
+// left, right, down, up, while the strip added is entirely empty (up to 15 blocks per side) -- any
+// empty rectangle containing the block is valid for the march, larger ones just save steps.
+// Rows are padded to an even number of blocks so a kernel can fetch two blocks per 32-bit load.
+inline void build_skip_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint16_t>* out,
                              int* cw_out, int* ch_out, int* pitch_out = nullptr) {
     const int cw = (width + kSkipK - 1) / kSkipK, ch = (height + kSkipK - 1) / kSkipK;
-    std::vector<int> d((size_t)cw * ch, 255);
+    std::vector<uint8_t> full((size_t)cw * ch, 0);
     for (int y = 0; y < height; ++y)
         for (int w = 0; w < wpr; ++w) {
             uint32_t v = bits[(size_t)y * wpr + w];
@@ -25,26 +27,40 @@ inline void build_skip_field(const uint32_t* bits, int width, int height, int wp
                 const int b = __builtin_ctz(v);
                 v &= v - 1;
                 const int x = w * 32 + b;
-                if (x < width) d[(size_t)(y >> kSkipShift) * cw + (x >> kSkipShift)] = 0;
+                if (x < width) full[(size_t)(y >> kSkipShift) * cw + (x >> kSkipShift)] = 1;
             }
         }
-    auto at = [&](int x, int y) -> int { return (x < 0 || y < 0 || x >= cw || y >= ch) ? 255 : d[(size_t)y * cw + x]; };
+    // summed-area table of non-empty blocks for O(1) strip tests (blocks outside the map count as empty)
+    std::vector<int> sat((size_t)(cw + 1) * (ch + 1), 0);
+    for (int y = 0; y < ch; ++y)
+        for (int x = 0; x < cw; ++x)
+            sat[(size_t)(y + 1) * (cw + 1) + x + 1] = full[(size_t)y * cw + x] + sat[(size_t)y * (cw + 1) + x + 1] +
+                                                      sat[(size_t)(y + 1) * (cw + 1) + x] - sat[(size_t)y * (cw + 1) + x];
+    auto count = [&](int x0, int y0, int x1, int y1) -> int {  // inclusive block rectangle, clipped to the map
+        x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, cw - 1); y1 = std::min(y1, ch - 1);
+        if (x0 > x1 || y0 > y1) return 0;
+        return sat[(size_t)(y1 + 1) * (cw + 1) + x1 + 1] - sat[(size_t)y0 * (cw + 1) + x1 + 1] -
+               sat[(size_t)(y1 + 1) * (cw + 1) + x0] + sat[(size_t)y0 * (cw + 1) + x0];
+    };
+    const int pitch = pitch_out ? ((cw + 1) & ~1) : cw;
+    out->assign((size_t)pitch * ch, 0);
     for (int y = 0; y < ch; ++y)
         for (int x = 0; x < cw; ++x) {
-            int m = d[(size_t)y * cw + x];
-            m = std::min(m, std::min(std::min(at(x - 1, y - 1), at(x, y - 1)), std::min(at(x + 1, y - 1), at(x - 1, y))) + 1);
-            d[(size_t)y * cw + x] = std::min(m, 255);
+            if (full[(size_t)y * cw + x]) {
+                (*out)[(size_t)y * pitch + x] = (uint16_t)kBlockFull;
+                continue;
+            }
+            int l = 0, r = 0, d = 0, u = 0;
+            for (bool grew = true; grew;) {
+                grew = false;
+                if (l < 15 && count(x - l - 1, y - d, x - l - 1, y + u) == 0) { ++l; grew = true; }
+                if (r < 15 && count(x + r + 1, y - d, x + r + 1, y + u) == 0) { ++r; grew = true; }
+                if (d < 15 && count(x - l, y - d - 1, x + r, y - d - 1) == 0) { ++d; grew = true; }
+                if (u < 15 && count(x - l, y + u + 1, x + r, y + u + 1) == 0) { ++u; grew = true; }
+            }
+            if (l == 15 && r == 15 && d == 15 && u == 15) u = 14;  // keep kBlockFull unambiguous
+            (*out)[(size_t)y * pitch + x] = (uint16_t)(l | (r << 4) | (d << 8) | (u << 12));
         }
-    for (int y = ch - 1; y >= 0; --y)
-        for (int x = cw - 1; x >= 0; --x) {
-            int m = d[(size_t)y * cw + x];
-            m = std::min(m, std::min(std::min(at(x + 1, y + 1), at(x, y + 1)), std::min(at(x - 1, y + 1), at(x + 1, y))) + 1);
-            d[(size_t)y * cw + x] = std::min(m, 255);
-        }
-    const int pitch = pitch_out ? ((cw + 3) & ~3) : cw;
-    out->assign((size_t)pitch * ch, 1);
-    for (int y = 0; y < ch; ++y)
-        for (int x = 0; x < cw; ++x) (*out)[(size_t)y * pitch + x] = (uint8_t)d[(size_t)y * cw + x];
     *cw_out = cw;
     *ch_out = ch;
     if (pitch_out) *pitch_out = pitch;

@@ -41,10 +41,9 @@ struct EnvView {
     const float* beam_sin;
     // occupancy grid + coarse free-distance field (grid_march_skip)
     const uint32_t* map_bits;
-    const uint8_t* skip;
-    int32_t skip_cw, skip_ch, skip_pitch;  // pitch: padded row length (multiple of 4)
+    const uint16_t* skip;                   // free-rectangle field, one u16 per 4x4-cell block
+    int32_t skip_cw, skip_ch, skip_pitch;  // pitch: padded row length in blocks (even)
     const uint8_t* cellfield;  // per-cell Chebyshev distance to the nearest occupied cell [map_h][map_w]
-    int32_t foot_r;  // blocks that cover the robot's circumradius: dist > foot_r => footprint is free
     GridGeom g;
     // rules
     int32_t timeout;
@@ -58,7 +57,7 @@ struct EnvView {
     int32_t tile_h;       // rows = 2*rc+1
     int32_t tile_stride;  // words per LDS row (odd)
     int32_t ctile_h;      // rows of the coarse distance tile
-    int32_t ctile_stride; // bytes per coarse row
+    int32_t ctile_stride; // blocks (u16) per coarse row in LDS
     int32_t tile_lg;      // log2 of the staging column pitch (>= tile_stride)
     int32_t ctile_lg;     // same for the coarse tile
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile

@@ -25,8 +25,8 @@ namespace {
 
 constexpr int kWave = 64;
 
-struct TileDist {  // coarse free-distance lookups in LDS
-    const uint8_t* d;
+struct TileDist {  // free-rectangle field lookups in LDS
+    const uint16_t* d;
     int cy0, cx0, stride;
     __device__ __forceinline__ int operator()(int cx, int cy) const {
         return d[__mul24(cy - cy0, stride) + (cx - cx0)];
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(rbuf + e.B);   // [B] neighbours per beam
-    uint8_t* ctile = reinterpret_cast<uint8_t*>(nbmask + e.B);
+    uint16_t* ctile = reinterpret_cast<uint16_t*>(nbmask + e.B);
 
     const int world = n / e.R;
     const int local = n - world * e.R;
@@ -480,21 +480,20 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
     for (int b = tid; b < e.B; b += blockDim.x) nbmask[b] = 0ull;
     if (!(e.debug_flags & 4)) {
-        // coarse free-distance tile over the same region, four blocks per 32-bit load (cx0 and the
-        // field's row pitch are multiples of 4); blocks outside the map are free (1)
+        // free-rectangle tile over the blocks a 6 m ray can reach, two blocks per 32-bit load (cx0 and the
+        // field's row pitch are even); blocks outside the map are empty with no extent (0)
         const int cwi = tid & ((1 << e.ctile_lg) - 1);
-        const int gx = cx0 + 4 * cwi;
-        const bool ccolok = 4 * cwi < ctw && gx >= 0 && gx < e.skip_pitch;
+        const int gx = cx0 + 2 * cwi;
+        const bool ccolok = 2 * cwi < ctw && gx >= 0 && gx < e.skip_pitch;
         const uint32_t* skip32 = reinterpret_cast<const uint32_t*>(e.skip);
         uint32_t* ctile32 = reinterpret_cast<uint32_t*>(ctile);
         for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
             const int gy = cy0 + r;
-            uint32_t val = 0x01010101u;
-            if (ccolok && gy >= 0 && gy < e.skip_ch) val = skip32[(gy * e.skip_pitch + gx) >> 2];
-            if (4 * cwi < ctw) ctile32[r * (e.ctile_stride >> 2) + cwi] = val;
+            uint32_t val = 0u;
+            if (ccolok && gy >= 0 && gy < e.skip_ch) val = skip32[(gy * e.skip_pitch + gx) >> 1];
+            if (2 * cwi < ctw) ctile32[r * (e.ctile_stride >> 1) + cwi] = val;
         }
     }
-
     __syncthreads();  // tile staged
 
     // --- first wave: compact the world's other robots within lidar reach into LDS, each with the
@@ -610,7 +609,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 }  // namespace
 
 size_t ray_lds_bytes(const EnvView& e) {
-    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 + (size_t)e.ctile_h * e.ctile_stride;
+    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 + (size_t)e.ctile_h * e.ctile_stride * sizeof(uint16_t);
 }
 
 size_t move_lds_bytes(const EnvView& e) {

@@ -86,7 +86,7 @@ static void begin_episode(const EmulEnv* e, int n, int local, float curx, float 
 void emul_raycast(const EmulEnv* e, int only_fresh) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
-    std::vector<uint8_t> skipf;
+    std::vector<uint16_t> skipf;
     int scw, sch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch);
     const GlobalDist dist{skipf.data(), scw, sch, scw};
@@ -160,11 +160,6 @@ void emul_step(const EmulEnv* e, const float* actions) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
     const int R = e->R;
-    std::vector<uint8_t> skipf;
-    int scw, sch;
-    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch);
-    const GlobalDist dist{skipf.data(), scw, sch, scw};
-    const int foot_r = (int)ceil((0.2907 + (double)e->cell) / (kSkipK * (double)e->cell));
     std::vector<float> x(R), y(R), th(R), s(R), c(R), nx(R), ny(R), nth(R), ns(R), nc(R), v(R), w(R);
     std::vector<char> moving(R), shit(R), moved(R), livev(R), done_now(R);
     for (int world = 0; world < e->W; ++world) {
@@ -181,13 +176,7 @@ void emul_step(const EmulEnv* e, const float* actions) {
             nth[l] = wrap_angle(th[l] + w[l] * kDt);
             sincos_det(nth[l], &ns[l], &nc[l]);
             moving[l] = (v[l] != 0.0f) || (w[l] != 0.0f);
-            {
-                const int pcx = ((int)floorf((nx[l] - g.x0) * g.inv_cell)) >> kSkipShift;
-                const int pcy = ((int)floorf((ny[l] - g.y0) * g.inv_cell)) >> kSkipShift;
-                const bool inside = pcx >= 0 && pcy >= 0 && pcx < scw && pcy < sch;
-                shit[l] = 0;
-                if (!(inside && dist(pcx, pcy) > foot_r)) shit[l] = static_hit(occ, g, nx[l], ny[l], ns[l], nc[l]);
-            }
+            shit[l] = static_hit(occ, g, nx[l], ny[l], ns[l], nc[l]);
             moved[l] = 0;
         }
         for (int i = 0; i < R; ++i) {
@@ -264,11 +253,11 @@ void emul_step(const EmulEnv* e, const float* actions) {
 }
 
 // plain vs skipping march on arbitrary rays (returns the number of coarse blocks for sizing)
-int emul_skip_field(const EmulEnv* e, uint8_t* out, int cap) {
-    std::vector<uint8_t> f;
+int emul_skip_field(const EmulEnv* e, uint16_t* out, int cap) {
+    std::vector<uint16_t> f;
     int cw, ch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch);
-    if ((int)f.size() <= cap) memcpy(out, f.data(), f.size());
+    if ((int)f.size() <= cap) memcpy(out, f.data(), f.size() * 2);
     return (cw << 16) | ch;
 }
 
@@ -276,7 +265,7 @@ void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const
                 const float* tmax, float* out_plain, float* out_skip) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
-    std::vector<uint8_t> f;
+    std::vector<uint16_t> f;
     int cw, ch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch);
     const GlobalDist dist{f.data(), cw, ch, cw};
