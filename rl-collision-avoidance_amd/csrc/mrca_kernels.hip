@@ -487,7 +487,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         const bool ccolok = 2 * cwi < ctw && gx >= 0 && gx < e.skip_pitch;
         const uint32_t* skip32 = reinterpret_cast<const uint32_t*>(e.skip);
         uint32_t* ctile32 = reinterpret_cast<uint32_t*>(ctile);
-        for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
+        for (int r = tid >> e.ctile_lg; r < ((e.debug_flags & 64) ? 0 : cth); r += blockDim.x >> e.ctile_lg) {
             const int gy = cy0 + r;
             uint32_t val = 0u;
             if (ccolok && gy >= 0 && gy < e.skip_ch) val = skip32[(gy * e.skip_pitch + gx) >> 1];
@@ -536,7 +536,12 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         const float bc = e.beam_cos[b], bs = e.beam_sin[b];
         const float dx = c * bc - s * bs;
         const float dy = s * bc + c * bs;
-        rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+        if (e.debug_flags & 64) {  // experiment: free-rectangle field straight from L2, nothing staged
+            const GlobalDist gdist{e.skip, e.skip_cw, e.skip_ch, e.skip_pitch};
+            rbuf[b] = grid_march_skip(occ, gdist, e.g, x, y, dx, dy, kRangeMax);
+        } else {
+            rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+        }
     }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
     const int cnt = *nb_count;
