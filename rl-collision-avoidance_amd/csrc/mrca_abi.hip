@@ -321,6 +321,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     // per-robot latency chain (pose -> tile -> march -> store) better; measured 54.5 vs 62.0 us at 4096
     // robots (profiles/r01_h_ablation.txt)
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
+    v.lds_tile = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (mrca::move_lds_bytes(v) > 64 * 1024 || (1 << v.ctile_lg) > (cfg->beams >> v.ray_shift) ||
         (1 << v.tile_lg) > (cfg->beams >> v.ray_shift))
@@ -404,7 +405,9 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
-    env->view.debug_flags = flags & 0xFF;
+    env->view.debug_flags = flags & 0x3F;
+    if (flags & 64) env->view.lds_tile = 1;    // tuning knobs: 64 selects the LDS-tile kernel,
+    if (flags & 128) env->view.lds_tile = 0;   // 128 the L2 kernel
     const int knob = (flags >> 8) & 7;  // 0 keeps the default; k > 0 selects beams >> (k-1) threads per robot
     if (knob) {
         const int shift = knob - 1;

@@ -62,6 +62,7 @@ struct EnvView {
     int32_t ctile_lg;     // same for the coarse tile
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel launches beams >> ray_shift threads per robot
+    int32_t lds_tile;     // 1: raycast_kernel<true> (field tile staged in LDS), 0: raycast_kernel<false> (field from L2)
     int32_t debug_flags;  // profiling ablations only: 1 no neighbour tests, 2 no march, 4 no staging
 };
 

@@ -438,6 +438,10 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
     return (b % 8) * per + b / 8;
 }
 
+// kLdsTile = true : the free-rectangle tile around the robot is staged into LDS and the march reads it there;
+// kLdsTile = false: the march reads the field straight from the L1/L2-resident global copy (nothing staged).
+// Same arithmetic, same results; which one is launched is a tuning decision (mrca_abi.hip).
+template <bool kLdsTile>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int n = block_to_robot(blockIdx.x, e.N);
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int ctw = tw * (32 / kSkipK);
     const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
     for (int b = tid; b < e.B; b += blockDim.x) nbmask[b] = 0ull;
-    if (!(e.debug_flags & 4)) {
+    if (kLdsTile && !(e.debug_flags & 4)) {
         // free-rectangle tile over the blocks a 6 m ray can reach, two blocks per 32-bit load (cx0 and the
         // field's row pitch are even); blocks outside the map are empty with no extent (0)
         const int cwi = tid & ((1 << e.ctile_lg) - 1);
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         const bool ccolok = 2 * cwi < ctw && gx >= 0 && gx < e.skip_pitch;
         const uint32_t* skip32 = reinterpret_cast<const uint32_t*>(e.skip);
         uint32_t* ctile32 = reinterpret_cast<uint32_t*>(ctile);
-        for (int r = tid >> e.ctile_lg; r < ((e.debug_flags & 64) ? 0 : cth); r += blockDim.x >> e.ctile_lg) {
+        for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
             const int gy = cy0 + r;
             uint32_t val = 0u;
             if (ccolok && gy >= 0 && gy < e.skip_ch) val = skip32[(gy * e.skip_pitch + gx) >> 1];
@@ -536,11 +540,13 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         const float bc = e.beam_cos[b], bs = e.beam_sin[b];
         const float dx = c * bc - s * bs;
         const float dy = s * bc + c * bs;
-        if (e.debug_flags & 64) {  // experiment: free-rectangle field straight from L2, nothing staged
+        if (e.debug_flags & 6) {
+            rbuf[b] = kRangeMax;
+        } else if (kLdsTile) {
+            rbuf[b] = grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+        } else {
             const GlobalDist gdist{e.skip, e.skip_cw, e.skip_ch, e.skip_pitch};
             rbuf[b] = grid_march_skip(occ, gdist, e.g, x, y, dx, dy, kRangeMax);
-        } else {
-            rbuf[b] = (e.debug_flags & 6) ? kRangeMax : grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
         }
     }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
@@ -614,7 +620,8 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 }  // namespace
 
 size_t ray_lds_bytes(const EnvView& e) {
-    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 + (size_t)e.ctile_h * e.ctile_stride * sizeof(uint16_t);
+    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 +
+           (e.lds_tile ? (size_t)e.ctile_h * e.ctile_stride * sizeof(uint16_t) : 0);
 }
 
 size_t move_lds_bytes(const EnvView& e) {
@@ -633,8 +640,12 @@ void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, con
 }
 
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
-    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e,
-                       only_fresh);
+    if (e.lds_tile)
+        hipLaunchKernelGGL(raycast_kernel<true>, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e,
+                           only_fresh);
+    else
+        hipLaunchKernelGGL(raycast_kernel<false>, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e,
+                           only_fresh);
 }
 
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,

@@ -239,3 +239,24 @@ def test_full_batch_bit_exact_vs_c_oracle(hip, name, worlds, R, steps):
             torch.cuda.synchronize()
             U.assert_state_equal(U.HostView(env), ora, what=f"{name} full step {k}")
     env.close()
+
+
+@pytest.mark.parametrize("knob,label", [(64, "LDS tile"), (128, "L2 field")])
+def test_both_raycast_variants_bit_exact(hip, knob, label):
+    """raycast_kernel<true> (free-rectangle tile staged in LDS) and raycast_kernel<false> (field read from the
+    L2-resident copy) are the same arithmetic: both must match the oracle bit-for-bit."""
+    for sc in (S.stage1(num_worlds=4, robots_per_world=16, seed=5), S.stage2(num_worlds=1, seed=5)):
+        env = hip.VecStageWorld(sc)
+        env.set_debug_flags(knob)
+        ora = U.COracleEnv(sc)
+        env.reset()
+        ora.reset()
+        rng = np.random.default_rng(9)
+        for k in range(40):
+            a = U.random_actions(rng, sc.num_robots)
+            env.step(torch.from_numpy(a).cuda())
+            ora.step(a)
+            if k % 8 == 7:
+                torch.cuda.synchronize()
+                U.assert_state_equal(U.HostView(env), ora, what=f"{label} {sc.name} step {k}")
+        env.close()
