@@ -6,13 +6,14 @@
 //                  pose, every lane runs the rectangle SAT against its own current pose and a
 //                  wavefront ballot decides revert+stall.  Reward / terminal / episode
 //                  bookkeeping (Philox resets, group-synchronous episodes) follow in-lane.
-//   raycast_kernel one 256-thread workgroup per robot, two beams per thread.  The coarse
-//                  free-distance tile (4x4-cell blocks) around the robot is staged into LDS,
-//                  the other robots of the world within lidar reach are compacted into LDS by
-//                  the first wave (ballot + popcount) with the beams each can touch, then every
-//                  beam runs the exact skipping march (occupancy bits of non-empty blocks come
-//                  from the L2-resident bitmap) and slab-tests its neighbours.  Scan,
-//                  normalised observation and the frame-stack shift leave as 16-byte stores.
+//   raycast_kernel one 256-thread workgroup per robot, two beams per thread.  The other robots of
+//                  the world within lidar reach are compacted into LDS by the first wave (ballot
+//                  + popcount) together with a per-beam bitmask of who can touch which beam, while
+//                  every beam already runs the exact skipping march over the free-rectangle field
+//                  (<true>: its tile staged in LDS; <false>, the default: read from the L1/L2-
+//                  resident copy -- a ray needs ~5 lookups; occupancy bits of non-empty blocks come
+//                  from the L2-resident bitmap), then slab-tests its neighbours.  Scan, normalised
+//                  observation and the frame-stack shift leave through LDS as 16-byte stores.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
 //   gae_kernel     reverse GAE scan, thread per robot, coalesced over N.
 //
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     float s, c;
     sincos_det(th, &s, &c);
 
-    // --- stage the occupancy tile around the robot: thread -> (row, word) by shifts, no division
+    // --- geometry of the block tile around the robot (cells a 6 m ray can reach, + slack)
     const int ix0 = (int)floorf((x - e.g.x0) * e.g.inv_cell);
     const int iy0 = (int)floorf((y - e.g.y0) * e.g.inv_cell);
     const int ty0 = iy0 - e.tile_rc;

@@ -1,0 +1,82 @@
+"""The product's skipping ray march (free-rectangle field, csrc/mrca_device.h:grid_march_skip) must return
+EXACTLY what the plain cell-by-cell walk returns -- and that walk must equal the NumPy oracle's -- on rays
+chosen to hit the awkward cases: origins on cell boundaries, inside walls, outside the map, axis-aligned and
+45-degree directions, zero components, short ranges (the robot-outline walks use 0.38 / 0.44 m)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util as U
+from util import S, O
+
+
+def _rays(grid, n, rng):
+    g = grid
+    ox = rng.uniform(g.x0 - 2, g.x0 + g.width * g.cell + 2, n).astype(np.float32)
+    oy = rng.uniform(g.y0 - 2, g.y0 + g.height * g.cell + 2, n).astype(np.float32)
+    th = rng.uniform(-np.pi, np.pi, n)
+    th[:4000] = rng.integers(0, 8, 4000) * np.pi / 4
+    dx = np.cos(th).astype(np.float32)
+    dy = np.sin(th).astype(np.float32)
+    dx[:1000] = np.where(np.abs(dx[:1000]) < 1e-6, 0, dx[:1000])
+    dy[:1000] = np.where(np.abs(dy[:1000]) < 1e-6, 0, dy[:1000])
+    ox[4000:12000] = (g.x0 + rng.integers(0, g.width, 8000) * np.float32(g.cell)).astype(np.float32)
+    oy[8000:16000] = (g.y0 + rng.integers(0, g.height, 8000) * np.float32(g.cell)).astype(np.float32)
+    tmax = np.full(n, 6.0, np.float32)
+    tmax[::7] = rng.uniform(0, 6, len(tmax[::7])).astype(np.float32)
+    tmax[::11] = 0.44
+    tmax[::13] = 0.38
+    return ox, oy, dx, dy, tmax
+
+
+@pytest.mark.parametrize("name", ["stage1", "stage2", "circle", "synthetic"])
+def test_skipping_march_equals_plain_walk_and_oracle(name):
+    if name == "synthetic":
+        sc = S.stage1(1, 2, grid=U.small_grid(cell=0.1, size=16.0, ring_radius=7.0, blocks=[(-1, -1, 1, 0.5)]))
+    else:
+        sc = {"stage1": S.stage1(1, 2), "stage2": S.stage2(1), "circle": S.circle(1)}[name]
+    e = U.EmulEnv(sc)
+    rng = np.random.default_rng(hash(name) % 1000)
+    n = 400000
+    ox, oy, dx, dy, tmax = _rays(sc.grid, n, rng)
+    a = np.empty(n, np.float32)
+    b = np.empty(n, np.float32)
+    P = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
+    e.lib.emul_march(C.byref(e._st), n, P(ox), P(oy), P(dx), P(dy), P(tmax), P(a), P(b))
+    same = a.view(np.uint32) == b.view(np.uint32)
+    assert same.all(), f"{(~same).sum()} rays differ, first at {np.argwhere(~same)[0]}"
+    assert 0.1 < (a < tmax).mean() < 0.9          # the sample has both hits and misses
+    m = 15000
+    g = sc.grid
+    gm = O.GridMap(g.bits, g.width, g.height, g.cell, g.x0, g.y0)
+    o = O.grid_march(gm, ox[:m], oy[:m], dx[:m], dy[:m], tmax[:m], np.float32)
+    assert (o.view(np.uint32) == b[:m].view(np.uint32)).all()
+
+
+def test_free_rectangle_field_is_sound():
+    """Every rectangle stored for an empty block must contain no occupied cell (the march's only
+    assumption about the field), and non-empty blocks must be flagged."""
+    for sc in (S.stage1(1, 2), S.stage2(1), S.circle(1)):
+        e = U.EmulEnv(sc)
+        g = sc.grid
+        cw, ch = (g.width + 3) // 4, (g.height + 3) // 4
+        buf = np.zeros(cw * ch, np.uint16)
+        packed = e.lib.emul_skip_field(C.byref(e._st), C.c_void_p(buf.ctypes.data), buf.size)
+        assert (packed >> 16, packed & 0xFFFF) == (cw, ch)
+        f = buf.reshape(ch, cw)
+        occ = g.dense()
+        pad = np.zeros((ch * 4, cw * 4), bool)
+        pad[: g.height, : g.width] = occ
+        blk = pad.reshape(ch, 4, cw, 4).any(axis=(1, 3))
+        assert ((f == 0xFFFF) == blk).all()
+        sat = np.pad(blk.astype(np.int64).cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+        ys, xs = np.nonzero(~blk)
+        v = f[ys, xs].astype(np.int64)
+        x0 = np.clip(xs - (v & 15), 0, cw - 1)
+        x1 = np.clip(xs + ((v >> 4) & 15), 0, cw - 1)
+        y0 = np.clip(ys - ((v >> 8) & 15), 0, ch - 1)
+        y1 = np.clip(ys + (v >> 12), 0, ch - 1)
+        cnt = sat[y1 + 1, x1 + 1] - sat[y0, x1 + 1] - sat[y1 + 1, x0] + sat[y0, x0]
+        assert (cnt == 0).all()
+        assert ((v & 15) + ((v >> 4) & 15)).mean() > 2      # the rectangles are not trivial
