@@ -116,8 +116,8 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_beam_cos = take(B * 4);
     L->off_beam_sin = take(B * 4);
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
-    L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 1) & ~1) *
-                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK) * sizeof(uint16_t));
+    L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 2 * mrca::kSkipPadX + 1) & ~1) *
+                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK + 2 * mrca::kSkipPadY) * sizeof(uint16_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->total = off;
 }

@@ -102,7 +102,11 @@ struct GlobalGrid {  // bit lookups straight from the (L2-resident) bitmap
     int32_t width, height, wpr;
     MRCA_HD bool operator()(int ix, int iy) const {
         if (ix < 0 || iy < 0 || ix >= width || iy >= height) return false;
-        return (bits[iy * wpr + (ix >> 5)] >> (ix & 31)) & 1u;
+        return in_map(ix, iy);
+    }
+    // for cells known to lie inside the map (a cell of a non-empty block always does)
+    MRCA_HD bool in_map(int ix, int iy) const {
+        return (bits[(uint32_t)(iy * wpr + (ix >> 5))] >> (ix & 31)) & 1u;
     }
 };
 
@@ -169,12 +173,20 @@ constexpr int kSkipShift = 2;
 constexpr int kSkipK = 1 << kSkipShift;
 constexpr int kBlockFull = 0xFFFF;
 
+// The field is stored with a border of empty blocks (kSkipPadX columns left/right, kSkipPadY rows
+// below/above, value 0 = "empty, no extent"): clamping the block coordinates into the border replaces
+// every bounds check, and blocks outside the map read as what they are.
+constexpr int kSkipPadX = 2, kSkipPadY = 1;
+MRCA_HD int imin(int a, int b) { return a < b ? a : b; }
+MRCA_HD int imax(int a, int b) { return a > b ? a : b; }
+
 struct GlobalDist {  // free-rectangle field straight from global memory
-    const uint16_t* d;
+    const uint16_t* d;   // base of the padded array
     int32_t cw, ch, pitch;
     MRCA_HD int operator()(int cx, int cy) const {
-        if (cx < 0 || cy < 0 || cx >= cw || cy >= ch) return 0;  // outside the map: that block alone is free
-        return d[cy * pitch + cx];
+        const int x = imin(imax(cx + kSkipPadX, 0), cw + 2 * kSkipPadX - 1);   // -> v_med3_i32
+        const int y = imin(imax(cy + kSkipPadY, 0), ch + 2 * kSkipPadY - 1);
+        return d[(uint32_t)(y * pitch + x)];
     }
 };
 
@@ -262,7 +274,8 @@ MRCA_HD float grid_march_skip(const Occ& occ, const Dist& dist, const GridGeom& 
         bx = nbx;
         by = nby;
         v = dist(ix >> kSkipShift, iy >> kSkipShift);
-        if (v == kBlockFull && occ(ix, iy)) return t * g.cell;  // a cell of an empty block cannot be occupied
+        // a cell of an empty block cannot be occupied, and a non-empty block lies inside the map
+        if (v == kBlockFull && occ.in_map(ix, iy)) return t * g.cell;
     }
     return tmax;
 }

@@ -15,9 +15,10 @@ namespace mrca {
 // occupied cell gets kBlockFull.  The rectangle is grown greedily, one side at a time in the order
 // left, right, down, up, while the strip added is entirely empty (up to 15 blocks per side) -- any
 // empty rectangle containing the block is valid for the march, larger ones just save steps.
-// Rows are padded to an even number of blocks so a kernel can fetch two blocks per 32-bit load.
+// Storage: (ch + 2*kSkipPadY) rows of `pitch` entries, the map's block (0,0) at [kSkipPadY][kSkipPadX], the
+// border filled with 0 (see GlobalDist); pitch is even so a kernel can fetch two blocks per 32-bit load.
 inline void build_skip_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint16_t>* out,
-                             int* cw_out, int* ch_out, int* pitch_out = nullptr) {
+                             int* cw_out, int* ch_out, int* pitch_out) {
     const int cw = (width + kSkipK - 1) / kSkipK, ch = (height + kSkipK - 1) / kSkipK;
     std::vector<uint8_t> full((size_t)cw * ch, 0);
     for (int y = 0; y < height; ++y)
@@ -42,12 +43,12 @@ inline void build_skip_field(const uint32_t* bits, int width, int height, int wp
         return sat[(size_t)(y1 + 1) * (cw + 1) + x1 + 1] - sat[(size_t)y0 * (cw + 1) + x1 + 1] -
                sat[(size_t)(y1 + 1) * (cw + 1) + x0] + sat[(size_t)y0 * (cw + 1) + x0];
     };
-    const int pitch = pitch_out ? ((cw + 1) & ~1) : cw;
-    out->assign((size_t)pitch * ch, 0);
+    const int pitch = (cw + 2 * kSkipPadX + 1) & ~1;
+    out->assign((size_t)pitch * (ch + 2 * kSkipPadY), 0);
     for (int y = 0; y < ch; ++y)
         for (int x = 0; x < cw; ++x) {
             if (full[(size_t)y * cw + x]) {
-                (*out)[(size_t)y * pitch + x] = (uint16_t)kBlockFull;
+                (*out)[(size_t)(y + kSkipPadY) * pitch + x + kSkipPadX] = (uint16_t)kBlockFull;
                 continue;
             }
             int l = 0, r = 0, d = 0, u = 0;
@@ -59,11 +60,11 @@ inline void build_skip_field(const uint32_t* bits, int width, int height, int wp
                 if (u < 15 && count(x - l, y + u + 1, x + r, y + u + 1) == 0) { ++u; grew = true; }
             }
             if (l == 15 && r == 15 && d == 15 && u == 15) u = 14;  // keep kBlockFull unambiguous
-            (*out)[(size_t)y * pitch + x] = (uint16_t)(l | (r << 4) | (d << 8) | (u << 12));
+            (*out)[(size_t)(y + kSkipPadY) * pitch + x + kSkipPadX] = (uint16_t)(l | (r << 4) | (d << 8) | (u << 12));
         }
     *cw_out = cw;
     *ch_out = ch;
-    if (pitch_out) *pitch_out = pitch;
+    *pitch_out = pitch;
 }
 
 // Per-cell Chebyshev distance (in cells, saturated at 255) to the nearest occupied cell; 0 = occupied.

@@ -488,14 +488,15 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         // free-rectangle tile over the blocks a 6 m ray can reach, two blocks per 32-bit load (cx0 and the
         // field's row pitch are even); blocks outside the map are empty with no extent (0)
         const int cwi = tid & ((1 << e.ctile_lg) - 1);
-        const int gx = cx0 + 2 * cwi;
-        const bool ccolok = 2 * cwi < ctw && gx >= 0 && gx < e.skip_pitch;
+        const int gx = cx0 + 2 * cwi;   // even; the padded field starts kSkipPadX (even) blocks left of the map
+        const bool ccolok = 2 * cwi < ctw && gx >= -kSkipPadX && gx + kSkipPadX < e.skip_pitch;
         const uint32_t* skip32 = reinterpret_cast<const uint32_t*>(e.skip);
         uint32_t* ctile32 = reinterpret_cast<uint32_t*>(ctile);
         for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
             const int gy = cy0 + r;
             uint32_t val = 0u;
-            if (ccolok && gy >= 0 && gy < e.skip_ch) val = skip32[(gy * e.skip_pitch + gx) >> 1];
+            if (ccolok && gy >= -kSkipPadY && gy < e.skip_ch + kSkipPadY)
+                val = skip32[((gy + kSkipPadY) * e.skip_pitch + gx + kSkipPadX) >> 1];
             if (2 * cwi < ctw) ctile32[r * (e.ctile_stride >> 1) + cwi] = val;
         }
     }

@@ -87,9 +87,9 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
     std::vector<uint16_t> skipf;
-    int scw, sch;
-    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch);
-    const GlobalDist dist{skipf.data(), scw, sch, scw};
+    int scw, sch, spitch;
+    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch, &spitch);
+    const GlobalDist dist{skipf.data(), scw, sch, spitch};
     for (int n = 0; n < e->N; ++n) {
         const bool fresh = e->fresh[n] != 0;
         if (only_fresh && !fresh) continue;
@@ -255,9 +255,11 @@ void emul_step(const EmulEnv* e, const float* actions) {
 // plain vs skipping march on arbitrary rays (returns the number of coarse blocks for sizing)
 int emul_skip_field(const EmulEnv* e, uint16_t* out, int cap) {
     std::vector<uint16_t> f;
-    int cw, ch;
-    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch);
-    if ((int)f.size() <= cap) memcpy(out, f.data(), f.size() * 2);
+    int cw, ch, pitch;
+    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch, &pitch);
+    if (cw * ch <= cap)   // hand the un-padded [ch][cw] view to the test
+        for (int y = 0; y < ch; ++y)
+            memcpy(out + (size_t)y * cw, f.data() + (size_t)(y + kSkipPadY) * pitch + kSkipPadX, (size_t)cw * 2);
     return (cw << 16) | ch;
 }
 
@@ -266,9 +268,9 @@ void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
     std::vector<uint16_t> f;
-    int cw, ch;
-    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch);
-    const GlobalDist dist{f.data(), cw, ch, cw};
+    int cw, ch, pitch;
+    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch, &pitch);
+    const GlobalDist dist{f.data(), cw, ch, pitch};
     for (int i = 0; i < n; ++i) {
         out_plain[i] = grid_march(occ, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
         out_skip[i] = grid_march_skip(occ, dist, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
