@@ -68,7 +68,13 @@ def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
         env.step(U.random_actions(rng, sc.num_robots))
         ticks += 1
     dt = time.perf_counter() - t0
+    try:   # a container may expose more CPUs than its cgroup lets it use: say so next to `cores`
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        cpu_limit = "unlimited" if quota[0] == "max" else f"{int(quota[0]) / int(quota[1]):.1f} CPUs"
+    except Exception:
+        cpu_limit = "unknown"
     out = {"value": sc.num_robots * ticks / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+           "cgroup_cpu_limit": cpu_limit,
            "sample": f"C/OpenMP port of the oracle, {sc_name}: {worlds} worlds x {sc.robots_per_world} robots x 512 "
                      f"beams (the GPU workload), {ticks} ticks in {dt:.1f} s on {threads} host threads"}
     # NumPy oracle, one core, small sample

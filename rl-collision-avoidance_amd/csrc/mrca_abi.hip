@@ -311,8 +311,6 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.tile_stride = ((v.tile_h + 31) / 32 + 1) | 1;
     v.ctile_h = v.tile_h / mrca::kSkipK + 2;
     v.ctile_stride = v.tile_stride * (32 / mrca::kSkipK);
-    v.tile_lg = 0;
-    while ((1 << v.tile_lg) < v.tile_stride) ++v.tile_lg;
     v.ctile_lg = 0;
     while ((1 << v.ctile_lg) < v.ctile_stride / 2) ++v.ctile_lg;  // staged as 32-bit words (2 blocks each)
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
@@ -323,8 +321,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
     v.lds_tile = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
-    if (mrca::move_lds_bytes(v) > 64 * 1024 || (1 << v.ctile_lg) > (cfg->beams >> v.ray_shift) ||
-        (1 << v.tile_lg) > (cfg->beams >> v.ray_shift))
+    if (mrca::move_lds_bytes(v) > 64 * 1024 || (1 << v.ctile_lg) > (cfg->beams >> v.ray_shift))
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
                          (double)cfg->map_cell));
     if (env->lds_bytes > 160 * 1024)
@@ -406,14 +403,19 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     env->view.debug_flags = flags & 0x3F;
-    if (flags & 64) env->view.lds_tile = 1;    // tuning knobs: 64 selects the LDS-tile kernel,
+    if (flags & 64) {                          // tuning knobs: 64 selects the LDS-tile kernel,
+        mrca::EnvView probe = env->view;
+        probe.lds_tile = 1;
+        if (mrca::ray_lds_bytes(probe) > 160 * 1024)
+            return fail(MRCA_ERR_UNSUPPORTED, "LDS-tile kernel needs %zu B of LDS (> 160 KiB)", mrca::ray_lds_bytes(probe));
+        env->view.lds_tile = 1;
+    }
     if (flags & 128) env->view.lds_tile = 0;   // 128 the L2 kernel
     const int knob = (flags >> 8) & 7;  // 0 keeps the default; k > 0 selects beams >> (k-1) threads per robot
     if (knob) {
         const int shift = knob - 1;
         const int threads = env->cfg.beams >> shift;
-        if (threads < 64 || threads < (env->cfg.beams >> 2) || threads < (1 << env->view.ctile_lg) ||
-            threads < (1 << env->view.tile_lg))
+        if (threads < 64 || threads < (env->cfg.beams >> 2) || threads < (1 << env->view.ctile_lg))
             return fail(MRCA_ERR_INVALID, "threads-per-robot knob %d out of range", knob);
         env->view.ray_shift = shift;
     }

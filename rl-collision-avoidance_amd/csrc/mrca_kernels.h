@@ -58,8 +58,7 @@ struct EnvView {
     int32_t tile_stride;  // words per LDS row (odd)
     int32_t ctile_h;      // rows of the coarse distance tile
     int32_t ctile_stride; // blocks (u16) per coarse row in LDS
-    int32_t tile_lg;      // log2 of the staging column pitch (>= tile_stride)
-    int32_t ctile_lg;     // same for the coarse tile
+    int32_t ctile_lg;     // log2 of the staging column pitch of the block tile (32-bit words)
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel launches beams >> ray_shift threads per robot
     int32_t lds_tile;     // 1: raycast_kernel<true> (field tile staged in LDS), 0: raycast_kernel<false> (field from L2)
