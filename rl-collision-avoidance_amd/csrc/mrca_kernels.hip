@@ -140,10 +140,24 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     const bool valid = lane < e.R;
     const int n = world * e.R + (valid ? lane : 0);
 
+    // every per-robot input is requested up front so that all of it arrives in ONE memory round trip
     float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
     const bool live = e.live[n] != 0;
-    const float v = live ? sane_cmd(actions[n * 2 + 0]) : 0.0f;
-    const float w = live ? sane_cmd(actions[n * 2 + 1]) : 0.0f;
+    const float act_v = actions[n * 2 + 0], act_w = actions[n * 2 + 1];
+    float gx = e.goal[n * 2 + 0], gy = e.goal[n * 2 + 1];
+    float pdist = e.prev_dist[n];
+    int t = e.t[n];
+    float reward = e.reward[n];
+    uint8_t done = e.done[n];
+    uint8_t res = e.result[n];
+    uint8_t first = e.first_result[n];
+    uint8_t crashed = e.crashed[n];
+    int ep = e.episode[n];
+    const int rmode = valid ? e.reset_mode[lane] : 0;
+    const int gmode = valid ? e.goal_mode[lane] : 0;
+    const int gid = valid ? e.group_id[lane] : -1;
+    const float v = live ? sane_cmd(act_v) : 0.0f;
+    const float w = live ? sane_cmd(act_w) : 0.0f;
 
     // integrate: explicit Euler with the heading at tick start
     float s, c;
@@ -244,7 +258,6 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     // committed pose of a robot that is not involved: moves unless the map stops it
     const float ox_ = x, oy_ = y, os_ = s, oc_ = c;  // pose at tick start
     bool moved = moving && !involved && !shit;
-    uint8_t crashed = e.crashed[n];
     if (moving && !involved) crashed = shit ? 1 : 0;
     if (moved) {
         x = nx;
@@ -284,11 +297,8 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     const float wgt = moved ? w : 0.0f;
 
     // reward / terminal (stage_world1.py:180-211)
-    float gx = e.goal[n * 2 + 0], gy = e.goal[n * 2 + 1];
     const float ddx = gx - x, ddy = gy - y;
     const float dist = sqrtf(ddx * ddx + ddy * ddy);
-    float pdist = e.prev_dist[n];
-    int t = e.t[n];
     float rg = (pdist - dist) * kKProgress;
     const bool reach = dist < kGoalRadius;
     rg = reach ? kRArrive : rg;
@@ -301,10 +311,6 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     result = crash ? 2 : result;
     result = tout ? 3 : result;
     const bool done_now = reach || crash || tout;
-    float reward = e.reward[n];
-    uint8_t done = e.done[n];
-    uint8_t res = e.result[n];
-    uint8_t first = e.first_result[n];
     uint8_t lv = live ? 1 : 0;
     if (live) {
         reward = (rg + rc) + rw;
@@ -321,7 +327,6 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         fresh = valid && live && done_now;
     } else if (e.auto_reset == 2) {
         if (live && done_now) lv = 0;
-        const int gid = valid ? e.group_id[lane] : -1;
         for (int g = 0; g < e.num_groups; ++g) {
             const bool in = valid && (gid == g);
             const unsigned long long members = __ballot(in);
@@ -332,9 +337,6 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     float spv = v, spw = w, ovgt = vgt, owgt = wgt;
     if (e.debug_flags & 32) fresh = false;
     // new episodes, one robot at a time with the whole wave sampling for it
-    int ep = e.episode[n];
-    const int rmode = valid ? e.reset_mode[lane] : 0;
-    const int gmode = valid ? e.goal_mode[lane] : 0;
     unsigned long long pending = __ballot(fresh);
     while (pending) {
         const int src = __ffsll((long long)pending) - 1;
