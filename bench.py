@@ -178,6 +178,23 @@ def main():
     mv_ms, ray_ms, launches = env.read_timing()
     env.enable_timing(False)
 
+    # side figure (single GPU, env mode only, outside the timed region above): the same world driven by the
+    # fp32 policy instead of the action pool -- SURVEY 8d (ii).  `--mode rollout|train` time these properly.
+    if args.mode == "env" and world_size == 1 and not args.no_extra:
+        from mrca.trainer import make_bench_step
+        roll = make_bench_step(env, "rollout", None)
+        for k in range(10):
+            roll(k)
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        n_roll = 100
+        for k in range(n_roll):
+            roll(k)
+        torch.cuda.synchronize()
+        extra["rollout_side_figure"] = {"value": N * n_roll / (time.perf_counter() - tr0), "unit": "agent-steps/s",
+                                        "note": "env + fp32 CNNPolicy inference per tick, 100 ticks after 10 warm-up "
+                                                "ticks; not part of `value`"}
+
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
