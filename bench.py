@@ -53,6 +53,16 @@ def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
     bounded number of ticks; the NumPy oracle's single-core figure is reported alongside."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    # a container may expose more CPUs than its cgroup lets it use: size the OpenMP team to the quota
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        cpu_limit = None if quota[0] == "max" else int(quota[0]) / int(quota[1])
+    except Exception:
+        cpu_limit = None
+    usable = len(os.sched_getaffinity(0))
+    if cpu_limit is not None:
+        usable = max(1, min(usable, int(cpu_limit + 0.999)))
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable))
     import util as U
     from mrca import scenario as S
     sc = S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=0) if sc_name == "stage1" else \
@@ -68,13 +78,9 @@ def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
         env.step(U.random_actions(rng, sc.num_robots))
         ticks += 1
     dt = time.perf_counter() - t0
-    try:   # a container may expose more CPUs than its cgroup lets it use: say so next to `cores`
-        quota = open("/sys/fs/cgroup/cpu.max").read().split()
-        cpu_limit = "unlimited" if quota[0] == "max" else f"{int(quota[0]) / int(quota[1]):.1f} CPUs"
-    except Exception:
-        cpu_limit = "unknown"
     out = {"value": sc.num_robots * ticks / dt, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-           "cgroup_cpu_limit": cpu_limit,
+           "cgroup_cpu_limit": "unlimited" if cpu_limit is None else f"{cpu_limit:.1f} CPUs",
+           "visible_cpus": os.cpu_count(),
            "sample": f"C/OpenMP port of the oracle, {sc_name}: {worlds} worlds x {sc.robots_per_world} robots x 512 "
                      f"beams (the GPU workload), {ticks} ticks in {dt:.1f} s on {threads} host threads"}
     # NumPy oracle, one core, small sample
