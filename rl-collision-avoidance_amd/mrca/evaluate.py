@@ -59,6 +59,13 @@ def circle_test(env, policy_fn, max_ticks=1200):
     fr = env.first_result
     reach = fr == 1
     n_reach = int(reach.sum())
+    # the paper's metrics (Long et al. 2018, Sec. V-B) over the robots that reached their goal; the straight
+    # line is |goal - init| - goal radius (0.5 m) at the speed limit of 1 m/s, one tick = 0.1 s
+    straight = ((env.goal - env.init_pose[:, :2]).norm(dim=1) - 0.5).clamp(min=0.0)
+    time_s = ticks_to_goal * 0.1
+    extra_time = (time_s - straight / 1.0)[reach]
+    extra_dist = (path - straight)[reach]
+    avg_speed = (path / time_s.clamp(min=0.1))[reach]
     return {
         "robots": N, "ticks_run": k + 1,
         "success_rate": n_reach / N,
@@ -66,7 +73,10 @@ def circle_test(env, policy_fn, max_ticks=1200):
         "timeout_rate": float((fr == 3).float().mean()),
         "unfinished_rate": float((fr == 0).float().mean()),
         "mean_ticks_to_goal": float(ticks_to_goal[reach].mean()) if n_reach else None,
-        "mean_path_ratio": float((path[reach] / 50.0).mean()) if n_reach else None,
+        "mean_path_ratio": float((path[reach] / straight[reach].clamp(min=1e-6)).mean()) if n_reach else None,
+        "extra_time_s": float(extra_time.mean()) if n_reach else None,
+        "extra_distance_m": float(extra_dist.mean()) if n_reach else None,
+        "average_speed_mps": float(avg_speed.mean()) if n_reach else None,
     }
 
 

@@ -22,7 +22,8 @@ class OracleAsVec:
         self.N = sc.num_robots
 
     def _sync(self):
-        for k in ("obs", "local_goal", "speed", "speed_gt", "done", "first_result", "reward", "pose"):
+        for k in ("obs", "local_goal", "speed", "speed_gt", "done", "first_result", "reward", "pose", "goal",
+                  "init_pose"):
             setattr(self, k, torch.from_numpy(np.ascontiguousarray(getattr(self.o, k))).cuda())
 
     def reset(self):
