@@ -472,6 +472,10 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int world = n / e.R;
     const int local = n - world * e.R;
     const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
+    // the first wave also requests "its" neighbour candidate now, in the same memory round trip
+    const bool cand = (tid < e.R) && (tid != local);
+    const int jn = world * e.R + ((tid < kWave && cand) ? tid : local);
+    const float xj = e.pose[jn * 3 + 0], yj = e.pose[jn * 3 + 1], thj = e.pose[jn * 3 + 2];
     float s, c;
     sincos_det(th, &s, &c);
 
@@ -507,9 +511,6 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     // --- first wave: compact the world's other robots within lidar reach into LDS, each with the
     //     (conservative) interval of beams that can touch it
     if (tid < kWave) {
-        const bool cand = (tid < e.R) && (tid != local);
-        const int j = world * e.R + (cand ? tid : local);
-        const float xj = e.pose[j * 3 + 0], yj = e.pose[j * 3 + 1], thj = e.pose[j * 3 + 2];
         const float ddx = xj - x, ddy = yj - y;
         // conservative cull: a hit below 6 m needs the centre within 6 + circumradius(0.2907) m
         bool keep = cand && (ddx * ddx + ddy * ddy <= 39.69f);
