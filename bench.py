@@ -62,12 +62,12 @@ def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
     usable = len(os.sched_getaffinity(0))
     if cpu_limit is not None:
         usable = max(1, min(usable, int(cpu_limit + 0.999)))
-    os.environ.setdefault("OMP_NUM_THREADS", str(usable))
     import util as U
     from mrca import scenario as S
     sc = S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=0) if sc_name == "stage1" else \
         S.stage2(num_worlds=worlds, seed=0)
     env = U.COracleEnv(sc)
+    env.lib.oc_set_threads(int(os.environ.get("OMP_NUM_THREADS", usable)))   # the OpenMP runtime is already up (torch)
     threads = int(env.lib.oc_max_threads())
     env.reset()
     rng = np.random.default_rng(1)

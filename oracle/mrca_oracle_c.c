@@ -342,6 +342,15 @@ void oc_step(const oc_env* e, const float* actions) {
     oc_observe(e, 0);
 }
 
+void oc_set_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oc_max_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

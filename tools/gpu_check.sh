@@ -21,9 +21,9 @@ fi
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   echo "== rocprofv3 kernel trace"
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$TAG" -o trace -- python "$R/bench.py" --steps 300 --warmup 30 --no-cpu-baseline > "$R/gpurun_out/prof_trace.log" 2>&1; echo "trace rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$TAG" -o trace -- python "$R/bench.py" --steps 300 --warmup 30 --no-cpu-baseline --no-extra > "$R/gpurun_out/prof_trace.log" 2>&1; echo "trace rc=$?"
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/gpurun_out/prof_$TAG" -o pmc_$C -- python "$R/bench.py" --steps 60 --warmup 10 --no-cpu-baseline > "$R/gpurun_out/prof_pmc_$C.log" 2>&1; echo "pmc $C rc=$?"
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/gpurun_out/prof_$TAG" -o pmc_$C -- python "$R/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extra > "$R/gpurun_out/prof_pmc_$C.log" 2>&1; echo "pmc $C rc=$?"
   done
   cd "$R"
   find gpurun_out/prof_$TAG -type f | head -20
