@@ -29,6 +29,27 @@ def go_to_goal_policy(obs, local_goal, speed):
     return torch.stack([v, w], dim=1)
 
 
+def staggered_roundabout_policy(num_robots, bias=1.4, near=3.5, vgain=0.8, stop=0.5, slowest=0.5):
+    """A stand-in with NON-TRIVIAL outcomes on the circle test (78 % success / 22 % crashes for one circle):
+    head for the goal, veer right in proportion to how close the nearest return in the front sector is (a
+    roundabout), slow down before obstacles, and -- to break the perfect symmetry of the scenario, which no
+    memoryless symmetric rule survives -- give every robot its own speed limit in [slowest, 1] m/s."""
+    idx = torch.arange(num_robots) % 50
+    scale = slowest + (1.0 - slowest) * ((idx * 7) % 50).float() / 49.0
+
+    def fn(obs, local_goal, speed):
+        lx, ly = local_goal[:, 0], local_goal[:, 1]
+        bearing = torch.atan2(ly, lx)
+        dist = torch.sqrt(lx * lx + ly * ly)
+        front = ((obs[:, -1, 176:336] + 0.5) * 6.0).min(dim=1).values
+        prox = ((near - front) / near).clamp(0.0, 1.0)
+        target = bearing - bias * prox * (dist > 1.0).float()
+        w = torch.clamp(2.5 * target, -1.0, 1.0)
+        v = torch.clamp(vgain * (front - stop), 0.0, 1.0) * (target.abs() < 1.0).float() * scale.to(obs.device)
+        return torch.stack([v, w], dim=1)
+    return fn
+
+
 def cnn_policy_fn(policy):
     def fn(obs, local_goal, speed):
         _mean, scaled = ppo.generate_action_no_sampling(policy, obs, local_goal, speed, ACTION_BOUND)
@@ -84,7 +105,7 @@ def main():
     ap = argparse.ArgumentParser(description="circle test (circle_test.py) at scale on the MI355X env")
     ap.add_argument("--circles", type=int, default=1, help="independent 50-robot circles (50 -> 50 000 robots: 1000)")
     ap.add_argument("--policy", default=None, help="state_dict file with the reference's keys (policy/stage2.pth)")
-    ap.add_argument("--max-ticks", type=int, default=1200)
+    ap.add_argument("--max-ticks", type=int, default=1200)   # circle_world.py:198 allows 10000
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     from .vec_env import VecStageWorld
@@ -94,7 +115,7 @@ def main():
         pol.load_state_dict(torch.load(a.policy, map_location=env.device))
         fn, name = cnn_policy_fn(pol), a.policy
     else:
-        fn, name = go_to_goal_policy, "go-to-goal stand-in (no checkpoint given)"
+        fn, name = staggered_roundabout_policy(env.N), "staggered-roundabout stand-in (no checkpoint given)"
     out = circle_test(env, fn, a.max_ticks)
     out["policy"] = name
     print(json.dumps(out))

@@ -18,7 +18,7 @@ class OracleAsVec:
     """The oracle behind the VecStageWorld surface, tensors on the GPU (test helper only)."""
 
     def __init__(self, sc):
-        self.o = U.oracle_env(sc, np.float32)
+        self.o = U.COracleEnv(sc)      # plain-C port, bit-identical to the NumPy oracle (tests/test_oracle_c.py)
         self.N = sc.num_robots
 
     def _sync(self):
@@ -51,14 +51,16 @@ def test_circle_success_rate_parity(which):
         fn = evaluate.cnn_policy_fn(pol)
         ticks = 120
     else:
-        fn = evaluate.go_to_goal_policy
-        ticks = 540
+        fn = evaluate.staggered_roundabout_policy(sc.num_robots)
+        ticks = 1100
     env = VecStageWorld(sc)
     m_hip = evaluate.circle_test(env, fn, max_ticks=ticks)
     ora = OracleAsVec(sc)
     m_ora = evaluate.circle_test(ora, fn, max_ticks=ticks)
     print(which, "HIP:", m_hip, "oracle:", m_ora)
     assert m_hip["success_rate"] == m_ora["success_rate"]
+    if which == "controller":
+        assert 0.3 < m_hip["success_rate"] < 1.0 and m_hip["crash_rate"] > 0.02   # a non-trivial outcome mix
     assert m_hip["crash_rate"] == m_ora["crash_rate"]
     assert m_hip["ticks_run"] == m_ora["ticks_run"]
     assert np.array_equal(env.first_result.cpu().numpy(), ora.o.first_result)
@@ -72,7 +74,7 @@ def test_circle_at_scale_runs():
     from mrca import evaluate
     from mrca.vec_env import VecStageWorld
     env = VecStageWorld(S.circle(num_worlds=200, seed=0))     # 10 000 robots
-    m = evaluate.circle_test(env, evaluate.go_to_goal_policy, max_ticks=60)
+    m = evaluate.circle_test(env, evaluate.staggered_roundabout_policy(env.N), max_ticks=60)
     assert m["robots"] == 10000 and 0.0 <= m["success_rate"] <= 1.0
     # every circle is the same deterministic scenario -> identical outcomes per circle
     fr = env.first_result.view(200, 50)
