@@ -1,11 +1,14 @@
 // mrca_kernels.hip -- gfx950 kernels of the batched Stage tick.
 //
 //   move_kernel    one 64-lane wavefront per world, lane = robot.  Latch action, integrate,
-//                  outline-vs-grid test, then the collision pass in robot order (Stage moves
-//                  its models one after another): iteration i broadcasts robot i's provisional
-//                  pose, every lane runs the rectangle SAT against its own current pose and a
-//                  wavefront ballot decides revert+stall.  Reward / terminal / episode
-//                  bookkeeping (Philox resets, group-synchronous episodes) follow in-lane.
+//                  outline-vs-grid test (skipped where the per-cell distance field proves the
+//                  footprint free; otherwise patches pulled into LDS by the whole wave and walked
+//                  four lanes per robot), then the collision pass in robot order (Stage moves its
+//                  models one after another): a broad phase picks the robots that can touch
+//                  anybody, each of them takes a turn -- its provisional pose is broadcast, every
+//                  lane runs the rectangle SAT against the pose it has at that point of the
+//                  order, a wavefront ballot decides revert+stall.  Reward / terminal / episode
+//                  bookkeeping (wave-parallel Philox resets, group ballots) follow.
 //   raycast_kernel one 256-thread workgroup per robot, two beams per thread.  The other robots of
 //                  the world within lidar reach are compacted into LDS by the first wave (ballot
 //                  + popcount) together with a per-beam bitmask of who can touch which beam, while
@@ -82,6 +85,7 @@ __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local
 // Wave-parallel rejection sampling: the 64 lanes evaluate 64 consecutive attempts k at once and the
 // lowest acceptable k wins -- the same draw the one-lane loop (sample_pose / sample_goal) returns,
 // without a wavefront waiting on one unlucky robot's long tail.  All arguments are wave-uniform.
+// lane must be wave-uniform: v_readlane_b32
 __device__ __forceinline__ int ibcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float fbcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -128,10 +132,6 @@ struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
         return (t[(iy - y0) * stride + ((ix >> 5) - w0)] >> (ix & 31)) & 1u;
     }
 };
-
-__device__ __forceinline__ float bcast(float v, int lane) {  // lane is wave-uniform: v_readlane_b32
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
 
 __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     bool involved = false;
     if (!(e.debug_flags & 16)) {
         for (int j = 0; j < e.R; ++j) {
-            const float ax = nx - bcast(x, j), ay = ny - bcast(y, j);
-            const float bx2 = nx - bcast(nx, j), by2 = ny - bcast(ny, j);
+            const float ax = nx - fbcast(x, j), ay = ny - fbcast(y, j);
+            const float bx2 = nx - fbcast(nx, j), by2 = ny - fbcast(ny, j);
             const float d_old = ax * ax + ay * ay, d_new = bx2 * bx2 + by2 * by2;
             if (j != lane && (d_old <= 0.3392f || d_new <= 0.3392f)) involved = true;  // (2*0.2907 + 0.001)^2
         }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         while (turn) {
             const int i = __ffsll((long long)turn) - 1;
             turn &= turn - 1;
-            const float xi = bcast(nx, i), yi = bcast(ny, i), si = bcast(ns, i), ci = bcast(nc, i);
+            const float xi = fbcast(nx, i), yi = fbcast(ny, i), si = fbcast(ns, i), ci = fbcast(nc, i);
             // robots after i in the order have not moved yet when i is tested
             const bool later = lane > i;
             const float cx_ = later ? ox_ : x, cy_ = later ? oy_ : y, cs_ = later ? os_ : s, cc_ = later ? oc_ : c;
