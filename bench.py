@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--scenario", default="stage1", choices=["stage1", "stage2"])
     ap.add_argument("--policy-dtype", default="f32", choices=["f32", "bf16"],
                     help="rollout/train: dtype of the policy INFERENCE pass (update stays fp32); f32 = the reference's")
+    ap.add_argument("--update-dtype", default="f32", choices=["f32", "bf16"],
+                    help="train: autocast dtype of the PPO update (master weights stay fp32); f32 = the reference's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the rollout/train side figures")
     args = ap.parse_args()
@@ -163,7 +165,8 @@ def main():
     else:
         from mrca.trainer import make_bench_step
         step_fn = make_bench_step(env, args.mode, dist,
-                                  inference_dtype=torch.bfloat16 if args.policy_dtype == "bf16" else None)
+                                  inference_dtype=torch.bfloat16 if args.policy_dtype == "bf16" else None,
+                                  update_dtype=torch.bfloat16 if args.update_dtype == "bf16" else None)
 
     if args.mode == "train":
         # warm-up must cover whole horizons so that MIOpen tuning / allocator growth of the FIRST update
@@ -221,7 +224,8 @@ def main():
                                    f"robots/GPU, 512 beams, 3 frames, cell {sc.grid.cell} m, auto-reset, "
                                    f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}",
                        "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode,
-                       "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None},
+                       "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
+                       "ppo_update_dtype": args.update_dtype if args.mode == "train" else None},
             "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(N),
                          "traffic_note": "bytes/launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; "

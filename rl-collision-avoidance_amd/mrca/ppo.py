@@ -144,15 +144,17 @@ def _minibatches(n, batch_size, drop_last, generator=None, device=None):
 
 
 def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, drop_last, value_coef,
-                index_batches, dist, flat_grads, log):
+                index_batches, dist, flat_grads, log, autocast_dtype=None):
     obss, goals, speeds, actions, logprobs, targets, advs = flat
     n = advs.shape[0]
     for _ in range(epoch):
         batches = index_batches(n) if index_batches is not None else \
             _minibatches(n, batch_size, drop_last, device=advs.device)
         for index in batches:
-            new_value, new_logprob, dist_entropy = policy.evaluate_actions(obss[index], goals[index], speeds[index],
-                                                                           actions[index])
+            with torch.autocast(advs.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+                new_value, new_logprob, dist_entropy = policy.evaluate_actions(obss[index], goals[index],
+                                                                               speeds[index], actions[index])
+            new_value, new_logprob = new_value.float(), new_logprob.float()
             ratio = torch.exp(new_logprob - logprobs[index])
             adv = advs[index]
             surrogate1 = ratio * adv
@@ -174,7 +176,7 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
 
 def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entropy=0.02, clip_value=0.2,
                       num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *, value_coef=20.0,
-                      index_batches=None, dist=None, flat_grads=None, log=None):
+                      index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None):
     """model/ppo.py:143-194.  ``memory`` = (obss, goals, speeds, actions, logprobs, targets, values,
     rewards, advs) as device tensors shaped [T, N, ...]."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -184,12 +186,12 @@ def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entrop
     flat = (obss.reshape(n, frames, obs_size), goals.reshape(n, 2), speeds.reshape(n, 2),
             actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1), advs.reshape(n, 1))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, False, value_coef,
-                index_batches, dist, flat_grads, log)
+                index_batches, dist, flat_grads, log, autocast_dtype)
 
 
 def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch, coeff_entropy=0.02,
                       clip_value=0.2, num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *,
-                      value_coef=20.0, index_batches=None, dist=None, flat_grads=None, log=None):
+                      value_coef=20.0, index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None):
     """model/ppo.py:197-259: the advantage statistics use ALL transitions, then the filtered rows
     are deleted and minibatches use drop_last=True."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -203,4 +205,4 @@ def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch
                                    actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1),
                                    advs.reshape(n, 1)))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, True, value_coef,
-                index_batches, dist, flat_grads, log)
+                index_batches, dist, flat_grads, log, autocast_dtype)

@@ -31,6 +31,7 @@ class HParams:
     value_coef: float = 20.0          # model/ppo.py:185
     action_bound: tuple = ((0.0, -1.0), (1.0, 1.0))   # ppo_stage1.py:170
     inference_dtype: object = None    # None = fp32 like the reference; torch.bfloat16 = opt-in fast rollouts
+    update_dtype: object = None       # autocast dtype of the PPO update's forward/backward (opt-in)
 
 
 def broadcast_parameters(module, dist):
@@ -87,7 +88,8 @@ class Stage1Trainer:
         kw = dict(policy=self.policy, optimizer=self.optimizer, batch_size=hp.batch_size, memory=memory,
                   epoch=hp.epoch, coeff_entropy=hp.coeff_entropy, clip_value=hp.clip_value, num_step=hp.horizon,
                   num_env=env.N, frames=hp.laser_hist, obs_size=hp.obs_size, act_size=hp.act_size,
-                  value_coef=hp.value_coef, dist=self.dist, flat_grads=self.flat_grads, log=self.loss_log)
+                  value_coef=hp.value_coef, dist=self.dist, flat_grads=self.flat_grads, log=self.loss_log,
+                  autocast_dtype=hp.update_dtype)
         if self.stage2:
             ppo.ppo_update_stage2(filter_index=ppo.get_filter_index(buf.done), **kw)
         else:
@@ -101,9 +103,9 @@ class Stage1Trainer:
             self.tick()
 
 
-def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None):
+def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, update_dtype=None):
     """bench.py --mode rollout|train: returns step_fn(k) doing one tick for all robots."""
-    hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype)
+    hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype, update_dtype=update_dtype)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0)
     tr.started = True  # bench.py resets the env itself
     if mode == "rollout":
