@@ -277,6 +277,20 @@ void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const
     }
 }
 
+// beam-interval culling: for n neighbour centres (robot frame), the interval the product would test
+void emul_beam_interval(int n, const float* lx, const float* ly, int beams, int* lo, int* hi) {
+    for (int i = 0; i < n; ++i) beam_interval(lx[i], ly[i], beams, &lo[i], &hi[i]);
+}
+
+void emul_ray_box(int n, const float* ox, const float* oy, const float* dx, const float* dy, const float* xj,
+                  const float* yj, const float* sj, const float* cj, float* t) {
+    for (int i = 0; i < n; ++i) t[i] = ray_box(ox[i], oy[i], dx[i], dy[i], xj[i], yj[i], sj[i], cj[i]);
+}
+
+int emul_obb(float xi, float yi, float si, float ci, float xj, float yj, float sj, float cj) {
+    return obb_overlap(xi, yi, si, ci, xj, yj, sj, cj) ? 1 : 0;
+}
+
 void emul_sincos(const float* th, int n, float* s, float* c) {
     for (int i = 0; i < n; ++i) sincos_det(th[i], &s[i], &c[i]);
 }
