@@ -79,6 +79,24 @@ def test_odd_sizes_and_synthetic_map(hip):
         sc = S.stage1(num_worlds=W, robots_per_world=R, seed=21 + R, grid=g)
         sc.frames, sc.beams = frames, beams
         _run_exact(hip, sc, 25, R, check_every=2)
+    # a fine grid (2.5 cm cells), the widest scan (1024 beams) and the deepest frame stack (8)
+    gf = U.small_grid(cell=0.025, size=14.0, ring_radius=6.2, blocks=[(0.5, 0.5, 1.5, 1.0)])
+    sc = S.stage1(num_worlds=2, robots_per_world=5, seed=77, grid=gf)
+    sc.frames, sc.beams = 8, 1024
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    rng = np.random.default_rng(3)
+    poses = np.stack([rng.uniform(-4, 4, 10), rng.uniform(-4, 4, 10), rng.uniform(-3, 3, 10)], 1).astype(np.float32)
+    goals = rng.uniform(-4, 4, (10, 2)).astype(np.float32)
+    env.reset(None, torch.from_numpy(poses).cuda(), torch.from_numpy(goals).cuda())
+    ora.reset(None, poses, goals)
+    for k in range(20):
+        a = U.random_actions(rng, 10)
+        env.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+    torch.cuda.synchronize()
+    U.assert_state_equal(U.HostView(env), ora, what="fine grid / 1024 beams / 8 frames")
+    env.close()
 
 
 def test_masked_reset_and_overrides(hip):
