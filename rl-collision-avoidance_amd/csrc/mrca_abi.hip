@@ -117,7 +117,7 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_beam_sin = take(B * 4);
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
     L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 2 * mrca::kSkipPadX + 1) & ~1) *
-                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK + 2 * mrca::kSkipPadY) * sizeof(uint16_t));
+                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK + 2 * mrca::kSkipPadY) * sizeof(uint32_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->total = off;
 }
@@ -232,11 +232,11 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_sin, bsin.data(), B * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_map, cfg->map_bits,
                            (size_t)cfg->map_height * cfg->map_words_per_row * 4, hipMemcpyHostToDevice));
-    std::vector<uint16_t> skip;
+    std::vector<uint32_t> skip;
     int skip_cw = 0, skip_ch = 0, skip_pitch = 0;
     mrca::build_skip_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &skip, &skip_cw,
                            &skip_ch, &skip_pitch);
-    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     {
         std::vector<uint8_t> cf;
         mrca::build_cell_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &cf);
@@ -285,7 +285,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.beam_cos = reinterpret_cast<const float*>(a + L.off_beam_cos);
     v.beam_sin = reinterpret_cast<const float*>(a + L.off_beam_sin);
     v.map_bits = reinterpret_cast<const uint32_t*>(a + L.off_map);
-    v.skip = reinterpret_cast<const uint16_t*>(a + L.off_skip);
+    v.skip = reinterpret_cast<const uint32_t*>(a + L.off_skip);
     v.skip_cw = skip_cw;
     v.skip_ch = skip_ch;
     v.skip_pitch = skip_pitch;
@@ -312,7 +312,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.ctile_h = v.tile_h / mrca::kSkipK + 2;
     v.ctile_stride = v.tile_stride * (32 / mrca::kSkipK);
     v.ctile_lg = 0;
-    while ((1 << v.ctile_lg) < v.ctile_stride / 2) ++v.ctile_lg;  // staged as 32-bit words (2 blocks each)
+    while ((1 << v.ctile_lg) < v.ctile_stride) ++v.ctile_lg;  // staged one 32-bit block entry per thread
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.debug_flags = 0;
     // 256 threads per 512-beam robot (2 beams each): 8 resident workgroups per CU instead of 4 hide the
@@ -321,7 +321,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
     v.lds_tile = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
-    if (mrca::move_lds_bytes(v) > 64 * 1024 || (1 << v.ctile_lg) > (cfg->beams >> v.ray_shift))
+    if (mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
                          (double)cfg->map_cell));
     if (env->lds_bytes > 160 * 1024)
@@ -406,8 +406,9 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (flags & 64) {                          // tuning knobs: 64 selects the LDS-tile kernel,
         mrca::EnvView probe = env->view;
         probe.lds_tile = 1;
-        if (mrca::ray_lds_bytes(probe) > 160 * 1024)
-            return fail(MRCA_ERR_UNSUPPORTED, "LDS-tile kernel needs %zu B of LDS (> 160 KiB)", mrca::ray_lds_bytes(probe));
+        if (mrca::ray_lds_bytes(probe) > 160 * 1024 || (1 << probe.ctile_lg) > (env->cfg.beams >> probe.ray_shift))
+            return fail(MRCA_ERR_UNSUPPORTED, "LDS-tile kernel needs %zu B of LDS / %d staging columns: not available "
+                        "for this map_cell / beams", mrca::ray_lds_bytes(probe), 1 << probe.ctile_lg);
         env->view.lds_tile = 1;
     }
     if (flags & 128) env->view.lds_tile = 0;   // 128 the L2 kernel
@@ -415,7 +416,8 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (knob) {
         const int shift = knob - 1;
         const int threads = env->cfg.beams >> shift;
-        if (threads < 64 || threads < (env->cfg.beams >> 2) || threads < (1 << env->view.ctile_lg))
+        if (threads < 64 || threads < (env->cfg.beams >> 2) ||
+            (env->view.lds_tile && threads < (1 << env->view.ctile_lg)))
             return fail(MRCA_ERR_INVALID, "threads-per-robot knob %d out of range", knob);
         env->view.ray_shift = shift;
     }

@@ -10,14 +10,14 @@
 namespace mrca {
 
 // Free-rectangle field for grid_march_skip: blocks of kSkipK x kSkipK cells.  For an EMPTY block the
-// entry packs four 4-bit extents L | R<<4 | D<<8 | U<<12 of a rectangle of empty blocks
+// entry packs four 8-bit extents L | R<<8 | D<<16 | U<<24 of a rectangle of empty blocks
 // [cx-L, cx+R] x [cy-D, cy+U] around it (blocks outside the map are empty); a block holding an
 // occupied cell gets kBlockFull.  The rectangle is grown greedily, one side at a time in the order
-// left, right, down, up, while the strip added is entirely empty (up to 15 blocks per side) -- any
+// left, right, down, up, while the strip added is entirely empty (up to kSkipMaxExtent blocks per side) -- any
 // empty rectangle containing the block is valid for the march, larger ones just save steps.
 // Storage: (ch + 2*kSkipPadY) rows of `pitch` entries, the map's block (0,0) at [kSkipPadY][kSkipPadX], the
-// border filled with 0 (see GlobalDist); pitch is even so a kernel can fetch two blocks per 32-bit load.
-inline void build_skip_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint16_t>* out,
+// border filled with 0 (see GlobalDist).
+inline void build_skip_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint32_t>* out,
                              int* cw_out, int* ch_out, int* pitch_out) {
     const int cw = (width + kSkipK - 1) / kSkipK, ch = (height + kSkipK - 1) / kSkipK;
     std::vector<uint8_t> full((size_t)cw * ch, 0);
@@ -28,14 +28,15 @@ inline void build_skip_field(const uint32_t* bits, int width, int height, int wp
                 const int b = __builtin_ctz(v);
                 v &= v - 1;
                 const int x = w * 32 + b;
-                if (x < width) full[(size_t)(y >> kSkipShift) * cw + (x >> kSkipShift)] = 1;
+                if (x < width)  // 2x2 occupancy of the block, bit (y&1)*2 + (x&1)
+                    full[(size_t)(y >> kSkipShift) * cw + (x >> kSkipShift)] |= (uint8_t)(1u << (((y & 1) << 1) | (x & 1)));
             }
         }
     // summed-area table of non-empty blocks for O(1) strip tests (blocks outside the map count as empty)
     std::vector<int> sat((size_t)(cw + 1) * (ch + 1), 0);
     for (int y = 0; y < ch; ++y)
         for (int x = 0; x < cw; ++x)
-            sat[(size_t)(y + 1) * (cw + 1) + x + 1] = full[(size_t)y * cw + x] + sat[(size_t)y * (cw + 1) + x + 1] +
+            sat[(size_t)(y + 1) * (cw + 1) + x + 1] = (full[(size_t)y * cw + x] != 0) + sat[(size_t)y * (cw + 1) + x + 1] +
                                                       sat[(size_t)(y + 1) * (cw + 1) + x] - sat[(size_t)y * (cw + 1) + x];
     auto count = [&](int x0, int y0, int x1, int y1) -> int {  // inclusive block rectangle, clipped to the map
         x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, cw - 1); y1 = std::min(y1, ch - 1);
@@ -48,19 +49,20 @@ inline void build_skip_field(const uint32_t* bits, int width, int height, int wp
     for (int y = 0; y < ch; ++y)
         for (int x = 0; x < cw; ++x) {
             if (full[(size_t)y * cw + x]) {
-                (*out)[(size_t)(y + kSkipPadY) * pitch + x + kSkipPadX] = (uint16_t)kBlockFull;
+                (*out)[(size_t)(y + kSkipPadY) * pitch + x + kSkipPadX] = kBlockFull | full[(size_t)y * cw + x];
                 continue;
             }
             int l = 0, r = 0, d = 0, u = 0;
             for (bool grew = true; grew;) {
                 grew = false;
-                if (l < 15 && count(x - l - 1, y - d, x - l - 1, y + u) == 0) { ++l; grew = true; }
-                if (r < 15 && count(x + r + 1, y - d, x + r + 1, y + u) == 0) { ++r; grew = true; }
-                if (d < 15 && count(x - l, y - d - 1, x + r, y - d - 1) == 0) { ++d; grew = true; }
-                if (u < 15 && count(x - l, y + u + 1, x + r, y + u + 1) == 0) { ++u; grew = true; }
+                const int M = kSkipMaxExtent;   // < 255, so a packed entry can never equal kBlockFull
+                if (l < M && count(x - l - 1, y - d, x - l - 1, y + u) == 0) { ++l; grew = true; }
+                if (r < M && count(x + r + 1, y - d, x + r + 1, y + u) == 0) { ++r; grew = true; }
+                if (d < M && count(x - l, y - d - 1, x + r, y - d - 1) == 0) { ++d; grew = true; }
+                if (u < M && count(x - l, y + u + 1, x + r, y + u + 1) == 0) { ++u; grew = true; }
             }
-            if (l == 15 && r == 15 && d == 15 && u == 15) u = 14;  // keep kBlockFull unambiguous
-            (*out)[(size_t)(y + kSkipPadY) * pitch + x + kSkipPadX] = (uint16_t)(l | (r << 4) | (d << 8) | (u << 12));
+            (*out)[(size_t)(y + kSkipPadY) * pitch + x + kSkipPadX] =
+                (uint32_t)l | ((uint32_t)r << 8) | ((uint32_t)d << 16) | ((uint32_t)u << 24);
         }
     *cw_out = cw;
     *ch_out = ch;

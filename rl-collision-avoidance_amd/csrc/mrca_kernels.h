@@ -41,7 +41,7 @@ struct EnvView {
     const float* beam_sin;
     // occupancy grid + coarse free-distance field (grid_march_skip)
     const uint32_t* map_bits;
-    const uint16_t* skip;                   // free-rectangle field, one u16 per 4x4-cell block
+    const uint32_t* skip;                   // free-rectangle field, one u32 per kSkipK x kSkipK-cell block
     int32_t skip_cw, skip_ch, skip_pitch;  // pitch: padded row length in blocks (even)
     const uint8_t* cellfield;  // per-cell Chebyshev distance to the nearest occupied cell [map_h][map_w]
     GridGeom g;
@@ -57,7 +57,7 @@ struct EnvView {
     int32_t tile_h;       // rows = 2*rc+1
     int32_t tile_stride;  // words per LDS row (odd)
     int32_t ctile_h;      // rows of the coarse distance tile
-    int32_t ctile_stride; // blocks (u16) per coarse row in LDS
+    int32_t ctile_stride; // blocks (u32) per row of the LDS block tile (raycast_kernel<true>)
     int32_t ctile_lg;     // log2 of the staging column pitch of the block tile (32-bit words)
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel launches beams >> ray_shift threads per robot

@@ -14,8 +14,8 @@
 //                  + popcount) together with a per-beam bitmask of who can touch which beam, while
 //                  every beam already runs the exact skipping march over the free-rectangle field
 //                  (<true>: its tile staged in LDS; <false>, the default: read from the L1/L2-
-//                  resident copy -- a ray needs ~5 lookups; occupancy bits of non-empty blocks come
-//                  from the L2-resident bitmap), then slab-tests its neighbours.  Scan, normalised
+//                  resident copy -- a ray needs ~4 lookups; a non-empty block's entry carries its
+//                  2x2 occupancy bits, so the cell bitmap is never read), then slab-tests its neighbours.  Scan, normalised
 //                  observation and the frame-stack shift leave through LDS as 16-byte stores.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
 //   gae_kernel     reverse GAE scan, thread per robot, coalesced over N.
@@ -30,9 +30,9 @@ namespace {
 constexpr int kWave = 64;
 
 struct TileDist {  // free-rectangle field lookups in LDS
-    const uint16_t* d;
+    const uint32_t* d;
     int cy0, cx0, stride;
-    __device__ __forceinline__ int operator()(int cx, int cy) const {
+    __device__ __forceinline__ uint32_t operator()(int cx, int cy) const {
         return d[__mul24(cy - cy0, stride) + (cx - cx0)];
     }
 };
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(rbuf + e.B);   // [B] neighbours per beam
-    uint16_t* ctile = reinterpret_cast<uint16_t*>(nbmask + e.B);
+    uint32_t* ctile = reinterpret_cast<uint32_t*>(nbmask + e.B);
 
     const int world = n / e.R;
     const int local = n - world * e.R;
@@ -491,19 +491,17 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
     for (int b = tid; b < e.B; b += blockDim.x) nbmask[b] = 0ull;
     if (kLdsTile && !(e.debug_flags & 4)) {
-        // free-rectangle tile over the blocks a 6 m ray can reach, two blocks per 32-bit load (cx0 and the
-        // field's row pitch are even); blocks outside the map are empty with no extent (0)
+        // free-rectangle tile over the blocks a 6 m ray can reach; blocks outside the padded field are empty
+        // with no extent (0)
         const int cwi = tid & ((1 << e.ctile_lg) - 1);
-        const int gx = cx0 + 2 * cwi;   // even; the padded field starts kSkipPadX (even) blocks left of the map
-        const bool ccolok = 2 * cwi < ctw && gx >= -kSkipPadX && gx + kSkipPadX < e.skip_pitch;
-        const uint32_t* skip32 = reinterpret_cast<const uint32_t*>(e.skip);
-        uint32_t* ctile32 = reinterpret_cast<uint32_t*>(ctile);
+        const int gx = cx0 + cwi;
+        const bool ccolok = cwi < ctw && gx >= -kSkipPadX && gx + kSkipPadX < e.skip_pitch;
         for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
             const int gy = cy0 + r;
             uint32_t val = 0u;
             if (ccolok && gy >= -kSkipPadY && gy < e.skip_ch + kSkipPadY)
-                val = skip32[((gy + kSkipPadY) * e.skip_pitch + gx + kSkipPadX) >> 1];
-            if (2 * cwi < ctw) ctile32[r * (e.ctile_stride >> 1) + cwi] = val;
+                val = e.skip[(gy + kSkipPadY) * e.skip_pitch + gx + kSkipPadX];
+            if (cwi < ctw) ctile[r * e.ctile_stride + cwi] = val;
         }
     }
     __syncthreads();  // tile staged
@@ -537,9 +535,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
     }
     // --- beams: thread t takes beams t, t + blockDim, ... (one each in the default launch)
-    // occupancy bits are only consulted inside non-empty 4x4 blocks (~1-2 lookups per ray): they come
-    // straight from the L2-resident bitmap, only the coarse free-distance tile lives in LDS
-    const GlobalGrid occ{e.map_bits, e.g.width, e.g.height, e.g.wpr};
+    // the field is all the march reads: non-empty blocks carry their own 2x2 occupancy bits
     const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
     for (int b = tid; b < e.B; b += blockDim.x) {
         const float bc = e.beam_cos[b], bs = e.beam_sin[b];
@@ -548,10 +544,10 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         if (e.debug_flags & 6) {
             rbuf[b] = kRangeMax;
         } else if (kLdsTile) {
-            rbuf[b] = grid_march_skip(occ, dist, e.g, x, y, dx, dy, kRangeMax);
+            rbuf[b] = grid_march_skip(dist, e.g, x, y, dx, dy, kRangeMax);
         } else {
             const GlobalDist gdist{e.skip, e.skip_cw, e.skip_ch, e.skip_pitch};
-            rbuf[b] = grid_march_skip(occ, gdist, e.g, x, y, dx, dy, kRangeMax);
+            rbuf[b] = grid_march_skip(gdist, e.g, x, y, dx, dy, kRangeMax);
         }
     }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
@@ -626,7 +622,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 
 size_t ray_lds_bytes(const EnvView& e) {
     return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 +
-           (e.lds_tile ? (size_t)e.ctile_h * e.ctile_stride * sizeof(uint16_t) : 0);
+           (e.lds_tile ? (size_t)e.ctile_h * e.ctile_stride * sizeof(uint32_t) : 0);
 }
 
 size_t move_lds_bytes(const EnvView& e) {

@@ -86,7 +86,7 @@ static void begin_episode(const EmulEnv* e, int n, int local, float curx, float 
 void emul_raycast(const EmulEnv* e, int only_fresh) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
-    std::vector<uint16_t> skipf;
+    std::vector<uint32_t> skipf;
     int scw, sch, spitch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch, &spitch);
     const GlobalDist dist{skipf.data(), scw, sch, spitch};
@@ -117,7 +117,7 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
             const float bc = e->beam_cos[b], bs = e->beam_sin[b];
             const float dx = c * bc - s * bs;
             const float dy = s * bc + c * bs;
-            float rng = grid_march_skip(occ, dist, g, x, y, dx, dy, kRangeMax);
+            float rng = grid_march_skip(dist, g, x, y, dx, dy, kRangeMax);
             for (size_t k = 0; k < nb.size(); k += 4) {
                 if (b < nbi[k / 2] || b > nbi[k / 2 + 1]) continue;
                 const float t = ray_box(x, y, dx, dy, nb[k], nb[k + 1], nb[k + 2], nb[k + 3]);
@@ -253,13 +253,13 @@ void emul_step(const EmulEnv* e, const float* actions) {
 }
 
 // plain vs skipping march on arbitrary rays (returns the number of coarse blocks for sizing)
-int emul_skip_field(const EmulEnv* e, uint16_t* out, int cap) {
-    std::vector<uint16_t> f;
+int emul_skip_field(const EmulEnv* e, uint32_t* out, int cap) {
+    std::vector<uint32_t> f;
     int cw, ch, pitch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch, &pitch);
     if (cw * ch <= cap)   // hand the un-padded [ch][cw] view to the test
         for (int y = 0; y < ch; ++y)
-            memcpy(out + (size_t)y * cw, f.data() + (size_t)(y + kSkipPadY) * pitch + kSkipPadX, (size_t)cw * 2);
+            memcpy(out + (size_t)y * cw, f.data() + (size_t)(y + kSkipPadY) * pitch + kSkipPadX, (size_t)cw * 4);
     return (cw << 16) | ch;
 }
 
@@ -267,13 +267,13 @@ void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const
                 const float* tmax, float* out_plain, float* out_skip) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
-    std::vector<uint16_t> f;
+    std::vector<uint32_t> f;
     int cw, ch, pitch;
     build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch, &pitch);
     const GlobalDist dist{f.data(), cw, ch, pitch};
     for (int i = 0; i < n; ++i) {
         out_plain[i] = grid_march(occ, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
-        out_skip[i] = grid_march_skip(occ, dist, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
+        out_skip[i] = grid_march_skip(dist, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
     }
 }
 
