@@ -153,8 +153,10 @@ const char* mrca_last_error(void);
  * recorded launches in milliseconds and clears the ring. */
 int mrca_enable_timing(mrca_env* env, int32_t on); /* on = n > 0: time every n-th step; 0: off */
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
-/* Profiling ablations ONLY (results are wrong while any flag is set): 1 = skip robot-robot lidar
- * tests, 2 = skip the grid march, 4 = skip tile staging (implies 2).  0 restores the product path. */
+/* Profiling ablations ONLY (results are wrong while any of bits 0-5 is set): 1 = skip robot-robot lidar
+ * tests, 2 = skip the grid march, 8 / 16 / 32 = move kernel without its outline test / collision loop /
+ * resets.  Bits 8-10 = k > 0 launch the ray cast with beams >> (k-1) threads per robot (a tuning knob:
+ * results are unchanged).  0 restores the product path. */
 int mrca_set_debug_flags(mrca_env* env, int32_t flags);
 
 #ifdef __cplusplus

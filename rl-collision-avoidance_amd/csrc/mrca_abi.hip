@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -38,7 +40,7 @@ struct Layout {
     size_t field_off[MRCA_F_COUNT];
     size_t field_bytes[MRCA_F_COUNT];
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
-    size_t off_beam_cos, off_beam_sin, off_map, off_skip, off_cellfield;
+    size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield;
     size_t total;
 };
 
@@ -116,13 +118,42 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_beam_cos = take(B * 4);
     L->off_beam_sin = take(B * 4);
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
-    L->off_skip = take((size_t)((((c->map_width + mrca::kSkipK - 1) / mrca::kSkipK) + 2 * mrca::kSkipPadX + 1) & ~1) *
-                       ((c->map_height + mrca::kSkipK - 1) / mrca::kSkipK + 2 * mrca::kSkipPadY) * sizeof(uint32_t));
+    L->off_free_rect = take((size_t)(c->map_width + 2 * mrca::kFieldPadX) * (c->map_height + 2 * mrca::kFieldPadY) *
+                            sizeof(uint32_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->total = off;
 }
 
 constexpr int kTimingRing = 1024;
+
+// The free-rectangle field depends on the map only and takes ~1 s of host time for an 800 x 800 map:
+// environments created on the same map in one process (one per rank thread, per test, per bench leg)
+// share one host copy.  Keyed by the bitmap itself.
+struct HostField {
+    std::vector<uint32_t> bits;
+    int32_t width, height, wpr;
+    std::vector<uint32_t> entries;
+    int pitch;
+};
+std::shared_ptr<const HostField> host_field(const mrca_config* c) {
+    static std::mutex mu;
+    static std::vector<std::shared_ptr<const HostField>> cache;
+    const size_t words = (size_t)c->map_height * c->map_words_per_row;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& f : cache)
+        if (f->width == c->map_width && f->height == c->map_height && f->wpr == c->map_words_per_row &&
+            std::memcmp(f->bits.data(), c->map_bits, words * 4) == 0)
+            return f;
+    auto f = std::make_shared<HostField>();
+    f->bits.assign(c->map_bits, c->map_bits + words);
+    f->width = c->map_width;
+    f->height = c->map_height;
+    f->wpr = c->map_words_per_row;
+    mrca::build_free_rect_field(c->map_bits, c->map_width, c->map_height, c->map_words_per_row, &f->entries, &f->pitch);
+    if (cache.size() >= 4) cache.erase(cache.begin());
+    cache.push_back(f);
+    return f;
+}
 
 }  // namespace
 
@@ -232,11 +263,13 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_sin, bsin.data(), B * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_map, cfg->map_bits,
                            (size_t)cfg->map_height * cfg->map_words_per_row * 4, hipMemcpyHostToDevice));
-    std::vector<uint32_t> skip;
-    int skip_cw = 0, skip_ch = 0, skip_pitch = 0;
-    mrca::build_skip_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &skip, &skip_cw,
-                           &skip_ch, &skip_pitch);
-    HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_skip, skip.data(), skip.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    int free_rect_pitch = 0;
+    {
+        const std::shared_ptr<const HostField> hf = host_field(cfg);
+        free_rect_pitch = hf->pitch;
+        HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_free_rect, hf->entries.data(), hf->entries.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice));
+    }
     {
         std::vector<uint8_t> cf;
         mrca::build_cell_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &cf);
@@ -285,10 +318,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.beam_cos = reinterpret_cast<const float*>(a + L.off_beam_cos);
     v.beam_sin = reinterpret_cast<const float*>(a + L.off_beam_sin);
     v.map_bits = reinterpret_cast<const uint32_t*>(a + L.off_map);
-    v.skip = reinterpret_cast<const uint32_t*>(a + L.off_skip);
-    v.skip_cw = skip_cw;
-    v.skip_ch = skip_ch;
-    v.skip_pitch = skip_pitch;
+    v.free_rect = reinterpret_cast<const uint32_t*>(a + L.off_free_rect);
+    v.free_rect_pitch = free_rect_pitch;
     v.cellfield = reinterpret_cast<const uint8_t*>(a + L.off_cellfield);
     v.g.x0 = cfg->map_x0;
     v.g.y0 = cfg->map_y0;
@@ -304,22 +335,12 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.num_groups = num_groups;
     v.key0 = (uint32_t)(cfg->seed & 0xFFFFFFFFull);
     v.key1 = (uint32_t)(cfg->seed >> 32);
-    // tile: every cell a 6 m ray can enter lies within ceil(6/cell) cells of the start cell;
-    // +2 cells of slack for the rounding of the closed-form boundary times
-    v.tile_rc = (int32_t)std::ceil(mrca::kRangeMax * v.g.inv_cell) + 2;
-    v.tile_h = 2 * v.tile_rc + 1;
-    v.tile_stride = ((v.tile_h + 31) / 32 + 1) | 1;
-    v.ctile_h = v.tile_h / mrca::kSkipK + 2;
-    v.ctile_stride = v.tile_stride * (32 / mrca::kSkipK);
-    v.ctile_lg = 0;
-    while ((1 << v.ctile_lg) < v.ctile_stride) ++v.ctile_lg;  // staged one 32-bit block entry per thread
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.debug_flags = 0;
     // 256 threads per 512-beam robot (2 beams each): 8 resident workgroups per CU instead of 4 hide the
     // per-robot latency chain (pose -> tile -> march -> store) better; measured 54.5 vs 62.0 us at 4096
     // robots (profiles/r01_h_ablation.txt)
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
-    v.lds_tile = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
@@ -403,21 +424,11 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     env->view.debug_flags = flags & 0x3F;
-    if (flags & 64) {                          // tuning knobs: 64 selects the LDS-tile kernel,
-        mrca::EnvView probe = env->view;
-        probe.lds_tile = 1;
-        if (mrca::ray_lds_bytes(probe) > 160 * 1024 || (1 << probe.ctile_lg) > (env->cfg.beams >> probe.ray_shift))
-            return fail(MRCA_ERR_UNSUPPORTED, "LDS-tile kernel needs %zu B of LDS / %d staging columns: not available "
-                        "for this map_cell / beams", mrca::ray_lds_bytes(probe), 1 << probe.ctile_lg);
-        env->view.lds_tile = 1;
-    }
-    if (flags & 128) env->view.lds_tile = 0;   // 128 the L2 kernel
     const int knob = (flags >> 8) & 7;  // 0 keeps the default; k > 0 selects beams >> (k-1) threads per robot
     if (knob) {
         const int shift = knob - 1;
         const int threads = env->cfg.beams >> shift;
-        if (threads < 64 || threads < (env->cfg.beams >> 2) ||
-            (env->view.lds_tile && threads < (1 << env->view.ctile_lg)))
+        if (threads < 64 || threads < (env->cfg.beams >> 2))
             return fail(MRCA_ERR_INVALID, "threads-per-robot knob %d out of range", knob);
         env->view.ray_shift = shift;
     }

@@ -154,12 +154,12 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Same result as grid_march, far fewer steps: empty-space skipping over a coarse field of FREE
-// RECTANGLES.  The grid is cut into kSkipK x kSkipK-cell blocks; for every empty block the field
-// stores a rectangle of empty blocks around it -- 8-bit extents (left, right, down, up), so the
-// blocks [cx-L, cx+R] x [cy-D, cy+U] hold no occupied cell -- and kBlockFull for a block that is not
-// empty.  A ray in an empty block jumps straight to the face where it leaves that rectangle (in a
-// corridor the rectangle runs the length of the corridor); in a non-empty block it steps cell by cell.
+// Same result as grid_march, far fewer steps: empty-space skipping over a per-cell field of FREE
+// RECTANGLES.  For every empty cell the field stores a rectangle of empty cells around it -- 8-bit
+// extents (left, right, down, up), so the cells [ix-L, ix+R] x [iy-D, iy+U] are all empty -- and
+// kCellOccupied for an occupied cell.  A ray jumps straight to the face where it leaves the rectangle
+// of the cell it is in (in a corridor the rectangle runs the length of the corridor) and looks again:
+// ~2 lookups per lidar ray on the reference maps, and the cell bitmap is never read.
 //
 // Exactness: grid_march is a 2-way merge of the x-crossing events tx(b) and the y-crossing events
 // ty(b) (both monotone in b), ties -> y first.  Leaving the rectangle through its x face Bx happens
@@ -169,51 +169,45 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 // 0.01 cell of a boundary, so the walk resumes in precisely the cell, and with precisely the pending
 // boundaries, the cell-by-cell walk would have -- every later comparison, and the returned entry
 // time, are bit-identical.
-// 2x2-cell blocks and extents up to 63 blocks were chosen by counting march events on the reference maps
-// (per-wavefront maximum 3.9 / 3.4 on stage1 / stage2, against 5.5 / 6.5 for 4x4 blocks with 4-bit extents).
-constexpr int kSkipShift = 1;
-constexpr int kSkipK = 1 << kSkipShift;
-constexpr int kSkipMaxExtent = 63;
-// a non-empty block stores kBlockFull | its own 2x2 occupancy bits (bit (iy&1)*2 + (ix&1)), so the march
-// never touches the cell bitmap; the extent bytes of an empty block are <= kSkipMaxExtent, so < kBlockFull
-constexpr uint32_t kBlockFull = 0xFFFFFFF0u;
-static_assert(kSkipK == 2, "a non-empty block keeps its 2x2 occupancy in the low 4 bits of its entry");
-MRCA_HD bool block_cell_occupied(uint32_t v, int ix, int iy) {
-    return v >= kBlockFull && ((v >> (((iy & 1) << 1) | (ix & 1))) & 1u);
-}
+//
+// Granularity (measured, 4096 / 8228 robots, profiles/r01_u..z_ablation.txt): 4x4-cell blocks with
+// 4-bit extents 48 / 130 us per ray-cast launch on stage-1 / stage-2; 2x2-cell blocks with 8-bit
+// extents 38 / 77 us; per cell 34 / 43 us.  The per-cell field is 0.6 / 2.6 MB for the 20 m / 40 m maps
+// and stays L2-resident.
+constexpr int kFieldMaxExtent = 127;             // cells per side; 6 m of range is 120 cells at 0.05 m
+constexpr uint32_t kCellOccupied = 0xFFFFFFFFu;  // extents are <= 127, so no empty cell packs to this
 
-// The field is stored with a border of empty blocks (kSkipPadX columns left/right, kSkipPadY rows
-// below/above, value 0 = "empty, no extent"): clamping the block coordinates into the border replaces
-// every bounds check, and blocks outside the map read as what they are.
-constexpr int kSkipPadX = 2, kSkipPadY = 1;
+// The field is stored with a border of empty cells (kFieldPadX columns left/right, kFieldPadY rows
+// below/above, value 0 = "empty, no extent"): clamping the cell coordinates into the border replaces
+// every bounds check, and cells outside the map read as what they are.
+constexpr int kFieldPadX = 2, kFieldPadY = 1;
 MRCA_HD int imin(int a, int b) { return a < b ? a : b; }
 MRCA_HD int imax(int a, int b) { return a > b ? a : b; }
 
-struct GlobalDist {  // free-rectangle field straight from global memory
+struct FreeRectField {   // free-rectangle field straight from global memory (L1/L2-resident)
     const uint32_t* d;   // base of the padded array
-    int32_t cw, ch, pitch;
-    MRCA_HD uint32_t operator()(int cx, int cy) const {
-        const int x = imin(imax(cx + kSkipPadX, 0), cw + 2 * kSkipPadX - 1);   // -> v_med3_i32
-        const int y = imin(imax(cy + kSkipPadY, 0), ch + 2 * kSkipPadY - 1);
+    int32_t w, h, pitch; // map size in cells, entries per padded row
+    MRCA_HD uint32_t operator()(int ix, int iy) const {
+        const int x = imin(imax(ix + kFieldPadX, 0), w + 2 * kFieldPadX - 1);   // -> v_med3_i32
+        const int y = imin(imax(iy + kFieldPadY, 0), h + 2 * kFieldPadY - 1);
         return d[(uint32_t)(y * pitch + x)];
     }
 };
 
-// Flat, branch-poor form (one loop, one "event" per iteration, x/y handled by selects) so the 64 rays
-// of a wavefront stay in lock step: an iteration is either a jump to the face of the free rectangle
-// or a single cell step (non-empty block: the "rectangle" is the current cell).  No (tx, ty) state is
-// carried -- boundary times are always re-derived from the closed form, which is what makes every
-// path through here produce the same numbers as grid_march.
-template <class Dist>
-MRCA_HD float grid_march_skip(const Dist& dist, const GridGeom& g, float ox, float oy, float dx, float dy,
+// Flat, branch-poor form (one loop, one jump per iteration, x/y handled by selects) so the 64 rays of
+// a wavefront stay in lock step.  No (tx, ty) state is carried -- boundary times are always re-derived
+// from the closed form, which is what makes every path through here produce the same numbers as
+// grid_march.
+template <class Field>
+MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, float oy, float dx, float dy,
                               float tmax) {
     const float fx = (ox - g.x0) * g.inv_cell;
     const float fy = (oy - g.y0) * g.inv_cell;
     int ix = (int)floorf(fx);
     int iy = (int)floorf(fy);
     const float tmax_c = tmax * g.inv_cell;
-    uint32_t v = dist(ix >> kSkipShift, iy >> kSkipShift);  // carried: one field lookup per event
-    if (block_cell_occupied(v, ix, iy)) return 0.0f;
+    uint32_t v = field(ix, iy);  // carried: one field lookup per jump
+    if (v == kCellOccupied) return 0.0f;
     if (!(tmax_c > 0.0f)) return tmax;
     const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
     const float inv_dx = xnz ? 1.0f / dx : kInf;
@@ -225,14 +219,10 @@ MRCA_HD float grid_march_skip(const Dist& dist, const GridGeom& g, float ox, flo
     int bx = ix + (xpos ? 1 : 0);  // next pending boundary on each axis
     int by = iy + (ypos ? 1 : 0);
     for (int guard = 0; guard < kMaxMarchSteps; ++guard) {
-        const int cx = ix >> kSkipShift, cy = iy >> kSkipShift;
-        const bool jump = v < kBlockFull;
-        // faces of the region known to be free: the stored rectangle of blocks, or just this cell
+        // faces of the rectangle known to be free: boundary (i + e + 1) going up, (i - e) going down
         const int ex = (int)((v >> shx) & 255u), ey = (int)((v >> shy) & 255u);
-        const int boxx = (cx + ((ex ^ mx) - mx) + (xpos ? 1 : 0)) << kSkipShift;  // (c + e + 1) or (c - e)
-        const int boxy = (cy + ((ey ^ my) - my) + (ypos ? 1 : 0)) << kSkipShift;
-        const int Bx = jump ? boxx : bx;
-        const int By = jump ? boxy : by;
+        const int Bx = ix + ((ex ^ mx) - mx) + (xpos ? 1 : 0);
+        const int By = iy + ((ey ^ my) - my) + (ypos ? 1 : 0);
         const float rawx = ((float)Bx - fx) * inv_dx;
         const float rawy = ((float)By - fy) * inv_dy;
         const float tBx = xnz ? rawx : kInf;
@@ -247,7 +237,7 @@ MRCA_HD float grid_march_skip(const Dist& dist, const GridGeom& g, float ox, flo
         const int sS = xe ? sy : sx;
         const int bS0 = xe ? by : bx;
         int bS = bS0;
-        if (jump & (xe ? ynz : xnz)) {
+        if (xe ? ynz : xnz) {
             // position on the secondary axis at time t.  The consumed crossings are exactly those on
             // the near side of p* = fS + t*dS*(1 +- 2.4e-7) (rounding of 1/dS and of the closed form),
             // and pT differs from p* by < 1e-4 cells (|t*dS| <= 170, |fS| <= 2^11).  So when pT is
@@ -282,9 +272,8 @@ MRCA_HD float grid_march_skip(const Dist& dist, const GridGeom& g, float ox, flo
         iy = (xe ? nby - sy : By) + my;
         bx = nbx;
         by = nby;
-        v = dist(ix >> kSkipShift, iy >> kSkipShift);
-        // blocks outside the map read as empty (the zero border), like cells outside the map
-        if (block_cell_occupied(v, ix, iy)) return t * g.cell;
+        v = field(ix, iy);  // cells outside the map read as empty (the zero border)
+        if (v == kCellOccupied) return t * g.cell;
     }
     return tmax;
 }

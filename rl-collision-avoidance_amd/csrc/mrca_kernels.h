@@ -39,10 +39,10 @@ struct EnvView {
     // lidar beam directions in the robot frame (stageros.cpp:495-497), fp64-computed, fp32-rounded
     const float* beam_cos;
     const float* beam_sin;
-    // occupancy grid + coarse free-distance field (grid_march_skip)
+    // occupancy grid (move kernel) + per-cell free-rectangle field (grid_march_skip, ray-cast kernel)
     const uint32_t* map_bits;
-    const uint32_t* skip;                   // free-rectangle field, one u32 per kSkipK x kSkipK-cell block
-    int32_t skip_cw, skip_ch, skip_pitch;  // pitch: padded row length in blocks (even)
+    const uint32_t* free_rect;   // [map_h + 2*kFieldPadY][free_rect_pitch], see FreeRectField
+    int32_t free_rect_pitch;     // padded row length in entries
     const uint8_t* cellfield;  // per-cell Chebyshev distance to the nearest occupied cell [map_h][map_w]
     GridGeom g;
     // rules
@@ -52,17 +52,9 @@ struct EnvView {
     int32_t auto_reset;
     int32_t num_groups;
     uint32_t key0, key1;
-    // LDS tile geometry for the ray cast
-    int32_t tile_rc;      // half extent in cells
-    int32_t tile_h;       // rows = 2*rc+1
-    int32_t tile_stride;  // words per LDS row (odd)
-    int32_t ctile_h;      // rows of the coarse distance tile
-    int32_t ctile_stride; // blocks (u32) per row of the LDS block tile (raycast_kernel<true>)
-    int32_t ctile_lg;     // log2 of the staging column pitch of the block tile (32-bit words)
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel launches beams >> ray_shift threads per robot
-    int32_t lds_tile;     // 1: raycast_kernel<true> (field tile staged in LDS), 0: raycast_kernel<false> (field from L2)
-    int32_t debug_flags;  // profiling ablations only: 1 no neighbour tests, 2 no march, 4 no staging
+    int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags)
 };
 
 size_t ray_lds_bytes(const EnvView& e);

@@ -12,11 +12,10 @@
 //   raycast_kernel one 256-thread workgroup per robot, two beams per thread.  The other robots of
 //                  the world within lidar reach are compacted into LDS by the first wave (ballot
 //                  + popcount) together with a per-beam bitmask of who can touch which beam, while
-//                  every beam already runs the exact skipping march over the free-rectangle field
-//                  (<true>: its tile staged in LDS; <false>, the default: read from the L1/L2-
-//                  resident copy -- a ray needs ~4 lookups; a non-empty block's entry carries its
-//                  2x2 occupancy bits, so the cell bitmap is never read), then slab-tests its neighbours.  Scan, normalised
-//                  observation and the frame-stack shift leave through LDS as 16-byte stores.
+//                  every beam already runs the exact skipping march over the per-cell free-rectangle
+//                  field (read from its L1/L2-resident copy: ~2 lookups per ray, the cell bitmap is
+//                  never touched), then slab-tests its neighbours.  Scan, normalised observation and
+//                  the frame-stack shift leave through LDS as 16-byte stores.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
 //   gae_kernel     reverse GAE scan, thread per robot, coalesced over N.
 //
@@ -28,14 +27,6 @@ namespace mrca {
 namespace {
 
 constexpr int kWave = 64;
-
-struct TileDist {  // free-rectangle field lookups in LDS
-    const uint32_t* d;
-    int cy0, cx0, stride;
-    __device__ __forceinline__ uint32_t operator()(int cx, int cy) const {
-        return d[__mul24(cy - cy0, stride) + (cx - cx0)];
-    }
-};
 
 __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
                                               float* py, float* pth, float* gx, float* gy, float* pdist,
@@ -441,33 +432,33 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
     return (b % 8) * per + b / 8;
 }
 
-// kLdsTile = true : the free-rectangle tile around the robot is staged into LDS and the march reads it there;
-// kLdsTile = false: the march reads the field straight from the L1/L2-resident global copy (nothing staged).
-// Same arithmetic, same results; which one is launched is a tuning decision (mrca_abi.hip).
-template <bool kLdsTile>
+// The march reads the free-rectangle field straight from its L1/L2-resident global copy: ~2 dependent
+// lookups per ray.  (Staging a tile of it in LDS per robot was measured slower at every granularity tried,
+// the tile costs more to fill than the few lookups it serves.)
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int n = block_to_robot(blockIdx.x, e.N);
     const int tid = threadIdx.x;
-    const bool fresh = e.fresh[n] != 0;
-    if (only_fresh && !fresh) return;  // block-uniform
+    const uint8_t fresh_flag = e.fresh[n];
 
-    // the two frames that will be shifted down are fetched now, long before they are stored again
+    // the two frames that will be shifted down are fetched now, long before they are stored again -- and
+    // without waiting for the fresh flag (a robot that did start an episode just ignores them)
     float4 keep1 = make_float4(0.f, 0.f, 0.f, 0.f), keep2 = keep1;
     const bool wide = tid < (e.B >> 2);
     const int fstride = e.B >> 2;
     float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B) + tid;
-    if (wide && !fresh && e.F == 3) {
+    if (wide && !only_fresh && e.F == 3) {
         keep1 = ob4[fstride];
         keep2 = ob4[2 * fstride];
     }
+    const bool fresh = fresh_flag != 0;
+    if (only_fresh && !fresh) return;  // block-uniform
 
     float4* nb = reinterpret_cast<float4*>(lds);
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(rbuf + e.B);   // [B] neighbours per beam
-    uint32_t* ctile = reinterpret_cast<uint32_t*>(nbmask + e.B);
 
     const int world = n / e.R;
     const int local = n - world * e.R;
@@ -479,32 +470,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     float s, c;
     sincos_det(th, &s, &c);
 
-    // --- geometry of the block tile around the robot (cells a 6 m ray can reach, + slack)
-    const int ix0 = (int)floorf((x - e.g.x0) * e.g.inv_cell);
-    const int iy0 = (int)floorf((y - e.g.y0) * e.g.inv_cell);
-    const int ty0 = iy0 - e.tile_rc;
-    const int tw0 = (ix0 - e.tile_rc) >> 5;
-    const int tw = ((ix0 + e.tile_rc) >> 5) - tw0 + 1;
-    const int cy0 = ty0 >> kSkipShift;
-    const int cx0 = tw0 * (32 / kSkipK);
-    const int ctw = tw * (32 / kSkipK);
-    const int cth = ((ty0 + e.tile_h - 1) >> kSkipShift) - cy0 + 1;
     for (int b = tid; b < e.B; b += blockDim.x) nbmask[b] = 0ull;
-    if (kLdsTile && !(e.debug_flags & 4)) {
-        // free-rectangle tile over the blocks a 6 m ray can reach; blocks outside the padded field are empty
-        // with no extent (0)
-        const int cwi = tid & ((1 << e.ctile_lg) - 1);
-        const int gx = cx0 + cwi;
-        const bool ccolok = cwi < ctw && gx >= -kSkipPadX && gx + kSkipPadX < e.skip_pitch;
-        for (int r = tid >> e.ctile_lg; r < cth; r += blockDim.x >> e.ctile_lg) {
-            const int gy = cy0 + r;
-            uint32_t val = 0u;
-            if (ccolok && gy >= -kSkipPadY && gy < e.skip_ch + kSkipPadY)
-                val = e.skip[(gy + kSkipPadY) * e.skip_pitch + gx + kSkipPadX];
-            if (cwi < ctw) ctile[r * e.ctile_stride + cwi] = val;
-        }
-    }
-    __syncthreads();  // tile staged
+    __syncthreads();  // masks cleared before the first wave scatters into them
 
     // --- first wave: compact the world's other robots within lidar reach into LDS, each with the
     //     (conservative) interval of beams that can touch it
@@ -535,20 +502,12 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
     }
     // --- beams: thread t takes beams t, t + blockDim, ... (one each in the default launch)
-    // the field is all the march reads: non-empty blocks carry their own 2x2 occupancy bits
-    const TileDist dist{ctile, cy0, cx0, e.ctile_stride};
+    const FreeRectField field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
     for (int b = tid; b < e.B; b += blockDim.x) {
         const float bc = e.beam_cos[b], bs = e.beam_sin[b];
         const float dx = c * bc - s * bs;
         const float dy = s * bc + c * bs;
-        if (e.debug_flags & 6) {
-            rbuf[b] = kRangeMax;
-        } else if (kLdsTile) {
-            rbuf[b] = grid_march_skip(dist, e.g, x, y, dx, dy, kRangeMax);
-        } else {
-            const GlobalDist gdist{e.skip, e.skip_cw, e.skip_ch, e.skip_pitch};
-            rbuf[b] = grid_march_skip(gdist, e.g, x, y, dx, dy, kRangeMax);
-        }
+        rbuf[b] = (e.debug_flags & 2) ? kRangeMax : grid_march_skip(field, e.g, x, y, dx, dy, kRangeMax);
     }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
     const int cnt = *nb_count;
@@ -621,8 +580,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 }  // namespace
 
 size_t ray_lds_bytes(const EnvView& e) {
-    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12 +
-           (e.lds_tile ? (size_t)e.ctile_h * e.ctile_stride * sizeof(uint32_t) : 0);
+    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12;
 }
 
 size_t move_lds_bytes(const EnvView& e) {
@@ -641,12 +599,7 @@ void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, con
 }
 
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
-    if (e.lds_tile)
-        hipLaunchKernelGGL(raycast_kernel<true>, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e,
-                           only_fresh);
-    else
-        hipLaunchKernelGGL(raycast_kernel<false>, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e,
-                           only_fresh);
+    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e, only_fresh);
 }
 
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <map>
 #include <vector>
 
 #include "../../rl-collision-avoidance_amd/csrc/mrca_device.h"
@@ -35,6 +36,20 @@ struct EmulEnv {
     int32_t pre_dist_zero, auto_reset, num_groups;
     uint32_t key0, key1;
 };
+
+// the free-rectangle field of a map, built once per distinct map (keyed by a hash of the bitmap)
+struct CachedField {
+    std::vector<uint32_t> f;
+    int pitch = 0;
+};
+static const CachedField& field_of(const EmulEnv* e) {
+    static std::map<uint64_t, CachedField> cache;
+    uint64_t h = 1469598103934665603ull ^ ((uint64_t)e->width << 32) ^ (uint64_t)e->height;
+    for (size_t i = 0; i < (size_t)e->height * e->wpr; ++i) h = (h ^ e->map_bits[i]) * 1099511628211ull;
+    CachedField& c = cache[h];
+    if (c.f.empty()) build_free_rect_field(e->map_bits, e->width, e->height, e->wpr, &c.f, &c.pitch);
+    return c;
+}
 
 static GridGeom geom(const EmulEnv* e) {
     GridGeom g;
@@ -85,11 +100,8 @@ static void begin_episode(const EmulEnv* e, int n, int local, float curx, float 
 
 void emul_raycast(const EmulEnv* e, int only_fresh) {
     const GridGeom g = geom(e);
-    const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
-    std::vector<uint32_t> skipf;
-    int scw, sch, spitch;
-    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &skipf, &scw, &sch, &spitch);
-    const GlobalDist dist{skipf.data(), scw, sch, spitch};
+    const CachedField& cf = field_of(e);
+    const FreeRectField dist{cf.f.data(), e->width, e->height, cf.pitch};
     for (int n = 0; n < e->N; ++n) {
         const bool fresh = e->fresh[n] != 0;
         if (only_fresh && !fresh) continue;
@@ -252,25 +264,22 @@ void emul_step(const EmulEnv* e, const float* actions) {
     emul_raycast(e, 0);
 }
 
-// plain vs skipping march on arbitrary rays (returns the number of coarse blocks for sizing)
-int emul_skip_field(const EmulEnv* e, uint32_t* out, int cap) {
-    std::vector<uint32_t> f;
-    int cw, ch, pitch;
-    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch, &pitch);
-    if (cw * ch <= cap)   // hand the un-padded [ch][cw] view to the test
-        for (int y = 0; y < ch; ++y)
-            memcpy(out + (size_t)y * cw, f.data() + (size_t)(y + kSkipPadY) * pitch + kSkipPadX, (size_t)cw * 4);
-    return (cw << 16) | ch;
+// the product's free-rectangle field, un-padded [height][width], for the soundness test
+int emul_free_rect_field(const EmulEnv* e, uint32_t* out, int cap) {
+    const CachedField& cf = field_of(e);
+    if (e->width * e->height > cap) return -1;
+    for (int y = 0; y < e->height; ++y)
+        memcpy(out + (size_t)y * e->width, cf.f.data() + (size_t)(y + kFieldPadY) * cf.pitch + kFieldPadX,
+               (size_t)e->width * 4);
+    return 0;
 }
 
 void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const float* dx, const float* dy,
                 const float* tmax, float* out_plain, float* out_skip) {
     const GridGeom g = geom(e);
     const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
-    std::vector<uint32_t> f;
-    int cw, ch, pitch;
-    build_skip_field(e->map_bits, e->width, e->height, e->wpr, &f, &cw, &ch, &pitch);
-    const GlobalDist dist{f.data(), cw, ch, pitch};
+    const CachedField& cf = field_of(e);
+    const FreeRectField dist{cf.f.data(), e->width, e->height, cf.pitch};
     for (int i = 0; i < n; ++i) {
         out_plain[i] = grid_march(occ, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);
         out_skip[i] = grid_march_skip(dist, g, ox[i], oy[i], dx[i], dy[i], tmax[i]);

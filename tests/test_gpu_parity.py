@@ -259,10 +259,11 @@ def test_full_batch_bit_exact_vs_c_oracle(hip, name, worlds, R, steps):
     env.close()
 
 
-@pytest.mark.parametrize("knob,label", [(64, "LDS tile"), (128, "L2 field")])
-def test_both_raycast_variants_bit_exact(hip, knob, label):
-    """raycast_kernel<true> (free-rectangle tile staged in LDS) and raycast_kernel<false> (field read from the
-    L2-resident copy) are the same arithmetic: both must match the oracle bit-for-bit."""
+@pytest.mark.parametrize("knob,label", [(256, "1 beam per thread"), (512, "2 beams per thread"),
+                                        (768, "4 beams per thread")])
+def test_raycast_launch_shapes_bit_exact(hip, knob, label):
+    """The threads-per-robot tuning knob only changes how beams are dealt to threads: every launch shape
+    must match the oracle bit-for-bit."""
     for sc in (S.stage1(num_worlds=4, robots_per_world=16, seed=5), S.stage2(num_worlds=1, seed=5)):
         env = hip.VecStageWorld(sc)
         env.set_debug_flags(knob)

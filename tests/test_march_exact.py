@@ -55,33 +55,24 @@ def test_skipping_march_equals_plain_walk_and_oracle(name):
 
 
 def test_free_rectangle_field_is_sound():
-    """Every rectangle stored for an empty block must contain no occupied cell (the march's only
-    assumption about the field), and non-empty blocks must be flagged."""
+    """Every rectangle stored for an empty cell must contain no occupied cell (the march's only
+    assumption about the field), and occupied cells must be flagged."""
     for sc in (S.stage1(1, 2), S.stage2(1), S.circle(1)):
         e = U.EmulEnv(sc)
         g = sc.grid
-        K = 2   # kSkipK
-        cw, ch = (g.width + K - 1) // K, (g.height + K - 1) // K
-        buf = np.zeros(cw * ch, np.uint32)
-        packed = e.lib.emul_skip_field(C.byref(e._st), C.c_void_p(buf.ctypes.data), buf.size)
-        assert (packed >> 16, packed & 0xFFFF) == (cw, ch)
-        f = buf.reshape(ch, cw)
+        buf = np.zeros(g.width * g.height, np.uint32)
+        assert e.lib.emul_free_rect_field(C.byref(e._st), C.c_void_p(buf.ctypes.data), buf.size) == 0
+        f = buf.reshape(g.height, g.width)
         occ = g.dense()
-        pad = np.zeros((ch * K, cw * K), bool)
-        pad[: g.height, : g.width] = occ
-        blk = pad.reshape(ch, K, cw, K).any(axis=(1, 3))
-        assert ((f >= 0xFFFFFFF0) == blk).all()
-        for dy in (0, 1):          # non-empty blocks carry their own 2x2 occupancy
-            for dx in (0, 1):
-                bit = (f >> np.uint32(dy * 2 + dx)) & 1
-                assert (bit[blk] == pad[dy::2, dx::2][blk]).all()
-        sat = np.pad(blk.astype(np.int64).cumsum(0).cumsum(1), ((1, 0), (1, 0)))
-        ys, xs = np.nonzero(~blk)
+        assert ((f == 0xFFFFFFFF) == occ).all()
+        sat = np.pad(occ.astype(np.int64).cumsum(0).cumsum(1), ((1, 0), (1, 0)))
+        ys, xs = np.nonzero(~occ)
         v = f[ys, xs].astype(np.int64)
-        x0 = np.clip(xs - (v & 255), 0, cw - 1)
-        x1 = np.clip(xs + ((v >> 8) & 255), 0, cw - 1)
-        y0 = np.clip(ys - ((v >> 16) & 255), 0, ch - 1)
-        y1 = np.clip(ys + (v >> 24), 0, ch - 1)
+        assert (v & 0xFF).max() <= 127 and (v >> 24).max() <= 127
+        x0 = np.clip(xs - (v & 255), 0, g.width - 1)
+        x1 = np.clip(xs + ((v >> 8) & 255), 0, g.width - 1)
+        y0 = np.clip(ys - ((v >> 16) & 255), 0, g.height - 1)
+        y1 = np.clip(ys + (v >> 24), 0, g.height - 1)
         cnt = sat[y1 + 1, x1 + 1] - sat[y0, x1 + 1] - sat[y1 + 1, x0] + sat[y0, x0]
         assert (cnt == 0).all()
         assert ((v & 255) + ((v >> 8) & 255)).mean() > 4    # the rectangles are not trivial

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU ablation of the ray-cast kernel (profiling only): times the tick with parts switched off via
-mrca_set_debug_flags so the cost split march / neighbours / staging / writes is known."""
+mrca_set_debug_flags so the cost split march / neighbours / writes is known."""
 import os
 import sys
 
@@ -26,13 +26,16 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
     for k in range(50):
         env.step(pool[k % 8])
     for flags, label in ((0, "full"), (1, "no neighbour tests"), (2, "no march"), (3, "no march, no neighbours"),
-                         (7, "no staging/march/neighbours (writes only)"), (8, "move: no outline test"),
+                         (8, "move: no outline test"),
                          (16, "move: no collision loop"), (32, "move: no resets"), (56, "move: none of the three"),
-                         (64, "raycast_kernel<LDS tile>"), (128, "raycast_kernel<L2 field>"),
                          (256, "512 threads/robot (1 beam each)"), (512, "256 threads/robot (2 beams each)"),
                          (768, "128 threads/robot (4 beams each)"), (512, "back to 256 threads"),
                          (0, "full again")):
-        env.set_debug_flags(flags)
+        try:
+            env.set_debug_flags(flags)
+        except Exception as exc:  # a variant this build / map does not support
+            print(f"{name:<14} flags={flags} {label:<44} unsupported: {exc}")
+            continue
         for k in range(20):
             env.step(pool[k % 8])
         torch.cuda.synchronize()
