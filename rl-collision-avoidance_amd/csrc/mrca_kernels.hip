@@ -434,24 +434,18 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 
 // The march reads the free-rectangle field straight from its L1/L2-resident global copy: ~2 dependent
 // lookups per ray.  (Staging a tile of it in LDS per robot was measured slower at every granularity tried,
-// the tile costs more to fill than the few lookups it serves.)
+// the tile costs more to fill than the few lookups it serves.  So were persistent workgroups
+// walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
+// no difference: the hardware's own workgroup scheduling at 8 waves per SIMD is the best overlap found.)
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int n = block_to_robot(blockIdx.x, e.N);
     const int tid = threadIdx.x;
-    const uint8_t fresh_flag = e.fresh[n];
+    // the fresh flag comes through the scalar cache (n is block-uniform; the aligned word holding the byte),
+    // so nothing below queues behind it in the vector-memory counter
+    const uint32_t fresh_word = reinterpret_cast<const uint32_t*>(e.fresh)[n >> 2];
 
-    // the two frames that will be shifted down are fetched now, long before they are stored again -- and
-    // without waiting for the fresh flag (a robot that did start an episode just ignores them)
-    float4 keep1 = make_float4(0.f, 0.f, 0.f, 0.f), keep2 = keep1;
-    const bool wide = tid < (e.B >> 2);
-    const int fstride = e.B >> 2;
-    float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B) + tid;
-    if (wide && !only_fresh && e.F == 3) {
-        keep1 = ob4[fstride];
-        keep2 = ob4[2 * fstride];
-    }
-    const bool fresh = fresh_flag != 0;
+    const bool fresh = ((fresh_word >> ((n & 3) * 8)) & 0xFFu) != 0;
     if (only_fresh && !fresh) return;  // block-uniform
 
     float4* nb = reinterpret_cast<float4*>(lds);
@@ -467,6 +461,16 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const bool cand = (tid < e.R) && (tid != local);
     const int jn = world * e.R + ((tid < kWave && cand) ? tid : local);
     const float xj = e.pose[jn * 3 + 0], yj = e.pose[jn * 3 + 1], thj = e.pose[jn * 3 + 2];
+    // the two frames that will be shifted down are fetched now, long before they are stored again (issued
+    // AFTER the neighbour pose so that waiting for that pose never waits for these): unconditionally and
+    // branch-free (a robot that did start an episode, a thread outside the 16-byte
+    // epilogue or a stack that is not 3 deep just ignores what it fetched from a valid address)
+    __builtin_amdgcn_sched_barrier(0);  // keep the issue order pose -> frames
+    const bool wide = tid < (e.B >> 2);
+    const int fstride = e.B >> 2;
+    float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B) + (wide ? tid : 0);
+    const float4 keep1 = ob4[e.F == 3 ? fstride : 0];
+    const float4 keep2 = ob4[e.F == 3 ? 2 * fstride : 0];
     float s, c;
     sincos_det(th, &s, &c);
 
@@ -535,8 +539,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     if (wide) {
         const float4 r4 = reinterpret_cast<const float4*>(rbuf)[tid];
         const float4 o4 = make_float4(r4.x / 6.0f - 0.5f, r4.y / 6.0f - 0.5f, r4.z / 6.0f - 0.5f, r4.w / 6.0f - 0.5f);
-        reinterpret_cast<float4*>(e.scan + (size_t)n * e.B)[tid] = r4;
         float4* ob = ob4;
+        reinterpret_cast<float4*>(e.scan + (size_t)n * e.B)[tid] = r4;
         if (fresh) {
             for (int f = 0; f < e.F; ++f) ob[f * fstride] = o4;
         } else if (e.F == 3) {

@@ -27,7 +27,7 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
         env.step(pool[k % 8])
     for flags, label in ((0, "full"), (1, "no neighbour tests"), (2, "no march"), (3, "no march, no neighbours"),
                          (8, "move: no outline test"),
-                         (16, "move: no collision loop"), (32, "move: no resets"), (56, "move: none of the three"),
+                         (16, "move: no collision loop"), (32, "move: no resets"), (56, "move: none of the three"), 
                          (256, "512 threads/robot (1 beam each)"), (512, "256 threads/robot (2 beams each)"),
                          (768, "128 threads/robot (4 beams each)"), (512, "back to 256 threads"),
                          (0, "full again")):
