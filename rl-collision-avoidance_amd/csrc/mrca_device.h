@@ -165,8 +165,8 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 // ty(b) (both monotone in b), ties -> y first.  Leaving the rectangle through its x face Bx happens
 // iff tx(Bx) < ty(By); at that moment exactly the y events with ty(b) <= tx(Bx) have been consumed
 // (symmetrically: x events with tx(b) < ty(By)).  The next pending boundary is found from an
-// arithmetic estimate, corrected with the SAME closed-form times whenever the estimate is within
-// 0.01 cell of a boundary, so the walk resumes in precisely the cell, and with precisely the pending
+// arithmetic estimate that is always within one boundary of the truth and is settled with the SAME
+// closed-form times, so the walk resumes in precisely the cell, and with precisely the pending
 // boundaries, the cell-by-cell walk would have -- every later comparison, and the returned entry
 // time, are bit-identical.
 //
@@ -240,29 +240,21 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, f
         if (xe ? ynz : xnz) {
             // position on the secondary axis at time t.  The consumed crossings are exactly those on
             // the near side of p* = fS + t*dS*(1 +- 2.4e-7) (rounding of 1/dS and of the closed form),
-            // and pT differs from p* by < 1e-4 cells (|t*dS| <= 170, |fS| <= 2^11).  So when pT is
-            // not within 0.01 of an integer the first pending boundary is floor(pT) (+1 going up) with
-            // no further checks; otherwise it is corrected with the closed-form times themselves.
+            // and pT differs from p* by far less than one cell (|t*dS| <= 170, |fS| <= 2^16: < 0.01),
+            // so the first pending boundary is floor(pT) (+1 going up) or one of its two neighbours.
+            // Which one is decided with the closed-form times themselves, branch-free (a data-dependent
+            // "only when close to a boundary" test would make the whole wavefront take the slow path
+            // whenever one of its 64 rays is close).
             const float pT = fS + (xe ? dy : dx) * t;
-            const float fl = floorf(pT);
-            const float fr = pT - fl;
-            int b = (int)fl + (sS > 0 ? 1 : 0);
+            int b = (int)floorf(pT) + (sS > 0 ? 1 : 0);
             b = sS > 0 ? (b < bS0 ? bS0 : b) : (b > bS0 ? bS0 : b);
-            if (!(fr >= 0.01f && fr <= 0.99f)) {
-                for (;;) {  // step back while the previous crossing was NOT consumed
-                    const float tp = ((float)(b - sS) - fS) * invS;
-                    const bool cons = (tp < t) | ((tp == t) & xe);
-                    if ((b == bS0) | cons) break;
-                    b -= sS;
-                }
-                for (;;) {  // step forward while this crossing WAS consumed
-                    const float tc = ((float)b - fS) * invS;
-                    const bool cons = (tc < t) | ((tc == t) & xe);
-                    if (!cons) break;
-                    b += sS;
-                }
-            }
-            bS = b;
+            const float tp = ((float)(b - sS) - fS) * invS;   // the crossing before b ...
+            const float tc = ((float)b - fS) * invS;          // ... and b itself: consumed before t?
+            const bool cons_p = (tp < t) | ((tp == t) & xe);
+            const bool cons_c = (tc < t) | ((tc == t) & xe);
+            const int back = ((b != bS0) & !cons_p) ? sS : 0;
+            const int fwd = cons_c ? sS : 0;                  // cons_c implies cons_p (times are monotone)
+            bS = b - back + fwd;
         }
         // new cell and pending boundaries (for the secondary axis "cell = boundary + m" restates the
         // invariant, for the exit axis the boundary is crossed)

@@ -173,13 +173,28 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     const int piy = (int)floorf((ny - e.g.y0) * e.g.inv_cell);
     const int py0 = piy - hc;
     const int pw0 = (pix - hc) >> 5;
-    bool need = false;
-    if (valid && !(e.debug_flags & 8)) {
-        // nothing occupied within hc cells (Chebyshev) of the centre cell => every cell the outline walk
-        // could visit is free => no hit, without touching the bitmap
-        const bool inside = pix >= 0 && piy >= 0 && pix < e.g.width && piy < e.g.height;
-        need = !(inside && e.cellfield[(size_t)piy * e.g.width + pix] > hc);
+    // nothing occupied within hc cells (Chebyshev) of the centre cell => every cell the outline walk
+    // could visit is free => no hit, without touching the bitmap.  The byte is requested here and used
+    // after the broad phase below, which needs no memory and so runs inside this load's latency.
+    const bool inside = pix >= 0 && piy >= 0 && pix < e.g.width && piy < e.g.height;
+    const bool check_map = valid && !(e.debug_flags & 8);
+    const uint8_t clearance = (check_map && inside) ? e.cellfield[(size_t)piy * e.g.width + pix] : 0;
+
+    // --- broad phase of the robot-robot collision pass (the pass itself follows the outline test): robot i
+    //     can only touch robot j if its provisional centre comes within 2 x circumradius of j's old or
+    //     new centre, so only the (few) robots with such a neighbour take a turn in the ordered pass;
+    //     everybody else commits straight away -- their outcome does not depend on the order.
+    bool involved = false;
+    if (!(e.debug_flags & 16)) {
+        for (int j = 0; j < e.R; ++j) {
+            const float ax = nx - fbcast(x, j), ay = ny - fbcast(y, j);
+            const float bx2 = nx - fbcast(nx, j), by2 = ny - fbcast(ny, j);
+            const float d_old = ax * ax + ay * ay, d_new = bx2 * bx2 + by2 * by2;
+            if (j != lane && (d_old <= 0.3392f || d_new <= 0.3392f)) involved = true;  // (2*0.2907 + 0.001)^2
+        }
+        involved = involved && valid;
     }
+    const bool need = check_map && !(inside && clearance > hc);
     {
         unsigned long long todo = __ballot(need);
         while (todo) {
@@ -232,20 +247,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     __syncthreads();
     const bool shit = need && hit_flag[lane] != 0;
 
-    // --- collision pass in robot order (Stage's sequential model loop).  Broad phase first: robot i
-    //     can only touch robot j if its provisional centre comes within 2 x circumradius of j's old or
-    //     new centre, so only the (few) robots with such a neighbour take a turn in the ordered pass;
-    //     everybody else commits straight away -- their outcome does not depend on the order.
-    bool involved = false;
-    if (!(e.debug_flags & 16)) {
-        for (int j = 0; j < e.R; ++j) {
-            const float ax = nx - fbcast(x, j), ay = ny - fbcast(y, j);
-            const float bx2 = nx - fbcast(nx, j), by2 = ny - fbcast(ny, j);
-            const float d_old = ax * ax + ay * ay, d_new = bx2 * bx2 + by2 * by2;
-            if (j != lane && (d_old <= 0.3392f || d_new <= 0.3392f)) involved = true;  // (2*0.2907 + 0.001)^2
-        }
-        involved = involved && valid;
-    }
+    // --- collision pass in robot order (Stage's sequential model loop)
     // committed pose of a robot that is not involved: moves unless the map stops it
     const float ox_ = x, oy_ = y, os_ = s, oc_ = c;  // pose at tick start
     bool moved = moving && !involved && !shit;
