@@ -27,6 +27,7 @@ namespace mrca {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kPatchBatch = 4;   // footprint patches fetched per memory round trip in move_kernel
 
 __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
                                               float* py, float* pth, float* gx, float* gy, float* pdist,
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
 
     // --- outline-vs-grid test.  Skipped (same answer: free) when the coarse free-distance field says
     //     every block within the footprint's circumradius of the provisional centre is empty.  For the
-    //     others the (2*hc+1)-row patch under the footprint is pulled into LDS by the WHOLE wave, four
+    //     others the (2*hc+1)-row patch under the footprint is pulled into LDS by the WHOLE wave, kPatchBatch
     //     robots' loads in flight at a time, and each robot then walks its outline in LDS.
     const int hc = e.foot_hc;
     const int prow = 2 * hc + 1;
@@ -198,18 +199,18 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     {
         unsigned long long todo = __ballot(need);
         while (todo) {
-            int src[4];
+            int src[kPatchBatch];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kPatchBatch; ++q) {
                 src[q] = todo ? (__ffsll((long long)todo) - 1) : -1;
                 if (todo) todo &= todo - 1;
             }
             for (int k0 = 0; k0 < psize; k0 += kWave) {
                 const int k = k0 + lane;
                 const int r = k / pwords, wi = k - r * pwords;
-                uint32_t val[4];
+                uint32_t val[kPatchBatch];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < kPatchBatch; ++q) {
                     val[q] = 0u;
                     if (src[q] >= 0 && k < psize) {
                         const int gy = ibcast(py0, src[q]) + r;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < kPatchBatch; ++q)
                     if (src[q] >= 0 && k < psize) mini[src[q] * psize + k] = val[q];
             }
         }
