@@ -184,13 +184,43 @@ constexpr int kFieldPadX = 2, kFieldPadY = 1;
 MRCA_HD int imin(int a, int b) { return a < b ? a : b; }
 MRCA_HD int imax(int a, int b) { return a > b ? a : b; }
 
+// median of three: clamp(x, lo, hi) for lo <= hi in ONE v_med3_i32 on the device (the compiler cannot prove
+// lo <= hi for run-time bounds and would emit max + min).  LO is a small compile-time constant (an inline
+// operand), hi may live in a scalar register.
+MRCA_HD int med3_i32(int a, int b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    const int lo = imin(a, imin(b, c)), hi = imax(a, imax(b, c));
+    return a + b + c - lo - hi;   // no overflow for the operands used here (|.| <= 2^30) ...
+#endif
+}
+template <int LO>
+MRCA_HD int clamp_from(int x, int hi) {   // clamp(x, LO, hi), LO <= hi
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(LO), "s"(hi));
+    return r;
+#else
+    return imin(imax(x, LO), hi);
+#endif
+}
+
 struct FreeRectField {   // free-rectangle field straight from global memory (L1/L2-resident)
     const uint32_t* d;   // base of the padded array
     int32_t w, h, pitch; // map size in cells, entries per padded row
     MRCA_HD uint32_t operator()(int ix, int iy) const {
-        const int x = imin(imax(ix + kFieldPadX, 0), w + 2 * kFieldPadX - 1);   // -> v_med3_i32
-        const int y = imin(imax(iy + kFieldPadY, 0), h + 2 * kFieldPadY - 1);
-        return d[(uint32_t)(y * pitch + x)];
+        const int x = clamp_from<-kFieldPadX>(ix, w + kFieldPadX - 1);
+        const int y = clamp_from<-kFieldPadY>(iy, h + kFieldPadY - 1);
+        // |y|, pitch < 2^23: 24-bit multiply-add
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int idx = __mul24(y, pitch) + x;
+#else
+        const int idx = y * pitch + x;
+#endif
+        return d[(uint32_t)(idx + (kFieldPadY * pitch + kFieldPadX))];
     }
 };
 
@@ -198,15 +228,31 @@ struct FreeRectField {   // free-rectangle field straight from global memory (L1
 // a wavefront stay in lock step.  No (tx, ty) state is carried -- boundary times are always re-derived
 // from the closed form, which is what makes every path through here produce the same numbers as
 // grid_march.
+// What all rays leaving one point share: the origin in cell units, its cell and that cell's field entry
+// (a lidar computes it once per robot, not once per beam).
+struct MarchOrigin {
+    float fx, fy;
+    int32_t ix0, iy0;
+    uint32_t v0;
+};
 template <class Field>
-MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, float oy, float dx, float dy,
+MRCA_HD MarchOrigin march_origin(const Field& field, const GridGeom& g, float ox, float oy) {
+    MarchOrigin o;
+    o.fx = (ox - g.x0) * g.inv_cell;
+    o.fy = (oy - g.y0) * g.inv_cell;
+    o.ix0 = (int)floorf(o.fx);
+    o.iy0 = (int)floorf(o.fy);
+    o.v0 = field(o.ix0, o.iy0);
+    return o;
+}
+
+template <class Field>
+MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const MarchOrigin& org, float dx, float dy,
                               float tmax) {
-    const float fx = (ox - g.x0) * g.inv_cell;
-    const float fy = (oy - g.y0) * g.inv_cell;
-    int ix = (int)floorf(fx);
-    int iy = (int)floorf(fy);
+    const float fx = org.fx, fy = org.fy;
+    const int ix0 = org.ix0, iy0 = org.iy0;
     const float tmax_c = tmax * g.inv_cell;
-    uint32_t v = field(ix, iy);  // carried: one field lookup per jump
+    uint32_t v = org.v0;  // carried: one field lookup per jump
     if (v == kCellOccupied) return 0.0f;
     if (!(tmax_c > 0.0f)) return tmax;
     const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
@@ -214,22 +260,36 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, f
     const float inv_dy = ynz ? 1.0f / dy : kInf;
     const bool xpos = dx > 0.0f, ypos = dy > 0.0f;
     const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
-    const int mx = xpos ? 0 : -1, my = ypos ? 0 : -1;  // cell = boundary + m once the boundary is crossed
+    const int ux = xpos ? 1 : 0, uy = ypos ? 1 : 0;      // current cell = pending boundary - u, on each axis
     const int shx = xpos ? 8 : 0, shy = ypos ? 24 : 16;  // which extent byte faces the direction of travel
-    int bx = ix + (xpos ? 1 : 0);  // next pending boundary on each axis
-    int by = iy + (ypos ? 1 : 0);
-    for (int guard = 0; guard < kMaxMarchSteps; ++guard) {
-        // faces of the rectangle known to be free: boundary (i + e + 1) going up, (i - e) going down
+    // a pending boundary only ever moves in the direction of travel: clamp(b, from b0) = med3(b, b0, lim)
+    const int limx = xpos ? 0x3FFFFFFF : -0x3FFFFFFF, limy = ypos ? 0x3FFFFFFF : -0x3FFFFFFF;
+    // An axis-parallel ray never crosses a boundary of its zero axis -- which then is always the secondary
+    // axis below (its exit time is +inf), so the whole estimate is skipped for such a ray.
+    const bool bothnz = xnz & ynz;
+    // The state is just the next pending boundary on each axis (the cell follows from it).
+    int bx = ix0 + ux;
+    int by = iy0 + uy;
+    float t = 0.0f;
+    bool hit = false;
+    int guard = kMaxMarchSteps;
+    do {
+        // faces of the rectangle known to be free: e cells beyond the current cell's own far face
         const int ex = (int)((v >> shx) & 255u), ey = (int)((v >> shy) & 255u);
-        const int Bx = ix + ((ex ^ mx) - mx) + (xpos ? 1 : 0);
-        const int By = iy + ((ey ^ my) - my) + (ypos ? 1 : 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int Bx = __mul24(ex, sx) + bx;
+        const int By = __mul24(ey, sy) + by;
+#else
+        const int Bx = ex * sx + bx;
+        const int By = ey * sy + by;
+#endif
         const float rawx = ((float)Bx - fx) * inv_dx;
         const float rawy = ((float)By - fy) * inv_dy;
         const float tBx = xnz ? rawx : kInf;
         const float tBy = ynz ? rawy : kInf;
         const bool xe = tBx < tBy;  // leaves through the x face (ties: y first)
-        const float t = xe ? tBx : tBy;
-        if (t >= tmax_c) return tmax;
+        t = xe ? tBx : tBy;
+        if (t >= tmax_c) break;
         // the other ("secondary") axis: which of its crossings were consumed before time t?
         // x exit: y crossings with ty(b) <= t;  y exit: x crossings with tx(b) < t.
         const float fS = xe ? fy : fx;
@@ -237,7 +297,7 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, f
         const int sS = xe ? sy : sx;
         const int bS0 = xe ? by : bx;
         int bS = bS0;
-        if (xe ? ynz : xnz) {
+        if (bothnz) {
             // position on the secondary axis at time t.  The consumed crossings are exactly those on
             // the near side of p* = fS + t*dS*(1 +- 2.4e-7) (rounding of 1/dS and of the closed form),
             // and pT differs from p* by far less than one cell (|t*dS| <= 170, |fS| <= 2^16: < 0.01),
@@ -246,28 +306,28 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, f
             // "only when close to a boundary" test would make the whole wavefront take the slow path
             // whenever one of its 64 rays is close).
             const float pT = fS + (xe ? dy : dx) * t;
-            int b = (int)floorf(pT) + (sS > 0 ? 1 : 0);
-            b = sS > 0 ? (b < bS0 ? bS0 : b) : (b > bS0 ? bS0 : b);
-            const float tp = ((float)(b - sS) - fS) * invS;   // the crossing before b ...
+            const int b = med3_i32((int)floorf(pT) + (xe ? uy : ux), bS0, xe ? limy : limx);
+            const int bprev = b - sS;
+            const float tp = ((float)bprev - fS) * invS;      // the crossing before b ...
             const float tc = ((float)b - fS) * invS;          // ... and b itself: consumed before t?
             const bool cons_p = (tp < t) | ((tp == t) & xe);
             const bool cons_c = (tc < t) | ((tc == t) & xe);
-            const int back = ((b != bS0) & !cons_p) ? sS : 0;
-            const int fwd = cons_c ? sS : 0;                  // cons_c implies cons_p (times are monotone)
-            bS = b - back + fwd;
+            bS = cons_c ? b + sS : b;                         // cons_c implies cons_p (times are monotone)
+            bS = ((b != bS0) & !cons_p) ? bprev : bS;
         }
-        // new cell and pending boundaries (for the secondary axis "cell = boundary + m" restates the
-        // invariant, for the exit axis the boundary is crossed)
-        const int nbx = xe ? Bx + sx : bS;
-        const int nby = xe ? bS : By + sy;
-        ix = (xe ? Bx : nbx - sx) + mx;   // xe: cell just across Bx;  else: cell before pending bx
-        iy = (xe ? nby - sy : By) + my;
-        bx = nbx;
-        by = nby;
-        v = field(ix, iy);  // cells outside the map read as empty (the zero border)
-        if (v == kCellOccupied) return t * g.cell;
-    }
-    return tmax;
+        // pending boundaries after the jump: the exit-axis face is crossed, the secondary axis resumes at bS
+        bx = xe ? Bx + sx : bS;
+        by = xe ? bS : By + sy;
+        v = field(bx - ux, by - uy);  // cells outside the map read as empty (the zero border)
+        hit = v == kCellOccupied;
+    } while (!hit && --guard > 0);
+    return hit ? t * g.cell : tmax;
+}
+
+template <class Field>
+MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, float oy, float dx, float dy,
+                              float tmax) {
+    return grid_march_skip(field, g, march_origin(field, g, ox, oy), dx, dy, tmax);
 }
 
 // ------------------------------------------------------------------------------------------

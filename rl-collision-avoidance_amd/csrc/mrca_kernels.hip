@@ -510,11 +510,22 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     }
     // --- beams: thread t takes beams t, t + blockDim, ... (one each in the default launch)
     const FreeRectField field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
-    for (int b = tid; b < e.B; b += blockDim.x) {
-        const float bc = e.beam_cos[b], bs = e.beam_sin[b];
-        const float dx = c * bc - s * bs;
-        const float dy = s * bc + c * bs;
-        rbuf[b] = (e.debug_flags & 2) ? kRangeMax : grid_march_skip(field, e.g, x, y, dx, dy, kRangeMax);
+    const MarchOrigin org = march_origin(field, e.g, x, y);   // once per robot: shared by all its beams
+    {
+        int b = tid;                                           // tid < blockDim <= B
+        float bc = e.beam_cos[b], bs = e.beam_sin[b];
+        while (b < e.B) {
+            // the next beam's direction is requested now and arrives while this one marches
+            const int bn = b + blockDim.x;
+            const int bl = bn < e.B ? bn : b;
+            const float nbc = e.beam_cos[bl], nbs = e.beam_sin[bl];
+            const float dx = c * bc - s * bs;
+            const float dy = s * bc + c * bs;
+            rbuf[b] = (e.debug_flags & 2) ? kRangeMax : grid_march_skip(field, e.g, org, dx, dy, kRangeMax);
+            b = bn;
+            bc = nbc;
+            bs = nbs;
+        }
     }
     __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
     const int cnt = *nb_count;
