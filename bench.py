@@ -233,7 +233,7 @@ def main():
                          "bytes_per_agent_step": BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
                          "launches_timed": launches,
-                         "note": "HBM is the nominal roof (SURVEY 8d); the kernel is VALU-bound in the ray march (~70 % VALU busy at 8 waves/SIMD), see DESIGN.md 5"},
+                         "note": "HBM is the nominal roof (SURVEY 8d); the kernel is bound by VALU issue and dependent L2 lookups in the ray march, see DESIGN.md 5"},
         }
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(args.scenario, args.worlds, args.robots_per_world)
