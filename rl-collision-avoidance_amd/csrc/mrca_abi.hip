@@ -338,15 +338,15 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.debug_flags = 0;
     // 256 threads per 512-beam robot (2 beams each): 8 resident workgroups per CU instead of 4 hide the
-    // per-robot latency chain (pose -> tile -> march -> store) better; measured 54.5 vs 62.0 us at 4096
-    // robots (profiles/r01_h_ablation.txt)
+    // per-robot latency chain (pose -> march -> store) better; measured 33.2 us against 39.9 us for
+    // 512 threads x 1 beam and 33.8 us for 128 threads x 4 beams at 4096 robots (profiles/r01_aa_ablation.txt)
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
                          (double)cfg->map_cell));
     if (env->lds_bytes > 160 * 1024)
-        return bail(fail(MRCA_ERR_UNSUPPORTED, "ray-cast tile needs %zu B of LDS (> 160 KiB): use a coarser map_cell",
+        return bail(fail(MRCA_ERR_UNSUPPORTED, "the ray cast needs %zu B of LDS per robot (> 160 KiB): too many beams",
                          env->lds_bytes));
     *env_out = env;
     return MRCA_OK;

@@ -118,8 +118,9 @@ class VecStageWorld:
         _lib.check(self.lib.mrca_enable_timing(self._h, int(on)), "mrca_enable_timing")
 
     def set_debug_flags(self, flags):
-        """Profiling ablations only (results are wrong while set): 1 no robot-robot lidar tests,
-        2 no grid march, 4 no tile staging."""
+        """Profiling ablations only (results are wrong while bits 0-5 are set): 1 no robot-robot lidar
+        tests, 2 no grid march, 8 / 16 / 32 move kernel without outline test / collision loop / resets;
+        bits 8-10 = k > 0: ray cast launched with beams >> (k-1) threads per robot (results unchanged)."""
         _lib.check(self.lib.mrca_set_debug_flags(self._h, int(flags)), "mrca_set_debug_flags")
 
     def read_timing(self):
