@@ -1,0 +1,58 @@
+"""Properties of the compiled gfx950 code that the design relies on (no GPU needed: hipcc cross-compiles).
+
+* fp32 determinism: the tick is specified as separately rounded IEEE operations, so the device code may
+  contain fused multiply-adds ONLY inside the compiler's division / square-root expansions
+  (-ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt).
+* occupancy: the ray-cast kernel must fit 8 waves per SIMD (<= 64 VGPRs) and no kernel may spill to scratch.
+"""
+import bisect
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "mrca_kernels.s"
+    # the flags of csrc/build.sh that shape the device code
+    flags = re.findall(r"^\s+(-f[\w=-]+(?:\s+-f[\w=-]+)*)", open(os.path.join(CSRC, "build.sh")).read(), re.M)
+    flags = " ".join(flags).split()
+    assert "-ffp-contract=off" in flags and "-fhip-fp32-correctly-rounded-divide-sqrt" in flags, flags
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only",
+                    os.path.join(CSRC, "mrca_kernels.hip"), "-o", str(out)], check=True, capture_output=True)
+    return open(out).read().split("\n")
+
+
+def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm):
+    fused = [i for i, l in enumerate(device_asm)
+             if re.match(r"\s+v_(pk_fma|fma|fmac|mad|mac|madmk|madak|fmamk|fmaak)_(legacy_)?f(16|32)", l)]
+    anchors = [i for i, l in enumerate(device_asm)
+               if re.match(r"\s+v_(div_scale|div_fmas|div_fixup|rsq|sqrt|rcp)_f32", l)]
+    assert fused and anchors
+    for i in fused:
+        k = bisect.bisect_left(anchors, i)
+        dist = min(abs(anchors[j] - i) for j in (k - 1, k) if 0 <= j < len(anchors))
+        assert dist <= 30, f"fused multiply-add outside a div/sqrt expansion: line {i}: {device_asm[i].strip()}"
+
+
+def test_register_budget_and_no_scratch(device_asm):
+    text = "\n".join(device_asm)
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
+    assert len(kernels) == 4, [k for k, _ in kernels]
+    for name, body in kernels:
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        assert scratch == 0, f"{name} spills {scratch} B/lane to scratch"
+        if "raycast_kernel" in name:
+            assert vgpr <= 64, f"raycast_kernel needs {vgpr} VGPRs: fewer than 8 waves per SIMD"
+        else:
+            assert vgpr <= 128, f"{name} needs {vgpr} VGPRs"
