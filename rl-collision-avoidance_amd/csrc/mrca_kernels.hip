@@ -439,7 +439,9 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // lookups per ray.  (Staging a tile of it in LDS per robot was measured slower at every granularity tried,
 // the tile costs more to fill than the few lookups it serves.  So were persistent workgroups
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
-// no difference: the hardware's own workgroup scheduling at 8 waves per SIMD is the best overlap found.)
+// no difference, nor did rotating which wave prepares the neighbour list and which waves run the epilogue
+// (profiles/r01_am_ablation_wave_rotation.txt): the hardware's own workgroup scheduling at 8 waves per SIMD
+// is the best overlap found.)
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int n = block_to_robot(blockIdx.x, e.N);

@@ -1,7 +1,8 @@
 """Properties of the compiled gfx950 code that the design relies on (no GPU needed: hipcc cross-compiles).
 
 * fp32 determinism: the tick is specified as separately rounded IEEE operations, so the device code may
-  contain fused multiply-adds ONLY inside the compiler's division / square-root expansions
+  contain fused multiply-adds ONLY inside the compiler's division / square-root expansions (fp32, and the
+  float-assisted expansion of integer division)
   (-ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt).
 * occupancy: the ray-cast kernel must fit 8 waves per SIMD (<= 64 VGPRs) and no kernel may spill to scratch.
 """
@@ -36,7 +37,7 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
     fused = [i for i, l in enumerate(device_asm)
              if re.match(r"\s+v_(pk_fma|fma|fmac|mad|mac|madmk|madak|fmamk|fmaak)_(legacy_)?f(16|32)", l)]
     anchors = [i for i, l in enumerate(device_asm)
-               if re.match(r"\s+v_(div_scale|div_fmas|div_fixup|rsq|sqrt|rcp)_f32", l)]
+               if re.match(r"\s+v_(div_scale|div_fmas|div_fixup|rsq|sqrt|rcp|rcp_iflag)_f32", l)]
     assert fused and anchors
     for i in fused:
         k = bisect.bisect_left(anchors, i)
