@@ -93,7 +93,7 @@ typedef struct mrca_config {
     int32_t beams;             /* 512 (stage1.world:14); 64..1024, multiple of 64 */
     int32_t frames;            /* 3 (LASER_HIST, ppo_stage1.py:24); 1..8 */
     /* occupancy grid shared by all worlds; cells outside it are free */
-    int32_t map_width, map_height, map_words_per_row;
+    int32_t map_width, map_height, map_words_per_row;   /* cells; at most 16384 per side */
     float map_cell, map_x0, map_y0; /* cell edge [m]; world coords of the lower-left corner */
     const uint32_t* map_bits;       /* host, [map_height][map_words_per_row], bit b of word w = column 32w+b */
     /* reward / episode rules (stage_world1.py:180-211 and the stage2 / circle variants) */

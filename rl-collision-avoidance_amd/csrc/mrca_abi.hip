@@ -58,6 +58,10 @@ int validate(const mrca_config* c) {
     if (c->map_width < 1 || c->map_height < 1 || c->map_words_per_row < (c->map_width + 31) / 32)
         return fail(MRCA_ERR_INVALID, "bad map geometry %dx%d wpr %d", c->map_width, c->map_height,
                     c->map_words_per_row);
+    // the grid walks keep cell coordinates in fp32 (exact integers, sub-cell estimates good to << 1 cell up to
+    // 2^16) and index the per-cell fields with 24-bit multiplies
+    if (c->map_width > 16384 || c->map_height > 16384)
+        return fail(MRCA_ERR_UNSUPPORTED, "map %dx%d cells: at most 16384 per side", c->map_width, c->map_height);
     if (!(c->map_cell > 0.0f)) return fail(MRCA_ERR_INVALID, "map_cell must be > 0");
     if (!c->map_bits) return fail(MRCA_ERR_INVALID, "map_bits is NULL");
     if (c->auto_reset < 0 || c->auto_reset > 2) return fail(MRCA_ERR_INVALID, "auto_reset %d", c->auto_reset);

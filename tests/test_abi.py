@@ -56,6 +56,7 @@ def test_arena_bytes_and_layout(built_lib):
 @pytest.mark.parametrize("field,value,code", [
     ("robots_per_world", 65, -4), ("robots_per_world", 0, -1), ("beams", 500, -1), ("frames", 0, -1),
     ("abi_version", 99, -1), ("map_cell", 0.0, -1), ("auto_reset", 7, -1), ("num_worlds", 0, -1),
+    ("map_width", 0, -1), ("map_height", 20000, -4),
 ])
 def test_config_validation_errors(built_lib, field, value, code):
     cfg, _keep = _cfg(S.stage1(num_worlds=2, robots_per_world=8))
