@@ -194,7 +194,7 @@ MRCA_HD int med3_i32(int a, int b, int c) {
     return r;
 #else
     const int lo = imin(a, imin(b, c)), hi = imax(a, imax(b, c));
-    return a + b + c - lo - hi;   // no overflow for the operands used here (|.| <= 2^30) ...
+    return a + b + c - lo - hi;   // no overflow for the operands used here (two of them < 2^20, one < 2^30)
 #endif
 }
 template <int LO>
@@ -224,10 +224,6 @@ struct FreeRectField {   // free-rectangle field straight from global memory (L1
     }
 };
 
-// Flat, branch-poor form (one loop, one jump per iteration, x/y handled by selects) so the 64 rays of
-// a wavefront stay in lock step.  No (tx, ty) state is carried -- boundary times are always re-derived
-// from the closed form, which is what makes every path through here produce the same numbers as
-// grid_march.
 // What all rays leaving one point share: the origin in cell units, its cell and that cell's field entry
 // (a lidar computes it once per robot, not once per beam).
 struct MarchOrigin {
@@ -246,6 +242,10 @@ MRCA_HD MarchOrigin march_origin(const Field& field, const GridGeom& g, float ox
     return o;
 }
 
+// Flat, branch-poor form (one loop, one jump per iteration, x/y handled by selects) so the 64 rays of
+// a wavefront stay in lock step.  No (tx, ty) state is carried -- boundary times are always re-derived
+// from the closed form, which is what makes every path through here produce the same numbers as
+// grid_march.
 template <class Field>
 MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const MarchOrigin& org, float dx, float dy,
                               float tmax) {
