@@ -143,19 +143,62 @@ def _minibatches(n, batch_size, drop_last, generator=None, device=None):
     return out
 
 
+def _world_size(dist):
+    return dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+
+
+class KLAdaptiveLR:
+    """Opt-in learning-rate controller for the large-batch regime (not in the reference, whose lr is fixed at
+    5e-5 for 3072-sample updates): after every epoch the mean approximate KL(old || new) of that epoch's
+    minibatches is compared with ``target``; above 2x the lr is divided by ``factor``, below 0.5x multiplied.
+    The KL is averaged over ranks so that every rank's optimizer takes the same decision."""
+
+    def __init__(self, target, lr_min=1e-6, lr_max=1e-3, factor=1.5):
+        self.target, self.lr_min, self.lr_max, self.factor = float(target), lr_min, lr_max, factor
+        self.last_kl = None
+
+    def step(self, optimizer, kl_sum, count, dist):
+        s = torch.stack([kl_sum.double(), torch.as_tensor(float(count), dtype=torch.float64, device=kl_sum.device)])
+        if _world_size(dist) > 1:
+            dist.all_reduce(s)
+        kl = float(s[0] / s[1].clamp(min=1.0))
+        self.last_kl = kl
+        for g in optimizer.param_groups:
+            if kl > 2.0 * self.target:
+                g["lr"] = max(self.lr_min, g["lr"] / self.factor)
+            elif kl < 0.5 * self.target:
+                g["lr"] = min(self.lr_max, g["lr"] * self.factor)
+        return kl
+
+
 def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, drop_last, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype=None):
+                index_batches, dist, flat_grads, log, autocast_dtype=None, kl_ctl=None):
     obss, goals, speeds, actions, logprobs, targets, advs = flat
     n = advs.shape[0]
+    multi = _world_size(dist) > 1
+    if multi and flat_grads is None:
+        raise ValueError("ppo update with a multi-rank process group needs flat_grads (ppo.FlatGrads): without it "
+                         "the replicas would train unsynchronised")
     for _ in range(epoch):
         batches = index_batches(n) if index_batches is not None else \
             _minibatches(n, batch_size, drop_last, device=advs.device)
+        if multi:
+            # every rank must take the same number of optimiser steps (one gradient all-reduce each): Stage-2
+            # filtering leaves a different row count on every rank, so agree on the minimum for this epoch
+            s = torch.tensor([len(batches)], dtype=torch.int64, device=advs.device)
+            dist.all_reduce(s, op=dist.ReduceOp.MIN)
+            if int(s.item()) == 0:
+                raise RuntimeError(f"a rank kept fewer than batch_size={batch_size} transitions ({n} on this one): "
+                                   "lower --batch-size")
+            batches = batches[:int(s.item())]
+        kl_sum = torch.zeros((), device=advs.device)
         for index in batches:
             with torch.autocast(advs.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
                 new_value, new_logprob, dist_entropy = policy.evaluate_actions(obss[index], goals[index],
                                                                                speeds[index], actions[index])
             new_value, new_logprob = new_value.float(), new_logprob.float()
-            ratio = torch.exp(new_logprob - logprobs[index])
+            log_ratio = new_logprob - logprobs[index]
+            ratio = torch.exp(log_ratio)
             adv = advs[index]
             surrogate1 = ratio * adv
             surrogate2 = torch.clamp(ratio, 1 - clip_value, 1 + clip_value) * adv
@@ -170,13 +213,18 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
             if flat_grads is not None:
                 flat_grads.all_reduce_mean(dist)
             optimizer.step()
+            if kl_ctl is not None:
+                with torch.no_grad():
+                    kl_sum += ((ratio - 1.0) - log_ratio).mean()      # k3 estimator of KL(old || new), >= 0
             if log is not None:
                 log.append((policy_loss.detach(), value_loss.detach(), dist_entropy.detach()))
+        if kl_ctl is not None and len(batches):
+            kl_ctl.step(optimizer, kl_sum, len(batches), dist)
 
 
 def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entropy=0.02, clip_value=0.2,
                       num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *, value_coef=20.0,
-                      index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None):
+                      index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None, kl_ctl=None):
     """model/ppo.py:143-194.  ``memory`` = (obss, goals, speeds, actions, logprobs, targets, values,
     rewards, advs) as device tensors shaped [T, N, ...]."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -186,12 +234,13 @@ def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entrop
     flat = (obss.reshape(n, frames, obs_size), goals.reshape(n, 2), speeds.reshape(n, 2),
             actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1), advs.reshape(n, 1))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, False, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype)
+                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl)
 
 
 def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch, coeff_entropy=0.02,
                       clip_value=0.2, num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *,
-                      value_coef=20.0, index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None):
+                      value_coef=20.0, index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None,
+                      kl_ctl=None):
     """model/ppo.py:197-259: the advantage statistics use ALL transitions, then the filtered rows
     are deleted and minibatches use drop_last=True."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -205,4 +254,4 @@ def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch
                                    actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1),
                                    advs.reshape(n, 1)))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, True, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype)
+                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl)

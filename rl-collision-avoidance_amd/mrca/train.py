@@ -10,8 +10,11 @@ cal.log episode rewards, ppo.log "policy_loss, value_loss, entropy" per minibatc
 140-162, model/ppo.py:10-19), checkpoints `policy/Stage1_{n}` / `policy/stage2_{n}.pth` every 20
 updates with the reference's state_dict keys (ppo_stage1.py:122-124), resume from
 `policy/stage1_2.pth` / `policy/stage2.pth` when present (ppo_stage1.py:185-191).
-Added: optimizer / step / RNG state next to each checkpoint (`*.state`) for exact resume, and
-agent-steps/s, success / crash / timeout rates per update.
+Added: optimizer / step / RNG state next to each checkpoint (`*.state`, one action-noise generator state PER
+RANK) for exact resume, agent-steps/s and success / crash / timeout rates per update, and -- opt-in, for the
+large-batch regime of thousands of robots per GPU -- a KL-adaptive learning rate (`--kl-target`), bf16 autocast
+for the update / the rollout inference, and a periodic circle-test validation (`--circle-every`) that keeps the
+best checkpoint so far as `<policy-dir>/best_circle.pth`.
 """
 import argparse
 import logging
@@ -60,6 +63,19 @@ def main(argv=None):
     ap.add_argument("--policy-dir", default="policy")
     ap.add_argument("--save-every", type=int, default=20)       # ppo_stage1.py:123
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=None, help="default: the reference's 5e-5")
+    ap.add_argument("--epoch", type=int, default=None)
+    ap.add_argument("--horizon", type=int, default=None)
+    ap.add_argument("--coeff-entropy", type=float, default=None)
+    ap.add_argument("--kl-target", type=float, default=0.0, help="> 0: KL-adaptive learning rate (ppo.KLAdaptiveLR)")
+    ap.add_argument("--lr-max", type=float, default=1e-3)
+    ap.add_argument("--bf16-update", action="store_true", help="bf16 autocast in the PPO update (opt-in)")
+    ap.add_argument("--bf16-inference", action="store_true", help="bf16 autocast in the rollout policy (opt-in)")
+    ap.add_argument("--init", default=None, help="state_dict to start from (overrides the resume file)")
+    ap.add_argument("--circle-every", type=int, default=0, help="run the circle test every K updates (rank 0)")
+    ap.add_argument("--circle-worlds", type=int, default=20)
+    ap.add_argument("--circle-ticks", type=int, default=1500)
+    ap.add_argument("--max-seconds", type=float, default=0.0, help="stop after this much wall time (0 = no limit)")
     a = ap.parse_args(argv)
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,30 +98,67 @@ def main(argv=None):
         sc = scenario.stage2(num_worlds=a.worlds, seed=a.seed * 1000 + rank)
         hp = HParams(batch_size=512, epoch=4)                  # ppo_stage2.py:28-29
         resume, pattern = "stage2.pth", "stage2_{}.pth"
+    for k, v in (("learning_rate", a.lr), ("epoch", a.epoch), ("horizon", a.horizon),
+                 ("coeff_entropy", a.coeff_entropy)):
+        if v is not None:
+            setattr(hp, k, v)
+    hp.kl_target, hp.lr_max = a.kl_target, a.lr_max
+    if a.bf16_update:
+        hp.update_dtype = torch.bfloat16
+    if a.bf16_inference:
+        hp.inference_dtype = torch.bfloat16
     if a.batch_size:
         hp.batch_size = a.batch_size
-    elif sc.num_robots * world_size > 64:
-        # the reference's 1024 / 512 assume 24 / 44 robots; keep ~3 minibatches per epoch per 3072 samples
-        hp.batch_size = max(hp.batch_size, sc.num_robots * world_size * hp.horizon // 64)
+    elif sc.num_robots > 64:
+        # the reference's 1024 / 512 assume 24 / 44 robots (3 / 6 minibatches per epoch).  Minibatches are drawn
+        # from THIS rank's T*N rows, so the per-rank batch does not depend on the world size: 32 minibatches per
+        # epoch per rank; the global batch of one optimiser step is world_size x this.
+        hp.batch_size = max(hp.batch_size, sc.num_robots * hp.horizon // 32)
     env = VecStageWorld(sc)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=a.seed, stage2=(a.stage == 2))
+    out.info("per-rank minibatch %d rows, global batch per optimiser step %d, lr %g, epochs %d, horizon %d",
+             hp.batch_size, hp.batch_size * world_size, hp.learning_rate, hp.epoch, hp.horizon)
     os.makedirs(a.policy_dir, exist_ok=True)
-    f = os.path.join(a.policy_dir, resume)
+    f = a.init or os.path.join(a.policy_dir, resume)
     if os.path.exists(f):
         out.info("############Loading Model########### %s", f)
         tr.policy.load_state_dict(torch.load(f, map_location=env.device))
         st = f + ".state"
-        if os.path.exists(st):
+        if os.path.exists(st) and not a.init:
             extra = torch.load(st, map_location=env.device)
             tr.optimizer.load_state_dict(extra["optimizer"])
             tr.global_update = extra["global_update"]
-            tr.gen.set_state(extra["generator"].cpu())
+            gens = extra.get("generators") or [extra["generator"]]
+            if rank < len(gens):
+                tr.gen.set_state(gens[rank].cpu())
+            else:   # resumed on more ranks than were saved: fresh, distinct noise streams for the new ranks
+                tr.gen.manual_seed(a.seed * 1000 + rank + 7919 * (tr.global_update + 1))
+    elif a.init:
+        raise FileNotFoundError(a.init)
     else:
         out.info("############Start Training###########")
+    circle_env = None
+    best_circle = -1.0
+
+    def gather_generators():
+        g = tr.gen.get_state()
+        if dist is None:
+            return [g]
+        states = [None] * world_size
+        dist.all_gather_object(states, g)
+        return states
 
     tr.start()
     n_logged = 0
+    t_start = time.perf_counter()
     for _ in range(a.updates):
+        if a.max_seconds:
+            stop = torch.tensor([float(time.perf_counter() - t_start > a.max_seconds)], device=env.device)
+            if dist is not None:
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)     # every rank leaves the loop at the same update
+            if float(stop) > 0:
+                out.info("stopping: --max-seconds %.0f reached", a.max_seconds)
+                break
         t0 = time.perf_counter()
         ep_done = torch.zeros(3, device=env.device)
         ep_reward = torch.zeros(env.N, device=env.device)
@@ -131,16 +184,38 @@ def main(argv=None):
         for rew in finished[-1:]:
             for v in rew[:8].tolist():
                 cal.info(v)
-        out.info("update %05d  %.0f agent-steps/s  episodes %d  reach %.3f  crash %.3f  timeout %.3f",
+        kl = "" if tr.last_kl is None else "  kl %.4f  lr %.2e" % (tr.last_kl, tr.optimizer.param_groups[0]["lr"])
+        out.info("update %05d  %.0f agent-steps/s  episodes %d  reach %.3f  crash %.3f  timeout %.3f%s",
                  tr.global_update, env.N * world_size * hp.horizon / dt, int(tot), float(ep_done[0]) / tot,
-                 float(ep_done[1]) / tot, float(ep_done[2]) / tot)
-        if rank == 0 and tr.global_update % a.save_every == 0:
+                 float(ep_done[1]) / tot, float(ep_done[2]) / tot, kl)
+        if tr.global_update % a.save_every == 0:
+            gens = gather_generators()          # collective: every rank takes part
+            if rank == 0:
+                p = os.path.join(a.policy_dir, pattern.format(tr.global_update))
+                torch.save(tr.policy.state_dict(), p)
+                torch.save({"optimizer": tr.optimizer.state_dict(), "global_update": tr.global_update,
+                            "generator": gens[0], "generators": gens}, p + ".state")
+                out.info("########################## model saved when update %d times#########################",
+                         tr.global_update)
+        if a.circle_every and rank == 0 and tr.global_update % a.circle_every == 0:
+            from . import evaluate
+            if circle_env is None:
+                circle_env = VecStageWorld(scenario.circle(num_worlds=a.circle_worlds, seed=a.seed))
+            m = evaluate.circle_test(circle_env, evaluate.cnn_policy_fn(tr.policy), a.circle_ticks)
+            out.info("circle %05d  success %.3f  crash %.3f  unfinished %.3f  ticks %d", tr.global_update,
+                     m["success_rate"], m["crash_rate"], m["unfinished_rate"], m["ticks_run"])
+            if m["success_rate"] > best_circle:
+                best_circle = m["success_rate"]
+                torch.save(tr.policy.state_dict(), os.path.join(a.policy_dir, "best_circle.pth"))
+    if tr.global_update % a.save_every != 0:      # the last state of a run that stopped between save points
+        gens = gather_generators()
+        if rank == 0:
             p = os.path.join(a.policy_dir, pattern.format(tr.global_update))
             torch.save(tr.policy.state_dict(), p)
             torch.save({"optimizer": tr.optimizer.state_dict(), "global_update": tr.global_update,
-                        "generator": tr.gen.get_state()}, p + ".state")
-            out.info("########################## model saved when update %d times#########################",
-                     tr.global_update)
+                        "generator": gens[0], "generators": gens}, p + ".state")
+    if rank == 0:
+        torch.save(tr.policy.state_dict(), os.path.join(a.policy_dir, "last.pth"))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -32,6 +32,8 @@ class HParams:
     action_bound: tuple = ((0.0, -1.0), (1.0, 1.0))   # ppo_stage1.py:170
     inference_dtype: object = None    # None = fp32 like the reference; torch.bfloat16 = opt-in fast rollouts
     update_dtype: object = None       # autocast dtype of the PPO update's forward/backward (opt-in)
+    kl_target: float = 0.0            # > 0: KL-adaptive learning rate (ppo.KLAdaptiveLR; opt-in, large-batch regime)
+    lr_max: float = 1e-3
 
 
 def broadcast_parameters(module, dist):
@@ -52,6 +54,7 @@ class Stage1Trainer:
         broadcast_parameters(self.policy, dist)
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate)
         self.flat_grads = ppo.FlatGrads(self.policy.parameters())
+        self.kl_ctl = ppo.KLAdaptiveLR(self.hp.kl_target, lr_max=self.hp.lr_max) if self.hp.kl_target > 0 else None
         self.buffer = ppo.RolloutBuffer(self.hp.horizon, env.N, self.hp.laser_hist, self.hp.obs_size, dev,
                                         self.hp.act_size)
         self.gen = torch.Generator(device=dev)
@@ -89,12 +92,16 @@ class Stage1Trainer:
                   epoch=hp.epoch, coeff_entropy=hp.coeff_entropy, clip_value=hp.clip_value, num_step=hp.horizon,
                   num_env=env.N, frames=hp.laser_hist, obs_size=hp.obs_size, act_size=hp.act_size,
                   value_coef=hp.value_coef, dist=self.dist, flat_grads=self.flat_grads, log=self.loss_log,
-                  autocast_dtype=hp.update_dtype)
+                  autocast_dtype=hp.update_dtype, kl_ctl=self.kl_ctl)
         if self.stage2:
             ppo.ppo_update_stage2(filter_index=ppo.get_filter_index(buf.done), **kw)
         else:
             ppo.ppo_update_stage1(**kw)
         self.global_update += 1
+
+    @property
+    def last_kl(self):
+        return None if self.kl_ctl is None else self.kl_ctl.last_kl
 
     def run(self, ticks):
         if not self.started:

@@ -116,3 +116,86 @@ def test_flat_grads_is_one_bucket():
     for p in fg.params:
         assert p.grad.data_ptr() == base + 4 * off
         off += p.numel()
+
+
+# ------------------------------------------------------------------------------------------------
+# Stage 2: the filter leaves a different number of rows on each rank; both ranks must still take the SAME number of
+# optimiser steps (one gradient all-reduce each), otherwise the collectives pair up wrongly and RCCL hangs.
+def _worker_stage2(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    from mrca import ppo
+    from mrca.trainer import broadcast_parameters
+    pol = _policy()
+    broadcast_parameters(pol, dist)
+    opt = torch.optim.SGD(pol.parameters(), lr=1e-2)
+    fg = ppo.FlatGrads(pol.parameters())
+    mem = _memory()
+    half = N // world
+    local = tuple(None if m is None else m[:, rank * half:(rank + 1) * half].contiguous() for m in mem)
+    n_local = T * half                                  # 16 rows per rank
+    # rank 0 drops 1 row (15 kept -> 3 minibatches of 4 with drop_last), rank 1 drops 7 (9 kept -> 2 minibatches)
+    filt = torch.arange(1) if rank == 0 else torch.arange(7)
+    log = []
+    ppo.ppo_update_stage2(policy=pol, optimizer=opt, batch_size=4, memory=local, filter_index=filt, epoch=2,
+                          coeff_entropy=5e-4, clip_value=0.1, num_step=T, num_env=half, frames=3, obs_size=B,
+                          act_size=2, dist=dist, flat_grads=fg, log=log)
+    steps = torch.tensor([len(log)])
+    both = [torch.zeros_like(steps) for _ in range(world)]
+    dist.all_gather(both, steps)
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    # without flat_grads a multi-rank update must refuse to run (it would train unsynchronised replicas)
+    refused = False
+    try:
+        ppo.ppo_update_stage1(policy=pol, optimizer=opt, batch_size=4, memory=local, epoch=1, num_step=T, num_env=half,
+                              frames=3, obs_size=B, act_size=2, dist=dist, flat_grads=None)
+    except ValueError:
+        refused = True
+    if rank == 0:
+        assert n_local == 16
+        assert int(both[0]) == int(both[1]) == 2 * 2, (both, "2 epochs x min(3, 2) minibatches on every rank")
+        assert torch.equal(gathered[0], gathered[1]), "replicas diverged"
+        assert refused
+        torch.save(torch.tensor([1]), out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_stage2_update_with_unequal_filtering_stays_in_step():
+    out = os.path.join(tempfile.mkdtemp(), "ok.pt")
+    mp.spawn(_worker_stage2, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert os.path.exists(out)
+
+
+def _worker_kl(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mrca import ppo
+    pol = _policy()
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+    fg = ppo.FlatGrads(pol.parameters())
+    mem = _memory(seed=rank)       # different data per rank: the local KLs differ, the decision must not
+    half = N // world
+    local = tuple(None if m is None else m[:, :half].contiguous() for m in mem)
+    ctl = ppo.KLAdaptiveLR(target=1e-9, lr_min=1e-7)   # any movement exceeds this target: lr must shrink everywhere
+    ppo.ppo_update_stage1(policy=pol, optimizer=opt, batch_size=8, memory=local, epoch=3, num_step=T, num_env=half,
+                          frames=3, obs_size=B, act_size=2, dist=dist, flat_grads=fg, kl_ctl=ctl)
+    lr = torch.tensor([opt.param_groups[0]["lr"], ctl.last_kl], dtype=torch.float64)
+    both = [torch.zeros_like(lr) for _ in range(world)]
+    dist.all_gather(both, lr)
+    if rank == 0:
+        assert torch.equal(both[0], both[1]), both
+        assert abs(float(both[0][0]) - 1e-3 / 1.5 ** 3) < 1e-12
+        torch.save(torch.tensor([1]), out)
+    dist.destroy_process_group()
+
+
+def test_kl_adaptive_lr_takes_the_same_decision_on_every_rank():
+    out = os.path.join(tempfile.mkdtemp(), "ok.pt")
+    mp.spawn(_worker_kl, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert os.path.exists(out)
