@@ -153,11 +153,14 @@ const char* mrca_last_error(void);
  * recorded launches in milliseconds and clears the ring. */
 int mrca_enable_timing(mrca_env* env, int32_t on); /* on = n > 0: time every n-th step; 0: off */
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
-/* Profiling ablations ONLY (results are wrong while any of bits 0-5 is set): 1 = skip robot-robot lidar
- * tests, 2 = skip the grid march, 8 / 16 / 32 = move kernel without its outline test / collision loop /
- * resets.  Bits 8-10 = k > 0 launch the ray cast with beams >> (k-1) threads per robot (a tuning knob:
- * results are unchanged).  0 restores the product path. */
+#ifdef MRCA_PROFILING
+/* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product
+ * library neither exports this symbol nor contains the switches.  Results are WRONG while any of bits 0-5 is
+ * set: 1 = skip robot-robot lidar tests, 2 = skip the grid march, 8 / 16 / 32 = move kernel without its outline
+ * test / collision loop / resets.  Launch-shape knobs (results unchanged): bits 8-10 = k > 0: 1 << (k-1) beams per
+ * marching thread; bit 11: no dedicated preparation wave.  0 restores the product path. */
 int mrca_set_debug_flags(mrca_env* env, int32_t flags);
+#endif
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ struct Layout {
     size_t field_off[MRCA_F_COUNT];
     size_t field_bytes[MRCA_F_COUNT];
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
-    size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield;
+    size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield, off_head;
     size_t total;
 };
 
@@ -125,6 +125,7 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_free_rect = take((size_t)(c->map_width + 2 * mrca::kFieldPadX) * (c->map_height + 2 * mrca::kFieldPadY) *
                             sizeof(uint32_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
+    L->off_head = take(N * sizeof(float4));
     L->total = off;
 }
 
@@ -158,6 +159,19 @@ std::shared_ptr<const HostField> host_field(const mrca_config* c) {
     cache.push_back(f);
     return f;
 }
+
+// Launches must target the env's device whatever the caller's current device is (two envs on two GPUs in one
+// process; a torch caller whose current device differs): switch for the duration of the call, then restore.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 }  // namespace
 
@@ -325,6 +339,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.free_rect = reinterpret_cast<const uint32_t*>(a + L.off_free_rect);
     v.free_rect_pitch = free_rect_pitch;
     v.cellfield = reinterpret_cast<const uint8_t*>(a + L.off_cellfield);
+    v.head = reinterpret_cast<float4*>(a + L.off_head);
     v.g.x0 = cfg->map_x0;
     v.g.y0 = cfg->map_y0;
     v.g.cell = cfg->map_cell;
@@ -341,10 +356,10 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.key1 = (uint32_t)(cfg->seed >> 32);
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.debug_flags = 0;
-    // 256 threads per 512-beam robot (2 beams each): 8 resident workgroups per CU instead of 4 hide the
-    // per-robot latency chain (pose -> march -> store) better; measured 33.2 us against 39.9 us for
-    // 512 threads x 1 beam and 33.8 us for 128 threads x 4 beams at 4096 robots (profiles/r01_aa_ablation.txt)
+    // 256 marching threads per 512-beam robot, 2 beams each in lock step, plus one wave that prepares the neighbour
+    // list while the others march (variants measured in profiles/: threads per robot, with / without that wave)
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
+    v.ray_prep_wave = 1;
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
@@ -352,6 +367,9 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     if (env->lds_bytes > 160 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "the ray cast needs %zu B of LDS per robot (> 160 KiB): too many beams",
                          env->lds_bytes));
+    mrca::launch_head_init(v, nullptr);   // head records of the construction-time poses (all at the origin)
+    HIP_TRY_BAIL(hipGetLastError());
+    HIP_TRY_BAIL(hipDeviceSynchronize());
     *env_out = env;
     return MRCA_OK;
 #undef HIP_TRY_BAIL
@@ -376,6 +394,7 @@ int mrca_get_field(mrca_env* env, int field, void** ptr_dev_out, size_t* offset_
 
 int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, const float* goals_dev, void* stream) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    DeviceGuard guard(env->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     mrca::launch_reset(env->view, mask_dev, poses_dev, goals_dev, s);
     mrca::launch_raycast(env->view, /*only_fresh=*/1, s);
@@ -386,6 +405,7 @@ int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, c
 int mrca_step(mrca_env* env, const float* actions_dev, void* stream) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     if (!actions_dev) return fail(MRCA_ERR_INVALID, "actions_dev is NULL");
+    DeviceGuard guard(env->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool rec = env->timing > 0 && (env->step_count++ % env->timing) == 0 &&
                      env->ev_used + 3 <= (int)env->ev.size();
@@ -425,19 +445,27 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
     return MRCA_OK;
 }
 
+#if defined(MRCA_PROFILING)
+// Profiling build only (libmrca_env_prof.so): ablation switches (results are WRONG while bits 0-5 are set) and
+// launch-shape knobs (results unchanged): bits 8-10 = k > 0: 1 << (k-1) beams per marching thread; bit 11: no
+// dedicated preparation wave.
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     env->view.debug_flags = flags & 0x3F;
-    const int knob = (flags >> 8) & 7;  // 0 keeps the default; k > 0 selects beams >> (k-1) threads per robot
+    const int knob = (flags >> 8) & 7;
     if (knob) {
         const int shift = knob - 1;
         const int threads = env->cfg.beams >> shift;
-        if (threads < 64 || threads < (env->cfg.beams >> 2))
-            return fail(MRCA_ERR_INVALID, "threads-per-robot knob %d out of range", knob);
+        if (shift > 2 || threads < 64 || threads % 64 || threads < (env->cfg.beams >> 2))
+            return fail(MRCA_ERR_INVALID, "beams-per-thread knob %d out of range", knob);
         env->view.ray_shift = shift;
+    } else {
+        env->view.ray_shift = (env->cfg.beams >= 256) ? 1 : 0;   // the product's launch shape
     }
+    env->view.ray_prep_wave = (flags & 0x800) ? 0 : 1;
     return MRCA_OK;
 }
+#endif
 
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");

@@ -330,6 +330,126 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, float ox, f
     return grid_march_skip(field, g, march_origin(field, g, ox, oy), dx, dy, tmax);
 }
 
+// K rays from the same origin marched in LOCK STEP by one thread: the same per-ray arithmetic as
+// grid_march_skip (every number a ray produces is bit-identical), but the K field lookups of an iteration
+// are independent and issued back to back, so one wait covers K dependent-load latencies instead of one.
+// The loop runs while any ray is still marching; a finished ray keeps re-reading its last cell (an L1 hit)
+// and commits nothing.  Per wavefront the iteration count is max over lanes and rays instead of the sum over
+// rays of the max over lanes -- the VALU work is the same, the exposed latency is 1/K.
+template <int K, class Field>
+MRCA_HD void grid_march_skip_n(const Field& field, const GridGeom& g, const MarchOrigin& org, const float (&dx)[K],
+                               const float (&dy)[K], float tmax, float (&out)[K]) {
+    const float fx = org.fx, fy = org.fy;
+    const float tmax_c = tmax * g.inv_cell;
+    if (org.v0 == kCellOccupied) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = 0.0f;
+        return;
+    }
+    if (!(tmax_c > 0.0f)) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = tmax;
+        return;
+    }
+    float inv_dx[K], inv_dy[K], t[K];
+    int bx[K], by[K];
+    uint32_t v[K];
+    bool act[K], hit[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        inv_dx[k] = dx[k] != 0.0f ? 1.0f / dx[k] : kInf;
+        inv_dy[k] = dy[k] != 0.0f ? 1.0f / dy[k] : kInf;
+        bx[k] = org.ix0 + (dx[k] > 0.0f ? 1 : 0);
+        by[k] = org.iy0 + (dy[k] > 0.0f ? 1 : 0);
+        v[k] = org.v0;
+        t[k] = 0.0f;
+        act[k] = true;
+        hit[k] = false;
+    }
+    int guard = kMaxMarchSteps;
+    bool any = true;
+    while (any) {
+        int cx[K], cy[K], nbx[K], nby[K];
+        float tn[K];
+        bool go[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool xnz = dx[k] != 0.0f, ynz = dy[k] != 0.0f;
+            const bool xpos = dx[k] > 0.0f, ypos = dy[k] > 0.0f;
+            const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
+            const int ux = xpos ? 1 : 0, uy = ypos ? 1 : 0;
+            const int shx = xpos ? 8 : 0, shy = ypos ? 24 : 16;
+            const int limx = xpos ? 0x3FFFFFFF : -0x3FFFFFFF, limy = ypos ? 0x3FFFFFFF : -0x3FFFFFFF;
+            const int ex = (int)((v[k] >> shx) & 255u), ey = (int)((v[k] >> shy) & 255u);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int Bx = __mul24(ex, sx) + bx[k];
+            const int By = __mul24(ey, sy) + by[k];
+#else
+            const int Bx = ex * sx + bx[k];
+            const int By = ey * sy + by[k];
+#endif
+            const float rawx = ((float)Bx - fx) * inv_dx[k];
+            const float rawy = ((float)By - fy) * inv_dy[k];
+            const float tBx = xnz ? rawx : kInf;
+            const float tBy = ynz ? rawy : kInf;
+            const bool xe = tBx < tBy;
+            const float tt = xe ? tBx : tBy;
+            const float fS = xe ? fy : fx;
+            const float invS = xe ? inv_dy[k] : inv_dx[k];
+            const int sS = xe ? sy : sx;
+            const int bS0 = xe ? by[k] : bx[k];
+            int bS = bS0;
+            if (xnz & ynz) {
+                const float pT = fS + (xe ? dy[k] : dx[k]) * tt;
+                const int b = med3_i32((int)floorf(pT) + (xe ? uy : ux), bS0, xe ? limy : limx);
+                const int bprev = b - sS;
+                const float tp = ((float)bprev - fS) * invS;
+                const float tc = ((float)b - fS) * invS;
+                const bool cons_p = (tp < tt) | ((tp == tt) & xe);
+                const bool cons_c = (tc < tt) | ((tc == tt) & xe);
+                bS = cons_c ? b + sS : b;
+                bS = ((b != bS0) & !cons_p) ? bprev : bS;
+            }
+            go[k] = act[k] && !(tt >= tmax_c);
+            tn[k] = tt;
+            nbx[k] = go[k] ? (xe ? Bx + sx : bS) : bx[k];
+            nby[k] = go[k] ? (xe ? bS : By + sy) : by[k];
+            cx[k] = nbx[k] - ux;
+            cy[k] = nby[k] - uy;
+        }
+        uint32_t nv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) nv[k] = field(cx[k], cy[k]);   // K independent lookups in flight
+        --guard;
+        any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            bx[k] = nbx[k];
+            by[k] = nby[k];
+            t[k] = go[k] ? tn[k] : t[k];
+            v[k] = go[k] ? nv[k] : v[k];
+            hit[k] = go[k] ? (nv[k] == kCellOccupied) : hit[k];
+            act[k] = go[k] && !hit[k] && guard > 0;
+            any = any || act[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = hit[k] ? t[k] * g.cell : tmax;
+}
+
+// scan / 6 - 0.5 (stage_world1.py:140).  The quotient is formed as q = x * RN(1/6), r = fma(-q, 6, x),
+// q' = fma(r, RN(1/6), q) -- Markstein's correction, 3 instructions instead of the ~12 of an IEEE division --
+// and q' - 0.5 equals RN(RN(x / 6) - 0.5) for EVERY float x in [0, 6] (checked exhaustively over all 1 086 324 737
+// of them: tests/test_geometry_properties.py::test_norm_obs_equals_ieee_division samples them, tools/check_div6.c
+// is the full sweep; q' itself differs from RN(x / 6) only where x / 6 is subnormal, which the subtraction
+// absorbs).
+MRCA_HD float norm_obs(float x) {
+    const float inv6 = 1.0f / 6.0f;
+    const float q = x * inv6;
+    const float r = __builtin_fmaf(-q, 6.0f, x);
+    return __builtin_fmaf(r, inv6, q) - 0.5f;
+}
+
 // ------------------------------------------------------------------------------------------
 // Robot outline (0.44 x 0.38 rectangle) against the grid: march the four edges.
 // Edge k of the footprint (corner k -> corner k+1, corners (+,+),(-,+),(-,-),(+,-)): does the walk

@@ -30,6 +30,10 @@ struct EnvView {
     uint8_t* fresh;
     int32_t* t;
     int32_t* episode;
+    // internal, one 16-byte record per robot, rewritten by whoever changes a pose (move / reset kernels): sin and
+    // cos of the heading (deterministic sincos_det) and the free-rectangle field entry of the cell the robot
+    // stands in (as float bits).  The ray cast starts from it instead of recomputing all three per wave.
+    float4* head;       // [N] (sin, cos, bits(v0), 0)
     // scenario tables, per local index
     const int32_t* reset_mode;
     const int32_t* goal_mode;
@@ -53,15 +57,25 @@ struct EnvView {
     int32_t num_groups;
     uint32_t key0, key1;
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
-    int32_t ray_shift;    // raycast_kernel launches beams >> ray_shift threads per robot
-    int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags)
+    int32_t ray_shift;    // raycast_kernel marches 1 << ray_shift beams per thread in lock step
+    int32_t ray_prep_wave;  // 1: a dedicated wave prepares the neighbour list (blockDim = beams >> ray_shift + 64)
+    int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
 };
+
+// Ablation switches exist only in the profiling build of the library (csrc/build.sh --profiling ->
+// libmrca_env_prof.so, used by tools/ablate.py); in the product they fold to `false` at compile time.
+#if defined(MRCA_PROFILING)
+#define MRCA_DBG(e, bit) (((e).debug_flags & (bit)) != 0)
+#else
+#define MRCA_DBG(e, bit) false
+#endif
 
 size_t ray_lds_bytes(const EnvView& e);
 size_t move_lds_bytes(const EnvView& e);
 
 void launch_move(const EnvView& e, const float* actions, hipStream_t s);
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s);
+void launch_head_init(const EnvView& e, hipStream_t s);
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
                 float lam, int T, int N, float* targets, float* advs, hipStream_t s);

@@ -9,13 +9,15 @@
 //                  lane runs the rectangle SAT against the pose it has at that point of the
 //                  order, a wavefront ballot decides revert+stall.  Reward / terminal / episode
 //                  bookkeeping (wave-parallel Philox resets, group ballots) follow.
-//   raycast_kernel one 256-thread workgroup per robot, two beams per thread.  The other robots of
-//                  the world within lidar reach are compacted into LDS by the first wave (ballot
-//                  + popcount) together with a per-beam bitmask of who can touch which beam, while
-//                  every beam already runs the exact skipping march over the per-cell free-rectangle
-//                  field (read from its L1/L2-resident copy: ~2 lookups per ray, the cell bitmap is
-//                  never touched), then slab-tests its neighbours.  Scan, normalised observation and
-//                  the frame-stack shift leave through LDS as 16-byte stores.
+//   raycast_kernel one workgroup per robot: beams/K marching threads, each marching K beams in LOCK STEP
+//                  (K independent field lookups in flight per thread: the march is a chain of dependent
+//                  L2 lookups, ~2 per ray), plus one preparation wave that compacts the other robots of
+//                  the world within lidar reach into LDS (ballot + popcount) together with a per-beam
+//                  bitmask of who can touch which beam.  The robot's own sin/cos and the field entry of
+//                  its cell come from the 16-byte `head` record the move kernel published (scalar
+//                  loads), so no wave recomputes them.  Each thread then slab-tests its own beams against
+//                  the flagged neighbours; scan, normalised observation and the frame-stack shift leave
+//                  through LDS as 16-byte stores.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
 //   gae_kernel     reverse GAE scan, thread per robot, coalesced over N.
 //
@@ -148,12 +150,13 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     const int rmode = valid ? e.reset_mode[lane] : 0;
     const int gmode = valid ? e.goal_mode[lane] : 0;
     const int gid = valid ? e.group_id[lane] : -1;
+    const float4 hd = e.head[n];   // sin / cos of th and the field entry of the robot's cell, kept by whoever moved it
     const float v = live ? sane_cmd(act_v) : 0.0f;
     const float w = live ? sane_cmd(act_w) : 0.0f;
 
     // integrate: explicit Euler with the heading at tick start
-    float s, c;
-    sincos_det(th, &s, &c);
+    float s = hd.x, c = hd.y;
+    uint32_t cellv = __float_as_uint(hd.z);
     const float d = v * kDt;
     const float nx = x + d * c;
     const float ny = y + d * s;
@@ -178,15 +181,19 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     // could visit is free => no hit, without touching the bitmap.  The byte is requested here and used
     // after the broad phase below, which needs no memory and so runs inside this load's latency.
     const bool inside = pix >= 0 && piy >= 0 && pix < e.g.width && piy < e.g.height;
-    const bool check_map = valid && !(e.debug_flags & 8);
+    const bool check_map = valid && !MRCA_DBG(e, 8);
     const uint8_t clearance = (check_map && inside) ? e.cellfield[(size_t)piy * e.g.width + pix] : 0;
+    // the field entry of the provisional cell rides in the same round trip: it becomes the `head` entry if the
+    // move is committed
+    const FreeRectField rect_field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
+    const uint32_t cellv_new = rect_field(pix, piy);
 
     // --- broad phase of the robot-robot collision pass (the pass itself follows the outline test): robot i
     //     can only touch robot j if its provisional centre comes within 2 x circumradius of j's old or
     //     new centre, so only the (few) robots with such a neighbour take a turn in the ordered pass;
     //     everybody else commits straight away -- their outcome does not depend on the order.
     bool involved = false;
-    if (!(e.debug_flags & 16)) {
+    if (!MRCA_DBG(e, 16)) {
         for (int j = 0; j < e.R; ++j) {
             const float ax = nx - fbcast(x, j), ay = ny - fbcast(y, j);
             const float bx2 = nx - fbcast(nx, j), by2 = ny - fbcast(ny, j);
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         th = nth;
         s = ns;
         c = nc;
+        cellv = cellv_new;
     }
     {
         unsigned long long turn = __ballot(involved);
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
                     th = nth;
                     s = ns;
                     c = nc;
+                    cellv = cellv_new;
                     moved = true;
                 }
                 crashed = hit ? 1 : 0;
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         }
     }
     float spv = v, spw = w, ovgt = vgt, owgt = wgt;
-    if (e.debug_flags & 32) fresh = false;
+    if (MRCA_DBG(e, 32)) fresh = false;
     // new episodes, one robot at a time with the whole wave sampling for it
     unsigned long long pending = __ballot(fresh);
     while (pending) {
@@ -353,11 +362,19 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         } else {
             wave_sample_goal(lane, gm, (uint32_t)nsrc, eps, e.key0, e.key1, px, py, &qx, &qy);
         }
+        // head record of the new pose (wave-uniform values; only lane src keeps them)
+        float rs_, rc_;
+        sincos_det(pth, &rs_, &rc_);
+        const uint32_t rv_ = rect_field((int)floorf((px - e.g.x0) * e.g.inv_cell),
+                                        (int)floorf((py - e.g.y0) * e.g.inv_cell));
         if (lane == src) {
             ep = (int)eps;
             x = px;
             y = py;
             th = pth;
+            s = rs_;
+            c = rc_;
+            cellv = rv_;
             gx = qx;
             gy = qy;
             const float ex = qx - px, ey = qy - py;
@@ -393,7 +410,22 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         e.live[n] = lv;
         e.episode[n] = ep;
         e.fresh[n] = fresh ? 1 : 0;
+        e.head[n] = make_float4(s, c, __uint_as_float(cellv), 0.0f);
     }
+}
+
+__device__ __forceinline__ void write_head(const EnvView& e, int n, float x, float y, float th) {
+    float s, c;
+    sincos_det(th, &s, &c);
+    const FreeRectField rect_field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
+    const uint32_t v0 = rect_field((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell));
+    e.head[n] = make_float4(s, c, __uint_as_float(v0), 0.0f);
+}
+
+// head records from the poses as they are (mrca_create: before the first reset every robot sits at the origin)
+__global__ void head_init_kernel(EnvView e) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < e.N) write_head(e, n, e.pose[n * 3 + 0], e.pose[n * 3 + 1], e.pose[n * 3 + 2]);
 }
 
 __global__ void reset_kernel(EnvView e, const uint8_t* __restrict__ mask, const float* __restrict__ poses,
@@ -411,6 +443,7 @@ __global__ void reset_kernel(EnvView e, const uint8_t* __restrict__ mask, const 
     e.pose[n * 3 + 0] = x;
     e.pose[n * 3 + 1] = y;
     e.pose[n * 3 + 2] = th;
+    write_head(e, n, x, y, th);
     e.goal[n * 2 + 0] = gx;
     e.goal[n * 2 + 1] = gy;
     e.prev_dist[n] = pd;
@@ -439,9 +472,9 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // lookups per ray.  (Staging a tile of it in LDS per robot was measured slower at every granularity tried,
 // the tile costs more to fill than the few lookups it serves.  So were persistent workgroups
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
-// no difference, nor did rotating which wave prepares the neighbour list and which waves run the epilogue
-// (profiles/r01_am_ablation_wave_rotation.txt): the hardware's own workgroup scheduling at 8 waves per SIMD
-// is the best overlap found.)
+// no difference.)  What a chain of dependent lookups wants is more of them in flight: each thread marches its
+// K beams in lock step (grid_march_skip_n), so one wait covers K lookups.
+template <int K>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int n = block_to_robot(blockIdx.x, e.N);
@@ -457,34 +490,66 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
-    unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(rbuf + e.B);   // [B] neighbours per beam
+    float* obuf = rbuf + e.B;                                         // [B] normalised ranges
+    unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(obuf + e.B);   // [B] neighbours per beam
 
+    const int T = e.B / K;                    // marching threads
+    const bool extra = (int)blockDim.x > T;   // a dedicated preparation wave sits behind the marching ones
+    const int prep_base = extra ? T : 0;
+    const bool is_prep = tid >= prep_base && tid < prep_base + kWave;   // wave-uniform
+    const bool marches = tid < T;                                       // wave-uniform
     const int world = n / e.R;
     const int local = n - world * e.R;
-    const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
-    // the first wave also requests "its" neighbour candidate now, in the same memory round trip
-    const bool cand = (tid < e.R) && (tid != local);
-    const int jn = world * e.R + ((tid < kWave && cand) ? tid : local);
-    const float xj = e.pose[jn * 3 + 0], yj = e.pose[jn * 3 + 1], thj = e.pose[jn * 3 + 2];
-    // the two frames that will be shifted down are fetched now, long before they are stored again (issued
-    // AFTER the neighbour pose so that waiting for that pose never waits for these): unconditionally and
-    // branch-free (a robot that did start an episode, a thread outside the 16-byte
-    // epilogue or a stack that is not 3 deep just ignores what it fetched from a valid address)
-    __builtin_amdgcn_sched_barrier(0);  // keep the issue order pose -> frames
+    // the robot's own record is block-uniform: pose, sin / cos and the field entry of its cell
+    const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1];
+    const float4 hd = e.head[n];
+    const float s = hd.x, c = hd.y;
+    // the preparation wave requests "its" neighbour candidate in the same memory round trip
+    const int pl = tid - prep_base;
+    const bool cand = is_prep && (pl < e.R) && (pl != local);
+    const int jn = world * e.R + (cand ? pl : local);
+    float xj = 0.0f, yj = 0.0f;
+    float4 hj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (is_prep) {
+        xj = e.pose[jn * 3 + 0];
+        yj = e.pose[jn * 3 + 1];
+        hj = e.head[jn];
+    }
+    // beam directions in the robot frame for this thread's K beams (tid + k*T)
+    float bc[K], bs[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int b = (marches ? tid : 0) + k * T;
+        bc[k] = e.beam_cos[b];
+        bs[k] = e.beam_sin[b];
+    }
     const bool wide = tid < (e.B >> 2);
     const int fstride = e.B >> 2;
-    float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B) + (wide ? tid : 0);
-    const float4 keep1 = ob4[e.F == 3 ? fstride : 0];
-    const float4 keep2 = ob4[e.F == 3 ? 2 * fstride : 0];
-    float s, c;
-    sincos_det(th, &s, &c);
-
-    for (int b = tid; b < e.B; b += blockDim.x) nbmask[b] = 0ull;
-    __syncthreads();  // masks cleared before the first wave scatters into them
-
-    // --- first wave: compact the world's other robots within lidar reach into LDS, each with the
-    //     (conservative) interval of beams that can touch it
-    if (tid < kWave) {
+    float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B);
+    // The frame-stack shift (ppo_stage1.py:87-89: popleft / append) does not depend on this tick's ranges at all:
+    // the preparation wave moves frames 1.. down to 0.. on its own -- requested here, in the same round trip as its
+    // neighbour candidate, stored as soon as they arrive -- while the other waves march.  The marching waves never
+    // wait on an HBM load and carry no frame registers; they only append the newest frame.  (A robot that started
+    // an episode gets all its frames from the epilogue instead.)
+    const bool shifter = is_prep && !fresh && e.F == 3;
+    const int chunks = (fstride + kWave - 1) / kWave;          // float4 chunks per lane and frame (2 at 512 beams)
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool sh0 = shifter && chunks <= 2 && pl < fstride;            // this lane's first / second column
+    const bool sh1 = shifter && chunks <= 2 && pl + kWave < fstride;
+    const int j0 = sh0 ? pl : 0, j1 = sh1 ? pl + kWave : 0;
+    float4 keep1a = zero4, keep2a = zero4, keep1b = zero4, keep2b = zero4;
+    if (sh0) {
+        keep1a = ob4[fstride + j0];
+        keep2a = ob4[2 * fstride + j0];
+    }
+    if (sh1) {
+        keep1b = ob4[fstride + j1];
+        keep2b = ob4[2 * fstride + j1];
+    }
+    // --- preparation wave: compact the world's other robots within lidar reach into LDS, each with the
+    //     (conservative) interval of beams that can touch it.  It alone touches the masks before the barrier.
+    if (is_prep) {
+        for (int b = pl; b < e.B; b += kWave) nbmask[b] = 0ull;
         const float ddx = xj - x, ddy = yj - y;
         // conservative cull: a hit below 6 m needs the centre within 6 + circumradius(0.2907) m
         bool keep = cand && (ddx * ddx + ddy * ddy <= 39.69f);
@@ -495,77 +560,83 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
         const unsigned long long m = __ballot(keep);
         if (keep) {
-            float sj, cj;
-            sincos_det(thj, &sj, &cj);
-            const int idx = __popcll(m & ((1ull << tid) - 1ull));
-            nb[idx] = make_float4(xj, yj, sj, cj);
+            const int idx = __popcll(m & ((1ull << pl) - 1ull));
+            nb[idx] = make_float4(xj, yj, hj.x, hj.y);
             nbi[idx] = make_int2(lo, hi);
         }
-        const int cnt0 = (e.debug_flags & 1) ? 0 : __popcll(m);
-        if (tid == 0) *nb_count = cnt0;
+        const int cnt0 = MRCA_DBG(e, 1) ? 0 : __popcll(m);
+        if (pl == 0) *nb_count = cnt0;
         // scatter: bit k of nbmask[b] = "neighbour k can touch beam b".  One wave, program order: the
         // read-modify-writes of successive k never race, and within one k the lanes hit distinct beams.
         for (int k = 0; k < cnt0; ++k) {
             const int2 iv = nbi[k];
-            for (int b = iv.x + tid; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
+            for (int b = iv.x + pl; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
         }
-    }
-    // --- beams: thread t takes beams t, t + blockDim, ... (one each in the default launch)
-    const FreeRectField field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
-    const MarchOrigin org = march_origin(field, e.g, x, y);   // once per robot: shared by all its beams
-    {
-        int b = tid;                                           // tid < blockDim <= B
-        float bc = e.beam_cos[b], bs = e.beam_sin[b];
-        while (b < e.B) {
-            // the next beam's direction is requested now and arrives while this one marches
-            const int bn = b + blockDim.x;
-            const int bl = bn < e.B ? bn : b;
-            const float nbc = e.beam_cos[bl], nbs = e.beam_sin[bl];
-            const float dx = c * bc - s * bs;
-            const float dy = s * bc + c * bs;
-            rbuf[b] = (e.debug_flags & 2) ? kRangeMax : grid_march_skip(field, e.g, org, dx, dy, kRangeMax);
-            b = bn;
-            bc = nbc;
-            bs = nbs;
-        }
-    }
-    __syncthreads();  // neighbour list ready (the first wave built it while the others marched)
-    const int cnt = *nb_count;
-    for (int b = tid; b < e.B; b += blockDim.x) {
-        float rng = rbuf[b];
-        unsigned long long m = cnt > 0 ? nbmask[b] : 0ull;
-        if (m) {
-            const float bc = e.beam_cos[b], bs = e.beam_sin[b];
-            const float dx = c * bc - s * bs;
-            const float dy = s * bc + c * bs;
-            while (m) {
-                const int k = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const float4 q = nb[k];
-                const float t = ray_box(x, y, dx, dy, q.x, q.y, q.z, q.w);
-                rng = t < rng ? t : rng;
+        // frame-stack shift: a lane only ever touches "its" float4 columns, so reads and writes of different
+        // lanes never meet, and within a lane every store waits for the loads it depends on
+        if (shifter && chunks <= 2) {
+            if (sh0) {
+                ob4[j0] = keep1a;
+                ob4[fstride + j0] = keep2a;
             }
+            if (sh1) {
+                ob4[j1] = keep1b;
+                ob4[fstride + j1] = keep2b;
+            }
+        } else if (is_prep && !fresh) {   // any other stack depth / beam count: frame by frame, column by column
+            for (int j = pl; j < fstride; j += kWave)
+                for (int f = 0; f + 1 < e.F; ++f) ob4[f * fstride + j] = ob4[(f + 1) * fstride + j];
         }
-        rbuf[b] = rng < kRangeMax ? rng : kRangeMax;
+    }
+    // --- the march: K beams per thread in lock step
+    float dx[K], dy[K], rng[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        dx[k] = c * bc[k] - s * bs[k];
+        dy[k] = s * bc[k] + c * bs[k];
+        rng[k] = kRangeMax;
+    }
+    if (marches && !MRCA_DBG(e, 2)) {
+        const FreeRectField field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
+        MarchOrigin org;                       // once per robot: shared by all its beams
+        org.fx = (x - e.g.x0) * e.g.inv_cell;
+        org.fy = (y - e.g.y0) * e.g.inv_cell;
+        org.ix0 = (int)floorf(org.fx);
+        org.iy0 = (int)floorf(org.fy);
+        org.v0 = __float_as_uint(hd.z);
+        grid_march_skip_n<K>(field, e.g, org, dx, dy, kRangeMax, rng);
+    }
+    __syncthreads();  // neighbour list ready (the preparation wave built it while the others marched)
+    if (!marches) return;  // the dedicated preparation wave is done (whole wave: the barrier below counts live waves)
+    const int cnt = *nb_count;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int b = tid + k * T;
+        float r = rng[k];
+        unsigned long long m = cnt > 0 ? nbmask[b] : 0ull;
+        while (m) {
+            const int q = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float4 nbq = nb[q];
+            const float t = ray_box(x, y, dx[k], dy[k], nbq.x, nbq.y, nbq.z, nbq.w);
+            r = t < r ? t : r;
+        }
+        r = r < kRangeMax ? r : kRangeMax;
+        rbuf[b] = r;
+        obuf[b] = norm_obs(r);     // stage_world1.py:140, once per value, spread over all marching threads
     }
 
-    // --- scan, normalised observation (stage_world1.py:140), frame stack (ppo_stage1.py:59-60,87-89):
-    //     ranges go through LDS so that a quarter of the threads can move 16 bytes each
+    // --- scan, normalised observation, frame stack (ppo_stage1.py:59-60,87-89): ranges went through LDS so
+    //     that a quarter of the threads can move 16 bytes each
     __syncthreads();
     if (wide) {
         const float4 r4 = reinterpret_cast<const float4*>(rbuf)[tid];
-        const float4 o4 = make_float4(r4.x / 6.0f - 0.5f, r4.y / 6.0f - 0.5f, r4.z / 6.0f - 0.5f, r4.w / 6.0f - 0.5f);
-        float4* ob = ob4;
+        const float4 o4 = reinterpret_cast<const float4*>(obuf)[tid];
         reinterpret_cast<float4*>(e.scan + (size_t)n * e.B)[tid] = r4;
         if (fresh) {
-            for (int f = 0; f < e.F; ++f) ob[f * fstride] = o4;
-        } else if (e.F == 3) {
-            ob[0] = keep1;
-            ob[fstride] = keep2;
-            ob[2 * fstride] = o4;
+            for (int f = 0; f < e.F; ++f) ob4[f * fstride + tid] = o4;
         } else {
-            for (int f = 0; f + 1 < e.F; ++f) ob[f * fstride] = ob[(f + 1) * fstride];
-            ob[(e.F - 1) * fstride] = o4;
+            ob4[(e.F - 1) * fstride + tid] = o4;      // frames below were shifted by the preparation wave
         }
     }
     if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
@@ -600,7 +671,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 }  // namespace
 
 size_t ray_lds_bytes(const EnvView& e) {
-    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 12;
+    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 16;
 }
 
 size_t move_lds_bytes(const EnvView& e) {
@@ -618,8 +689,19 @@ void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, con
     hipLaunchKernelGGL(reset_kernel, dim3((e.N + bs - 1) / bs), dim3(bs), 0, s, e, mask, poses, goals);
 }
 
+void launch_head_init(const EnvView& e, hipStream_t s) {
+    const int bs = 256;
+    hipLaunchKernelGGL(head_init_kernel, dim3((e.N + bs - 1) / bs), dim3(bs), 0, s, e);
+}
+
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
-    hipLaunchKernelGGL(raycast_kernel, dim3(e.N), dim3(e.B >> e.ray_shift), ray_lds_bytes(e), s, e, only_fresh);
+    const int threads = (e.B >> e.ray_shift) + (e.ray_prep_wave ? kWave : 0);
+    const size_t lds = ray_lds_bytes(e);
+    switch (e.ray_shift) {
+        case 0: hipLaunchKernelGGL(raycast_kernel<1>, dim3(e.N), dim3(threads), lds, s, e, only_fresh); break;
+        case 1: hipLaunchKernelGGL(raycast_kernel<2>, dim3(e.N), dim3(threads), lds, s, e, only_fresh); break;
+        default: hipLaunchKernelGGL(raycast_kernel<4>, dim3(e.N), dim3(threads), lds, s, e, only_fresh); break;
+    }
 }
 
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,

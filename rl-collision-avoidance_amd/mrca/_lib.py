@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrca_env.so")
+# MRCA_ENV_LIB selects another build of the SAME library (tools/ablate.py points it at the profiling build
+# libmrca_env_prof.so); whichever it is, it must exist -- there is no fallback
+LIB_PATH = os.environ.get("MRCA_ENV_LIB") or os.path.join(_HERE, "libmrca_env.so")
 
 ABI_VERSION = 1
 
@@ -16,8 +18,7 @@ FIELDS = [  # order = enum mrca_field
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
-           "mrca_step", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
-           "mrca_set_debug_flags"]
+           "mrca_step", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing"]
 
 
 class MrcaConfig(C.Structure):
@@ -60,7 +61,8 @@ def load():
     lib.mrca_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
-    lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]
+    if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only
+        lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]
     lib.mrca_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.mrca_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libmrca_env.so ABI {lib.mrca_abi_version()} != binding ABI {ABI_VERSION}")

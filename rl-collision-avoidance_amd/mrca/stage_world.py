@@ -21,6 +21,13 @@ from . import scenario as S
 _backend_factory = None
 _shared = {}
 _shared_lock = threading.Lock()
+_base_seed = 0
+
+
+def set_seed(seed):
+    """Base seed of the per-facade pose / goal generators (see StageWorldBase.rng)."""
+    global _base_seed
+    _base_seed = int(seed)
 
 
 def set_backend_factory(factory):
@@ -148,6 +155,10 @@ class StageWorldBase:
         self.pre_distance = 0.0
         self.distance = 0.0
         self.world = shared_world(self.VARIANT, num_env)
+        # The reference draws poses / goals from the process-global ``np.random`` of its own MPI process
+        # (stage_world1.py:251-274).  Ranks are threads here, so every facade owns its generator -- seeded from
+        # (base seed, rank): a run is reproducible whatever order the rank threads are scheduled in.
+        self.rng = np.random.RandomState((_base_seed * 1000003 + 7919 * index + 17) & 0x7FFFFFFF)
 
     # ---- raw getters (stage_world1.py:116-153)
     def get_self_stateGT(self):
@@ -211,14 +222,21 @@ class StageWorldBase:
         self.distance = self.pre_distance
 
     def get_reward_and_terminate(self, t):
-        """stage_world1.py:180-211, evaluated on the device during the tick; ``t`` must track the
-        device's own step counter (it does in all three reference scripts)."""
+        """stage_world1.py:180-211.  The reward is evaluated on the device during the tick (it does not depend
+        on ``t``); the terminal flag and the result string are assembled here from the device's distance and
+        stall flag and the CALLER's step counter ``t``, with the reference's precedence (Reach Goal < Crashed <
+        Time out) -- so a script whose counter differs from the device's own gets the timeout it asked for."""
         w = self.world
         reward = float(w.field("reward")[self.index])
-        terminate = bool(w.field("done")[self.index])
-        result = _RESULT[int(w.field("result")[self.index])]
         self.pre_distance = self.distance
         self.distance = float(w.field("prev_dist")[self.index])
+        terminate, result = False, 0
+        if self.distance < self.goal_size:
+            terminate, result = True, "Reach Goal"
+        if int(w.field("crashed")[self.index]) == 1:
+            terminate, result = True, "Crashed"
+        if t > w.sc.timeout:
+            terminate, result = True, "Time out"
         return reward, terminate, result
 
     # ---- variant hooks
@@ -229,17 +247,17 @@ class StageWorldBase:
         return self.generate_random_goal()
 
     def generate_random_pose(self):
-        """stage_world1.py:251-260 (host numpy RNG, as in the reference)."""
+        """stage_world1.py:251-260 (host numpy RNG like the reference; one generator per facade)."""
         while True:
-            x, y = np.random.uniform(-9, 9), np.random.uniform(-9, 9)
+            x, y = self.rng.uniform(-9, 9), self.rng.uniform(-9, 9)
             if np.sqrt(x ** 2 + y ** 2) <= 9:
-                return [x, y, np.random.uniform(0, 2 * np.pi)]
+                return [x, y, self.rng.uniform(0, 2 * np.pi)]
 
     def generate_random_goal(self):
         """stage_world1.py:262-274."""
         self.init_pose = self.get_self_stateGT()
         while True:
-            x, y = np.random.uniform(-9, 9), np.random.uniform(-9, 9)
+            x, y = self.rng.uniform(-9, 9), self.rng.uniform(-9, 9)
             d_o = np.sqrt(x ** 2 + y ** 2)
             d_g = np.sqrt((x - self.init_pose[0]) ** 2 + (y - self.init_pose[1]) ** 2)
             if not (d_o > 9 or d_g > 10 or d_g < 8):
@@ -255,15 +273,15 @@ class _RegionMixin:
         """stage_world2.py:250-287: x~U(9,19), y in two bands, >= 7 m from the robot."""
         x_r, y_r, _ = self.get_self_stateGT()
         while True:
-            x = np.random.uniform(9, 19)
-            y = np.random.uniform(0, 1)
+            x = self.rng.uniform(9, 19)
+            y = self.rng.uniform(0, 1)
             y = -(y * 10 + 1) if y <= 0.4 else -(y * 10 + 9)
             if not np.sqrt((x - x_r) ** 2 + (y - y_r) ** 2) < 7:
                 return x, y
 
     def generate_random_pose(self):
         x, y = self._region_point()
-        return [x, y, np.random.uniform(0, 2 * np.pi)]
+        return [x, y, self.rng.uniform(0, 2 * np.pi)]
 
     def generate_random_goal(self):
         return list(self._region_point())

@@ -118,9 +118,11 @@ class VecStageWorld:
         _lib.check(self.lib.mrca_enable_timing(self._h, int(on)), "mrca_enable_timing")
 
     def set_debug_flags(self, flags):
-        """Profiling ablations only (results are wrong while bits 0-5 are set): 1 no robot-robot lidar
-        tests, 2 no grid march, 8 / 16 / 32 move kernel without outline test / collision loop / resets;
-        bits 8-10 = k > 0: ray cast launched with beams >> (k-1) threads per robot (results unchanged)."""
+        """Profiling build only (MRCA_ENV_LIB=.../libmrca_env_prof.so, include/mrca_env.h): ablation switches and
+        launch-shape knobs of the kernels.  The product library does not have them."""
+        if not hasattr(self.lib, "mrca_set_debug_flags"):
+            raise RuntimeError("this is the product build of libmrca_env.so: ablation switches exist only in the "
+                               "profiling build (csrc/build.sh --profiling, MRCA_ENV_LIB=...)")
         _lib.check(self.lib.mrca_set_debug_flags(self._h, int(flags)), "mrca_set_debug_flags")
 
     def read_timing(self):

@@ -125,11 +125,25 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
             nb.insert(nb.end(), {xj, yj, sj, cj});
             nbi.insert(nbi.end(), {lo, hi});
         }
+        // the kernel's thread t marches beams t and t + B/2 in lock step (grid_march_skip_n<2>)
+        std::vector<float> marched(e->B);
+        const MarchOrigin org = march_origin(dist, g, x, y);
+        for (int b = 0; b < e->B / 2; ++b) {
+            float ddx[2], ddy[2], out[2];
+            for (int k = 0; k < 2; ++k) {
+                const float bc = e->beam_cos[b + k * (e->B / 2)], bs = e->beam_sin[b + k * (e->B / 2)];
+                ddx[k] = c * bc - s * bs;
+                ddy[k] = s * bc + c * bs;
+            }
+            grid_march_skip_n<2>(dist, g, org, ddx, ddy, kRangeMax, out);
+            marched[b] = out[0];
+            marched[b + e->B / 2] = out[1];
+        }
         for (int b = 0; b < e->B; ++b) {
             const float bc = e->beam_cos[b], bs = e->beam_sin[b];
             const float dx = c * bc - s * bs;
             const float dy = s * bc + c * bs;
-            float rng = grid_march_skip(dist, g, x, y, dx, dy, kRangeMax);
+            float rng = marched[b];
             for (size_t k = 0; k < nb.size(); k += 4) {
                 if (b < nbi[k / 2] || b > nbi[k / 2 + 1]) continue;
                 const float t = ray_box(x, y, dx, dy, nb[k], nb[k + 1], nb[k + 2], nb[k + 3]);
@@ -137,7 +151,7 @@ void emul_raycast(const EmulEnv* e, int only_fresh) {
             }
             rng = rng < kRangeMax ? rng : kRangeMax;
             e->scan[(size_t)n * e->B + b] = rng;
-            const float o = rng / 6.0f - 0.5f;
+            const float o = norm_obs(rng);
             float* ob = e->obs + (size_t)n * e->F * e->B + b;
             if (fresh) {
                 for (int f = 0; f < e->F; ++f) ob[f * e->B] = o;
@@ -286,6 +300,30 @@ void emul_march(const EmulEnv* e, int n, const float* ox, const float* oy, const
     }
 }
 
+// the lock-step K-ray march: ray i is marched together with K-1 other rays from the SAME origin and range whose
+// directions are taken from rays i+1.. (so partners finish at different iterations); out[i] = result of ray i
+void emul_march_lockstep(const EmulEnv* e, int n, int K, const float* ox, const float* oy, const float* dx,
+                         const float* dy, const float* tmax, float* out) {
+    const GridGeom g = geom(e);
+    const CachedField& cf = field_of(e);
+    const FreeRectField dist{cf.f.data(), e->width, e->height, cf.pitch};
+    for (int i = 0; i < n; ++i) {
+        const MarchOrigin org = march_origin(dist, g, ox[i], oy[i]);
+        if (K == 2) {
+            const float ddx[2] = {dx[i], dx[(i + 1) % n]}, ddy[2] = {dy[i], dy[(i + 1) % n]};
+            float o[2];
+            grid_march_skip_n<2>(dist, g, org, ddx, ddy, tmax[i], o);
+            out[i] = o[0];
+        } else {
+            const float ddx[4] = {dx[(i + 3) % n], dx[(i + 1) % n], dx[i], dx[(i + 2) % n]};
+            const float ddy[4] = {dy[(i + 3) % n], dy[(i + 1) % n], dy[i], dy[(i + 2) % n]};
+            float o[4];
+            grid_march_skip_n<4>(dist, g, org, ddx, ddy, tmax[i], o);
+            out[i] = o[2];
+        }
+    }
+}
+
 // beam-interval culling: for n neighbour centres (robot frame), the interval the product would test
 void emul_beam_interval(int n, const float* lx, const float* ly, int beams, int* lo, int* hi) {
     for (int i = 0; i < n; ++i) beam_interval(lx[i], ly[i], beams, &lo[i], &hi[i]);
@@ -298,6 +336,10 @@ void emul_ray_box(int n, const float* ox, const float* oy, const float* dx, cons
 
 int emul_obb(float xi, float yi, float si, float ci, float xj, float yj, float sj, float cj) {
     return obb_overlap(xi, yi, si, ci, xj, yj, sj, cj) ? 1 : 0;
+}
+
+void emul_norm_obs(const float* x, int n, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = norm_obs(x[i]);
 }
 
 void emul_sincos(const float* th, int n, float* s, float* c) {

@@ -14,6 +14,7 @@ from util import S
 def _declared_symbols():
     hdr = open(os.path.join(U.ROOT, "include", "mrca_env.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"#ifdef MRCA_PROFILING.*?#endif", "", hdr, flags=re.S)     # not part of the product ABI
     return sorted(set(re.findall(r"\b(mrca_[a-z_]+)\s*\(", hdr)))
 
 
@@ -24,6 +25,8 @@ def test_header_symbols_exported(built_lib):
         assert hasattr(built_lib, n), f"libmrca_env.so does not export {n}"
     from mrca import _lib
     assert sorted(_lib.EXPORTS) == names
+    # the ablation switches live in the profiling build only (csrc/build.sh --profiling)
+    assert not hasattr(built_lib, "mrca_set_debug_flags")
 
 
 def test_abi_version(built_lib):

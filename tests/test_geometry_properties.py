@@ -127,3 +127,22 @@ def test_obb_overlap_symmetric_and_agrees_with_sampling():
             assert a == 1          # a common point proves overlap; SAT must agree
         n_ov += a
     assert 500 < n_ov < 2900
+
+
+def test_norm_obs_equals_ieee_division():
+    """mrca_device.h:norm_obs (multiply + two FMAs) == RN(RN(x / 6) - 0.5) for floats x in [0, 6]: every 7th bit
+    pattern plus the neighbourhoods of 0, of the subnormal boundary, of powers of two and of 6 (the full sweep is
+    tools/check_div6.c: 0 mismatches over all 1 086 324 737 values)."""
+    import ctypes as C
+    lib = U.emul_lib()
+    top = np.float32(6.0).view(np.uint32)
+    u = np.concatenate([np.arange(0, int(top) + 1, 7, dtype=np.uint32), np.arange(0, 70000, dtype=np.uint32),
+                        np.arange(0x007F0000, 0x00810000, dtype=np.uint32),
+                        np.arange(int(top) - 70000, int(top) + 1, dtype=np.uint32)] +
+                       [np.arange(e - 3000, e + 3000, dtype=np.uint32) for e in range(0x30000000, 0x40800001,
+                                                                                       0x00800000)])
+    x = u.view(np.float32)
+    got = np.empty_like(x)
+    lib.emul_norm_obs(C.c_void_p(x.ctypes.data), C.c_int(x.size), C.c_void_p(got.ctypes.data))
+    want = (x / np.float32(6.0) - np.float32(0.5)).astype(np.float32)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()

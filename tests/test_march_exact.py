@@ -47,6 +47,13 @@ def test_skipping_march_equals_plain_walk_and_oracle(name):
     same = a.view(np.uint32) == b.view(np.uint32)
     assert same.all(), f"{(~same).sum()} rays differ, first at {np.argwhere(~same)[0]}"
     assert 0.1 < (a < tmax).mean() < 0.9          # the sample has both hits and misses
+    # the lock-step K-ray march of the ray-cast kernel (grid_march_skip_n): each ray marched next to partners
+    # that finish earlier / later must still return exactly the single-ray result
+    for K in (2, 4):
+        c = np.empty(n, np.float32)
+        e.lib.emul_march_lockstep(C.byref(e._st), n, K, P(ox), P(oy), P(dx), P(dy), P(tmax), P(c))
+        same = c.view(np.uint32) == b.view(np.uint32)
+        assert same.all(), f"K={K}: {(~same).sum()} rays differ, first at {np.argwhere(~same)[0]}"
     m = 15000
     g = sc.grid
     gm = O.GridMap(g.bits, g.width, g.height, g.cell, g.x0, g.y0)

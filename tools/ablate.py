@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""GPU ablation of the ray-cast kernel (profiling only): times the tick with parts switched off via
-mrca_set_debug_flags so the cost split march / neighbours / writes is known."""
+"""GPU ablation of the kernels (profiling only): times the tick with parts switched off / launch shapes changed via
+mrca_set_debug_flags so the cost split march / neighbours / writes is known.  Uses the PROFILING build of the library
+(libmrca_env_prof.so, csrc/build.sh --profiling); the product library has no such switches."""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MRCA_ENV_LIB"] = os.path.join(ROOT, "rl-collision-avoidance_amd", "mrca", "libmrca_env_prof.so")
 sys.path.insert(0, os.path.join(ROOT, "rl-collision-avoidance_amd"))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
@@ -28,8 +30,11 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
     for flags, label in ((0, "full"), (1, "no neighbour tests"), (2, "no march"), (3, "no march, no neighbours"),
                          (8, "move: no outline test"),
                          (16, "move: no collision loop"), (32, "move: no resets"), (56, "move: none of the three"), 
-                         (256, "512 threads/robot (1 beam each)"), (512, "256 threads/robot (2 beams each)"),
-                         (768, "128 threads/robot (4 beams each)"), (512, "back to 256 threads"),
+                         (256, "512 marching threads (1 beam each) + prep wave"),
+                         (512, "256 marching threads (2 beams in lock step) + prep wave"),
+                         (768, "128 marching threads (4 beams in lock step) + prep wave"),
+                         (256 + 2048, "512 threads, wave 0 prepares"), (512 + 2048, "256 threads, wave 0 prepares"),
+                         (768 + 2048, "128 threads, wave 0 prepares"),
                          (0, "full again")):
         try:
             env.set_debug_flags(flags)
