@@ -35,16 +35,34 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_AGENT_STEP = 10332   # SURVEY 8(d) B_env_stack: 2140 + frame-stack shift (4096 read + 4096 write)
 
 
-def pmc_traffic(robots):
+def kernel_source_hash():
+    """sha256 (16 hex digits) of the device sources the ray-cast kernel is compiled from: PMC counters measured on
+    one version of the kernel say nothing about another."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mrca_kernels.hip", "mrca_device.h", "mrca_kernels.h"):
+        h.update(open(os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(robots, scenario):
     """HBM bytes per raycast_kernel launch from the committed rocprofv3 PMC passes (profiles/
     pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in KiB per launch at the profiled robot count,
-    FETCH doubled per MI355X_MICROARCH.md's gfx950 correction), scaled linearly to `robots`."""
+    FETCH doubled per MI355X_MICROARCH.md's gfx950 correction), scaled linearly to `robots`.
+    Refused (None + a note) when the counters were collected on another version of the kernel sources or on
+    another scenario: a stale figure must not ride along silently."""
     f = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(f):
-        return None
+        return None, "no profiles/pmc_traffic.json"
     d = json.load(open(f))
+    if d.get("kernel_src_sha16") != kernel_source_hash():
+        return None, (f"profiles/pmc_traffic.json was measured on kernel sources {d.get('kernel_src_sha16')}, this "
+                      f"build is {kernel_source_hash()}: re-run tools/pmc_profile.sh")
+    if d.get("scenario", "stage1") != scenario:
+        return None, f"profiles/pmc_traffic.json is for scenario {d.get('scenario', 'stage1')}"
     per_robot = (2.0 * d["fetch_kib"] + d["write_kib"]) * 1024.0 / d["robots"]
-    return per_robot * robots
+    return per_robot * robots, ("bytes/launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes on these "
+                                "kernel sources; 2*FETCH_SIZE + WRITE_SIZE)")
 
 
 def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
@@ -102,9 +120,11 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--mode", default="env", choices=["env", "rollout", "train"])
-    ap.add_argument("--worlds", type=int, default=128)
+    ap.add_argument("--worlds", type=int, default=None,
+                    help="worlds per GPU (default: 128 at 1 GPU = configs[1]; 187 Stage-2 worlds at N > 1 = configs[3])")
     ap.add_argument("--robots-per-world", type=int, default=32)
-    ap.add_argument("--scenario", default="stage1", choices=["stage1", "stage2"])
+    ap.add_argument("--scenario", default=None, choices=["stage1", "stage2"],
+                    help="default: stage1 at 1 GPU (BASELINE configs[1]), stage2 at N > 1 (configs[3]: 8192+ robots/GPU)")
     ap.add_argument("--policy-dtype", default="f32", choices=["f32", "bf16"],
                     help="rollout/train: dtype of the policy INFERENCE pass (update stays fp32); f32 = the reference's")
     ap.add_argument("--update-dtype", default="f32", choices=["f32", "bf16"],
@@ -116,6 +136,12 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BASELINE.json: configs[1] (4096 robots, Stage-1 rink) is the single-GPU workload; configs[3] (65 536 robots over
+    # 8 GPUs = 8192+ per GPU on the Stage-2 map, ppo_stage2.py:32 / worlds/stage2.world) is the multi-GPU one
+    if args.scenario is None:
+        args.scenario = "stage1" if world_size == 1 else "stage2"
+    if args.worlds is None:
+        args.worlds = 128 if args.scenario == "stage1" else 187
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda is unavailable and there is no CPU path")
     # test hooks (tests/test_gpu_bench_multirank.py): several ranks on ONE GPU over gloo, to exercise the
@@ -204,8 +230,36 @@ def main():
                                         "note": "env + fp32 CNNPolicy inference per tick, 100 ticks after 10 warm-up "
                                                 "ticks; not part of `value`"}
 
+    # multi-GPU side figure: a few PPO updates with the flat-bucket gradient all-reduce on the measured path
+    # (the env tick itself needs no collective, so `value` alone would never touch RCCL)
+    if world_size > 1 and args.mode == "env" and not args.no_extra:
+        from mrca import ppo as _ppo
+        from mrca.trainer import HParams, Stage1Trainer
+        hp = HParams(horizon=16, batch_size=16384, epoch=1)
+        tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0, stage2=False)
+        tr.started = True
+        tr.run(hp.horizon)                       # one warm-up update (MIOpen / allocator / RCCL set-up)
+        barrier()
+        tt0 = time.perf_counter()
+        n_upd = 2
+        tr.run(n_upd * hp.horizon)
+        barrier()
+        dt_tr = time.perf_counter() - tt0
+        extra["train_side_figure"] = {
+            "value": N * world_size * n_upd * hp.horizon / dt_tr, "unit": "agent-steps/s",
+            "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
+                           "optimizer_steps": len(tr.loss_log) - len(tr.loss_log) // (n_upd + 1)},
+            "note": "env + fp32 policy + GAE + PPO update (horizon 16, one epoch, minibatch 16384 per rank), every "
+                    "optimiser step all-reduces the flat gradient bucket; not part of `value`"}
+
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    per_rank = None
     if dist is not None:
+        mine = torch.tensor([N * args.steps / elapsed], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(gathered, mine)
+        per_rank = [float(x.item()) for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     total_robots = N * world_size
@@ -213,6 +267,7 @@ def main():
 
     if rank == 0:
         ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
+        traffic, traffic_note = pmc_traffic(N, args.scenario)
         achieved = BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
         out = {
             "metric": "agent-steps/s (N robots x 512-beam lidar)" if args.mode == "env" else
@@ -227,9 +282,8 @@ def main():
                        "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
                        "ppo_update_dtype": args.update_dtype if args.mode == "train" else None},
             "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": pmc_traffic(N),
-                         "traffic_note": "bytes/launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes; "
-                                         "2*FETCH_SIZE + WRITE_SIZE)",
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "bytes_per_agent_step": BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
                          "launches_timed": launches,
@@ -238,6 +292,9 @@ def main():
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(args.scenario, args.worlds, args.robots_per_world)
             out["cpu_baseline"]["reference_structural_cap"] = "240 agent-steps/s (24 robots x 10 Hz, stageros.cpp:819-828)"
+        if per_rank is not None:
+            out["per_rank_agent_steps_per_s"] = per_rank      # each rank's own rate on the same per-GPU workload
+            out["collective_backend"] = dist.get_backend()
         out.update(extra)
         print(json.dumps(out))
     if dist is not None:

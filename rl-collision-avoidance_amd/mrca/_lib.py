@@ -4,6 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+PROFILING_LIB_PATH = os.path.join(_HERE, "libmrca_env_prof.so")
 # MRCA_ENV_LIB selects another build of the SAME library (tools/ablate.py points it at the profiling build
 # libmrca_env_prof.so); whichever it is, it must exist -- there is no fallback
 LIB_PATH = os.environ.get("MRCA_ENV_LIB") or os.path.join(_HERE, "libmrca_env.so")
@@ -35,20 +36,21 @@ class MrcaConfig(C.Structure):
     ]
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load the in-tree HIP library (built by ``__graft_entry__.build()`` / csrc/build.sh)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load the in-tree HIP library (built by ``__graft_entry__.build()`` / csrc/build.sh).  ``path`` selects
+    another build of the same ABI (the profiling build); each is loaded once per process."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+            f"{path} is missing: the MI355X HIP library has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or csrc/build.sh). "
             "There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.mrca_abi_version.restype = C.c_int
     lib.mrca_last_error.restype = C.c_char_p
     lib.mrca_arena_bytes.argtypes = [C.POINTER(MrcaConfig), C.POINTER(C.c_size_t)]
@@ -65,12 +67,13 @@ def load():
         lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]
     lib.mrca_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.mrca_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"libmrca_env.so ABI {lib.mrca_abi_version()} != binding ABI {ABI_VERSION}")
-    _lib = lib
+        raise RuntimeError(f"{path} ABI {lib.mrca_abi_version()} != binding ABI {ABI_VERSION}")
+    _libs[path] = lib
     return lib
 
 
 def check(rc, what):
     if rc != 0:
-        msg = load().mrca_last_error().decode("utf-8", "replace")
+        msg = "; ".join(lib.mrca_last_error().decode("utf-8", "replace") for lib in _libs.values()
+                        if lib.mrca_last_error())
         raise RuntimeError(f"{what} failed ({rc}): {msg}")

@@ -75,7 +75,7 @@ def circle_test(env, policy_fn, max_ticks=1200):
         last_terminal = env.done.bool().clone()
         path += torch.where(pending, env.speed_gt[:, 0] * 0.1, torch.zeros_like(path))
         ticks_to_goal += pending.float()
-        if bool((env.first_result != 0).all()):
+        if k % 25 == 24 and bool((env.first_result != 0).all()):    # one host round trip every 25 ticks
             break
     fr = env.first_result
     reach = fr == 1

@@ -10,6 +10,18 @@ import torch.nn.functional as F
 from . import vec_env
 
 
+_bound_cache = {}
+
+
+def _bounds(action_bound, device, dtype):
+    """The clip bounds as device tensors, uploaded once (not one host-to-device copy per tick)."""
+    key = (tuple(map(tuple, action_bound)), str(device), dtype)
+    if key not in _bound_cache:
+        _bound_cache[key] = (torch.tensor(action_bound[0], device=device, dtype=dtype),
+                             torch.tensor(action_bound[1], device=device, dtype=dtype))
+    return _bound_cache[key]
+
+
 # ---------------------------------------------------------------------------------------------
 def generate_action(policy, obs, goal, speed, action_bound, generator=None, autocast_dtype=None):
     """model/ppo.py:57-82: sample a ~ N(mean, std); the UNclipped action and its logprob are what
@@ -27,8 +39,7 @@ def generate_action(policy, obs, goal, speed, action_bound, generator=None, auto
             logprob = gaussian_logprob(a, mean, logstd)
         else:
             v, a, logprob, _mean = policy(obs, goal, speed, generator=generator)
-        lo = torch.as_tensor(action_bound[0], device=a.device, dtype=a.dtype)
-        hi = torch.as_tensor(action_bound[1], device=a.device, dtype=a.dtype)
+        lo, hi = _bounds(action_bound, a.device, a.dtype)
         scaled = torch.minimum(torch.maximum(a, lo), hi)
     return v, a, logprob, scaled
 
@@ -37,8 +48,7 @@ def generate_action_no_sampling(policy, obs, goal, speed, action_bound):
     """model/ppo.py:84-107: deterministic mean action (circle_test.py:58-59)."""
     with torch.no_grad():
         mean, _v = policy.mean_value(obs, goal, speed)
-        lo = torch.as_tensor(action_bound[0], device=mean.device, dtype=mean.dtype)
-        hi = torch.as_tensor(action_bound[1], device=mean.device, dtype=mean.dtype)
+        lo, hi = _bounds(action_bound, mean.device, mean.dtype)
         scaled = torch.minimum(torch.maximum(mean, lo), hi)
     return mean, scaled
 

@@ -162,17 +162,17 @@ def main(argv=None):
         t0 = time.perf_counter()
         ep_done = torch.zeros(3, device=env.device)
         ep_reward = torch.zeros(env.N, device=env.device)
-        finished = []
+        last_return = torch.full((env.N,), float("nan"), device=env.device)   # return of each robot's last episode
         for _t in range(hp.horizon):
             was_live = env.live.bool().clone()   # stage 2: a finished robot keeps done=1 until its group restarts
             tr.tick()
             ep_reward += torch.where(was_live, env.reward, torch.zeros_like(env.reward))
             d = env.done.bool() & was_live       # count each terminal event once
-            if bool(d.any()):
-                finished.append(ep_reward[d].clone())
-                ep_reward[d] = 0
-                r = env.result[d]
-                ep_done += torch.stack([(r == 1).sum(), (r == 2).sum(), (r == 3).sum()]).float()
+            # no host round trip inside the horizon: the statistics stay on the device until the update is over
+            last_return = torch.where(d, ep_reward, last_return)
+            ep_reward = torch.where(d, torch.zeros_like(ep_reward), ep_reward)
+            r = env.result
+            ep_done += torch.stack([(d & (r == 1)).sum(), (d & (r == 2)).sum(), (d & (r == 3)).sum()]).float()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -181,9 +181,8 @@ def main(argv=None):
         for row in tr.loss_log[n_logged:]:
             ppo_log.info("{}, {}, {}".format(*[float(x) for x in row]))
         n_logged = len(tr.loss_log)
-        for rew in finished[-1:]:
-            for v in rew[:8].tolist():
-                cal.info(v)
+        for v in last_return[~torch.isnan(last_return)][:8].tolist():
+            cal.info(v)
         kl = "" if tr.last_kl is None else "  kl %.4f  lr %.2e" % (tr.last_kl, tr.optimizer.param_groups[0]["lr"])
         out.info("update %05d  %.0f agent-steps/s  episodes %d  reach %.3f  crash %.3f  timeout %.3f%s",
                  tr.global_update, env.N * world_size * hp.horizon / dt, int(tot), float(ep_done[0]) / tot,

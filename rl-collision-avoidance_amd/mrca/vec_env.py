@@ -19,10 +19,10 @@ RESULT_NAMES = {0: 0, 1: "Reach Goal", 2: "Crashed", 3: "Time out"}  # stage_wor
 
 
 class VecStageWorld:
-    def __init__(self, scenario: Scenario, device=None):
+    def __init__(self, scenario: Scenario, device=None, lib_path=None):
         if not torch.cuda.is_available():
             raise RuntimeError("VecStageWorld needs an MI355X (torch.cuda is unavailable); there is no CPU path")
-        self.lib = _lib.load()
+        self.lib = _lib.load(lib_path)      # lib_path: another build of the same library (the profiling build)
         self.scenario = sc = scenario
         if device is None:
             index = torch.cuda.current_device()

@@ -28,7 +28,7 @@ def test_bench_two_ranks_same_gpu():
     env = dict(os.environ, MRCA_BENCH_SAME_DEVICE="1", MRCA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_port()), os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "50",
-           "--warmup", "10", "--worlds", "16", "--no-cpu-baseline"]
+           "--warmup", "10", "--scenario", "stage1", "--worlds", "16", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -38,6 +38,41 @@ def test_bench_two_ranks_same_gpu():
     assert j["config"]["robots_per_gpu"] == 16 * 32
     # whole-job aggregate: robots on all ranks x steps / max-rank time
     assert abs(j["value"] - 2 * 16 * 32 * 50 / (j["ms_per_step"] * 1e-3 * 50)) / j["value"] < 1e-6
+    assert len(j["per_rank_agent_steps_per_s"]) == 2 and j["collective_backend"] == "gloo"
+    # the learner's collectives are on a measured path too: PPO updates with the flat gradient all-reduce
+    tr = j["train_side_figure"]
+    assert tr["collective"]["world_size"] == 2 and tr["collective"]["gradient_bucket_bytes"] == 2172101 * 4
+    assert tr["collective"]["optimizer_steps"] >= 2 and tr["value"] > 0
+
+
+def test_bench_multi_gpu_default_workload_is_configs3():
+    """BASELINE configs[3]: N > 1 defaults to the Stage-2 map with 187 worlds x 44 robots = 8228 robots per GPU."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MRCA_BENCH_SAME_DEVICE="1", MRCA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+           "--warmup", "5", "--no-cpu-baseline", "--no-extra"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["config"]["robots_per_gpu"] == 187 * 44 and j["config"]["workload"].startswith("stage2: 187 worlds")
+
+
+def test_bench_two_ranks_over_rccl():
+    """One rank per GPU over RCCL (backend "nccl"): needs >= 2 visible devices, skipped on a 1-GPU box."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "50",
+           "--warmup", "10", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["collective_backend"] == "nccl"
+    assert j["train_side_figure"]["collective"]["backend"] == "nccl"
+    assert j["train_side_figure"]["collective"]["world_size"] == 2
 
 
 def test_bench_single_rank_json_contract():

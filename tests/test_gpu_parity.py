@@ -4,9 +4,11 @@
 Bars
   * fp32 mode of the oracle (same operation order): BIT-EXACT on every field, flags included.
   * fp64 mode of the oracle (clean maths), one tick from identical state: pose / goal / reward /
-    local goal within 1e-5 (north-star tolerance); scan within 1e-5 on >= 99 % of beams and within
-    2e-3 everywhere (a beam that grazes a cell corner enters a different cell in fp32 and fp64;
-    the fraction is asserted and reported), flags equal on >= 99.5 % of robots.
+    local goal within 1e-5 (north-star tolerance); scan within 1e-5 on >= 99.9 % of beams.  Ranges are
+    QUANTISED to the cell grid (entry distance of the first occupied cell, like Stage's raster): a beam that
+    grazes a cell corner enters a different first cell in fp32 than in fp64, so the remaining beams (measured
+    2.7e-4 of them) differ by up to the extent of one cell along the ray -- bounded below by 1.5 cells
+    (0.075 m); a robot-robot slab hit is continuous and stays within 1e-5.  Flags equal on >= 99.5 % of robots.
   * full BASELINE sizes: the oracle checks a slice of worlds bit-exactly (worlds are independent)
     and the whole batch is checked through size-independent properties.
 """
@@ -151,8 +153,8 @@ def test_fp64_oracle_one_tick_from_identical_state(hip):
         worst_scan = max(worst_scan, float(ds.max()))
     print(f"fp64 check: beams off by >1e-5: {bad_beams}/{n_beams} = {bad_beams / n_beams:.2e}; worst {worst_scan:.2e}; "
           f"flag mismatches {flag_mismatch}/{n_rob}")
-    assert bad_beams / n_beams <= 0.01
-    assert worst_scan <= 2e-3 or bad_beams / n_beams <= 1e-3
+    assert bad_beams / n_beams <= 1e-3            # what is guaranteed: >= 99.9 % of beams within 1e-5 ...
+    assert worst_scan <= 1.5 * sc.grid.cell       # ... and the grazing ones within one cell's extent along the ray
     assert flag_mismatch / n_rob <= 0.005
     env.close()
 
@@ -259,13 +261,17 @@ def test_full_batch_bit_exact_vs_c_oracle(hip, name, worlds, R, steps):
     env.close()
 
 
-@pytest.mark.parametrize("knob,label", [(256, "1 beam per thread"), (512, "2 beams per thread"),
-                                        (768, "4 beams per thread")])
+@pytest.mark.parametrize("knob,label", [(256, "1 beam per thread"), (512, "2 beams per thread in lock step"),
+                                        (768, "4 beams per thread in lock step"),
+                                        (256 + 2048, "1 beam per thread, wave 0 prepares"),
+                                        (512 + 2048, "2 beams per thread, wave 0 prepares"),
+                                        (768 + 2048, "4 beams per thread, wave 0 prepares")])
 def test_raycast_launch_shapes_bit_exact(hip, knob, label):
-    """The threads-per-robot tuning knob only changes how beams are dealt to threads: every launch shape
-    must match the oracle bit-for-bit."""
+    """The launch-shape knobs of the PROFILING build (beams per marching thread, with / without the dedicated
+    preparation wave) only change how the work is dealt to threads: every shape must match the oracle bit-for-bit."""
+    from mrca import _lib
     for sc in (S.stage1(num_worlds=4, robots_per_world=16, seed=5), S.stage2(num_worlds=1, seed=5)):
-        env = hip.VecStageWorld(sc)
+        env = hip.VecStageWorld(sc, lib_path=_lib.PROFILING_LIB_PATH)
         env.set_debug_flags(knob)
         ora = U.COracleEnv(sc)
         env.reset()
@@ -279,3 +285,10 @@ def test_raycast_launch_shapes_bit_exact(hip, knob, label):
                 torch.cuda.synchronize()
                 U.assert_state_equal(U.HostView(env), ora, what=f"{label} {sc.name} step {k}")
         env.close()
+
+
+def test_product_library_has_no_ablation_switches(hip):
+    env = hip.VecStageWorld(S.stage1(num_worlds=1, robots_per_world=4))
+    with pytest.raises(RuntimeError, match="profiling build"):
+        env.set_debug_flags(1)
+    env.close()

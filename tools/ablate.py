@@ -6,7 +6,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["MRCA_ENV_LIB"] = os.path.join(ROOT, "rl-collision-avoidance_amd", "mrca", "libmrca_env_prof.so")
+
 sys.path.insert(0, os.path.join(ROOT, "rl-collision-avoidance_amd"))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
@@ -15,11 +15,12 @@ import __graft_entry__ as G  # noqa: E402
 
 G.build()
 from mrca import scenario as S  # noqa: E402
+from mrca import _lib  # noqa: E402
 from mrca.vec_env import VecStageWorld  # noqa: E402
 
 for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32, seed=1)),
                  ("stage2 187x44", S.stage2(num_worlds=187, seed=1))):
-    env = VecStageWorld(sc)
+    env = VecStageWorld(sc, lib_path=_lib.PROFILING_LIB_PATH)
     N = sc.num_robots
     gen = torch.Generator(device=env.device).manual_seed(1)
     pool = [torch.stack([torch.rand(N, generator=gen, device=env.device),
