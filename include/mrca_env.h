@@ -42,7 +42,7 @@ enum mrca_status {
     MRCA_ERR_INVALID = -1,     /* bad argument / config */
     MRCA_ERR_HIP = -2,         /* a HIP runtime call failed */
     MRCA_ERR_NOMEM = -3,       /* arena too small / allocation failed */
-    MRCA_ERR_UNSUPPORTED = -4  /* e.g. robots_per_world > 64 */
+    MRCA_ERR_UNSUPPORTED = -4  /* e.g. robots_per_world > 64 together with group-synchronous episodes */
 };
 
 /* episode structure */
@@ -89,7 +89,7 @@ typedef struct mrca_config {
     int32_t abi_version;       /* MRCA_ABI_VERSION */
     int32_t device;            /* HIP device ordinal */
     int32_t num_worlds;
-    int32_t robots_per_world;  /* 1..64 */
+    int32_t robots_per_world;  /* 1..64: one wavefront per world; > 64: per-robot threads + per-tick broad phase */
     int32_t beams;             /* 512 (stage1.world:14); 64..1024, multiple of 64 */
     int32_t frames;            /* 3 (LASER_HIST, ppo_stage1.py:24); 1..8 */
     /* occupancy grid shared by all worlds; cells outside it are free */
@@ -133,6 +133,13 @@ int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, c
  *   get_reward_and_terminate(step), get_laser_observation, get_local_goal, get_self_speed.
  * actions_dev f32[N,2] = (v, omega) already clipped by the caller (ppo_stage1.py:170, model/ppo.py:75). */
 int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
+
+/* The same tick for ONE world sharded over several GPUs (a single circle of 50 000 robots): every
+ * rank holds the whole world, feeds the commands of ALL robots (one all-gather of act[N,2] per tick -- the exchange
+ * step) and advances all of them -- the ordered collision pass needs every provisional pose and costs ~1 % of a
+ * tick, and identical arithmetic keeps the replicas bit-identical -- but casts the lidar only for its own robots
+ * [first_robot, first_robot + num_robots): scan / obs / local_goal of the other robots are left untouched. */
+int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream);
 
 /* Zero-copy access to a field: device pointer, byte offset inside the arena and byte size. */
 int mrca_get_field(mrca_env* env, int field, void** ptr_dev_out, size_t* offset_out, size_t* bytes_out);

@@ -44,6 +44,9 @@ RESULT_NONE, RESULT_REACH, RESULT_CRASH, RESULT_TIMEOUT = 0, 1, 2, 3
 
 RESET_TABLE, RESET_DISC, RESET_REGION = 0, 1, 2      # per-robot reset rule
 AUTO_NONE, AUTO_ROBOT, AUTO_GROUP = 0, 1, 2           # episode structure
+BIG_WORLD = 64              # worlds with more robots use the distance-culled passes (_collide_big / _raycast_big)
+CULL_COLLIDE = 0.6          # > 2 x circumradius 0.2907: rectangles further apart cannot overlap
+CULL_LIDAR = 6.3            # > 6 m + circumradius: robots further away cannot return a range below 6 m
 MAX_TRIES_POSE = 64
 MAX_TRIES_GOAL = 256
 STREAM_POSE, STREAM_GOAL = 0, 1
@@ -494,7 +497,9 @@ class OracleEnv:
         cth = th.copy()
         moved = np.zeros(N, bool)
         base = np.arange(cfg.W) * R
-        for i in range(R):
+        if R > BIG_WORLD:
+            self._collide_big(nx, ny, nth, ns, nc, moving, shit, cx, cy, cth, cs, cc, moved)
+        for i in range(R if R <= BIG_WORLD else 0):
             ii = base + i
             hit = shit[ii].copy()
             for j in range(R):
@@ -567,12 +572,75 @@ class OracleEnv:
         self._observe(fresh)
         return self.obs, self.local_goal, self.speed, self.reward, self.done, self.result
 
+    # ---------------------------------------------------------------- worlds with more than 64 robots
+    def _collide_big(self, nx, ny, nth, ns, nc, moving, shit, cx, cy, cth, cs, cc, moved):
+        """The SAME robot-order pass for worlds too large for the all-pairs loop (a single 500 / 50 000-robot
+        circle).  Only pairs are skipped that cannot overlap: two 0.44 x 0.38 rectangles whose
+        centres are further apart than 2 x circumradius (0.5815 m) are separated on every axis, so robot i only
+        needs the robots whose OLD or PROVISIONAL centre lies within CULL_COLLIDE = 0.6 m of its provisional
+        centre (a robot is at one of the two when i is tested).  Candidates come from two k-d trees (float64
+        copies of the fp32 coordinates: the cull itself is exact arithmetic on the same numbers); robots without
+        any candidate commit straight away, the others are walked in index order exactly like the loop above."""
+        from scipy.spatial import cKDTree
+        f, cfg = self.f, self.cfg
+        R = cfg.R
+        for w in range(cfg.W):
+            sl = slice(w * R, (w + 1) * R)
+            old = np.stack([cx[sl], cy[sl]], 1).astype(np.float64)
+            new = np.stack([nx[sl], ny[sl]], 1).astype(np.float64)
+            t_old, t_new = cKDTree(old), cKDTree(new)
+            near_old = t_old.query_ball_point(new, CULL_COLLIDE)
+            near_new = t_new.query_ball_point(new, CULL_COLLIDE)
+            for i in range(R):
+                n = w * R + i
+                if not moving[n]:
+                    continue
+                hit = bool(shit[n])
+                cand = sorted(set(near_old[i]) | set(near_new[i]))
+                for j in cand:
+                    if j == i or hit:
+                        continue
+                    m = w * R + j
+                    hit = bool(obb_overlap(nx[n], ny[n], ns[n], nc[n], cx[m], cy[m], cs[m], cc[m], f))
+                if not hit:
+                    cx[n], cy[n], cth[n], cs[n], cc[n] = nx[n], ny[n], nth[n], ns[n], nc[n]
+                    moved[n] = True
+                self.crashed[n] = 1 if hit else 0
+
+    def _raycast_big(self):
+        """Ray cast for worlds with more than 64 robots: a robot further than 6 m + circumradius (CULL_LIDAR =
+        6.3 m) from the sensor cannot return a range below 6 m, so only the others are slab-tested."""
+        from scipy.spatial import cKDTree
+        f, cfg = self.f, self.cfg
+        N, R, B = self.N, cfg.R, cfg.beams
+        x, y, th = self.pose[:, 0], self.pose[:, 1], self.pose[:, 2]
+        s, c = sincos(th, f)
+        dx = c[:, None] * self.bcos[None, :] - s[:, None] * self.bsin[None, :]
+        dy = s[:, None] * self.bcos[None, :] + c[:, None] * self.bsin[None, :]
+        ox = np.broadcast_to(x[:, None], (N, B))
+        oy = np.broadcast_to(y[:, None], (N, B))
+        rng = grid_march(cfg.grid, ox, oy, dx, dy, f(RANGE_MAX), f)
+        for w in range(cfg.W):
+            sl = slice(w * R, (w + 1) * R)
+            pts = np.stack([x[sl], y[sl]], 1).astype(np.float64)
+            tree = cKDTree(pts)
+            pairs = tree.query_pairs(CULL_LIDAR, output_type="ndarray")
+            if len(pairs) == 0:
+                continue
+            a = np.concatenate([pairs[:, 0], pairs[:, 1]]) + w * R      # sensor
+            b = np.concatenate([pairs[:, 1], pairs[:, 0]]) + w * R      # target
+            t = ray_box(x[a, None], y[a, None], dx[a], dy[a], x[b, None], y[b, None], s[b, None], c[b, None], f)
+            np.minimum.at(rng, a, t)
+        return np.minimum(rng, f(RANGE_MAX)).astype(f)
+
     # ---------------------------------------------------------------- sensing
     def raycast(self):
         """512 beams per robot against the grid and the other robots of the same world
         (stageros.cpp:479-516 geometry; libstage ray trace restated)."""
         f = self.f
         cfg = self.cfg
+        if cfg.R > BIG_WORLD:
+            return self._raycast_big()
         N, R, B = self.N, cfg.R, cfg.beams
         x, y, th = self.pose[:, 0], self.pose[:, 1], self.pose[:, 2]
         s, c = sincos(th, f)

@@ -40,6 +40,84 @@ typedef struct {
     int32_t first_world;
 } oc_env;
 
+
+/* ---- worlds with more than 64 robots (a single 500 / 50 000-robot circle) -------------------------
+ * The passes below are the SAME passes with a conservative distance cull in front, so that they finish: two
+ * 0.44 x 0.38 rectangles whose centres are more than 2 x circumradius (0.5815 m) apart are separated on every axis,
+ * and a robot further than 6 m + circumradius from a sensor cannot return a range below 6 m.  Candidates come from
+ * a spatial hash (cells of `cs` metres, chained buckets); every candidate is still put through the exact test. */
+#define OC_BIG_WORLD 64
+#define CULL_COLLIDE 0.6f
+#define CULL_LIDAR 6.3f
+typedef struct {
+    int32_t *head, *next, *cx, *cy;
+    int32_t mask;
+    float inv_cs;
+} oc_hash;
+
+static uint32_t oc_hash_of(int32_t ix, int32_t iy) {
+    return ((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u);
+}
+
+static oc_hash* oc_hash_new(int n, float cs) {
+    oc_hash* h = (oc_hash*)malloc(sizeof(oc_hash));
+    int m = 1;
+    while (m < 2 * n) m <<= 1;
+    h->mask = m - 1;
+    h->inv_cs = 1.0f / cs;
+    h->head = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
+    memset(h->head, 0xFF, sizeof(int32_t) * (size_t)m);
+    h->next = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    h->cx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    h->cy = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+    return h;
+}
+
+static void oc_hash_free(oc_hash* h) {
+    if (!h) return;
+    free(h->head); free(h->next); free(h->cx); free(h->cy); free(h);
+}
+
+static void oc_hash_insert(oc_hash* h, int id, float x, float y) {
+    const int32_t ix = (int32_t)floorf(x * h->inv_cs), iy = (int32_t)floorf(y * h->inv_cs);
+    const uint32_t b = oc_hash_of(ix, iy) & (uint32_t)h->mask;
+    h->cx[id] = ix; h->cy[id] = iy;
+    h->next[id] = h->head[b];
+    h->head[b] = id;
+}
+
+static void oc_hash_remove(oc_hash* h, int id) {
+    const uint32_t b = oc_hash_of(h->cx[id], h->cy[id]) & (uint32_t)h->mask;
+    int32_t* p = &h->head[b];
+    while (*p != id) p = &h->next[*p];
+    *p = h->next[id];
+}
+
+/* robots of n's world within `reach` of robot n (itself excluded): returns the count; with out != 0 also writes
+ * (x, y, sin, cos) per candidate */
+static void oc_sincos(float th, float* sn, float* cs);
+static int oc_hash_candidates(const oc_hash* h, const oc_env* e, int n, float reach, float* out, int fill) {
+    const float x = e->pose[n * 3], y = e->pose[n * 3 + 1];
+    const int world = n / e->R;
+    const int32_t ix = (int32_t)floorf(x * h->inv_cs), iy = (int32_t)floorf(y * h->inv_cs);
+    int cnt = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const uint32_t b = oc_hash_of(ix + dx, iy + dy) & (uint32_t)h->mask;
+            for (int32_t j = h->head[b]; j >= 0; j = h->next[j]) {
+                if (j == n || j / e->R != world || h->cx[j] != ix + dx || h->cy[j] != iy + dy) continue;
+                const float ddx = e->pose[j * 3] - x, ddy = e->pose[j * 3 + 1] - y;
+                if (!(ddx * ddx + ddy * ddy <= reach * reach)) continue;
+                if (fill) {
+                    out[cnt * 4] = e->pose[j * 3]; out[cnt * 4 + 1] = e->pose[j * 3 + 1];
+                    oc_sincos(e->pose[j * 3 + 2], &out[cnt * 4 + 2], &out[cnt * 4 + 3]);
+                }
+                ++cnt;
+            }
+        }
+    return cnt;
+}
+
 /* Cody-Waite by pi/2 + Cephes sinf/cosf polynomials, separately rounded * and + */
 static void oc_sincos(float th, float* sn, float* cs) {
     float k = rintf(th * 0.6366197723675814f);
@@ -207,6 +285,11 @@ static void oc_begin(const oc_env* e, int n, const float* po, const float* go) {
 /* 512 beams per robot against the grid and the other robots of its world (stageros.cpp:479-516),
  * scan/6 - 0.5 (stage_world1.py:140), frame deque (ppo_stage1.py:59-60,87-89), local goal (:155-160) */
 void oc_observe(const oc_env* e, int only_fresh) {
+    oc_hash* lidar_hash = 0;
+    if (e->R > OC_BIG_WORLD) {
+        lidar_hash = oc_hash_new(e->N, 6.5f);
+        for (int n = 0; n < e->N; ++n) oc_hash_insert(lidar_hash, n, e->pose[n * 3], e->pose[n * 3 + 1]);
+    }
 #pragma omp parallel for schedule(dynamic, 4)
     for (int n = 0; n < e->N; ++n) {
         const int fresh = e->fresh[n] != 0;
@@ -215,8 +298,13 @@ void oc_observe(const oc_env* e, int only_fresh) {
         const float x = e->pose[n * 3], y = e->pose[n * 3 + 1];
         float s, c;
         oc_sincos(e->pose[n * 3 + 2], &s, &c);
-        float nb[64 * 4];
+        float nb_small[64 * 4];
+        float* nb = nb_small;
         int cnt = 0;
+        if (lidar_hash) { /* big world: only the robots within CULL_LIDAR can return a range below 6 m */
+            nb = (float*)malloc((size_t)4 * sizeof(float) * (size_t)oc_hash_candidates(lidar_hash, e, n, CULL_LIDAR, 0, 0));
+            cnt = oc_hash_candidates(lidar_hash, e, n, CULL_LIDAR, nb, 1);
+        } else
         for (int j = 0; j < e->R; ++j) {
             if (j == local) continue;
             const int m = world * e->R + j;
@@ -245,7 +333,9 @@ void oc_observe(const oc_env* e, int only_fresh) {
         const float gx = e->goal[n * 2] - x, gy = e->goal[n * 2 + 1] - y;
         e->local_goal[n * 2] = gx * c + gy * s;
         e->local_goal[n * 2 + 1] = gy * c - gx * s;
+        if (lidar_hash) free(nb);
     }
+    oc_hash_free(lidar_hash);
 }
 
 void oc_reset(const oc_env* e, const uint8_t* mask, const float* poses, const float* goals) {
@@ -264,10 +354,15 @@ void oc_reset(const oc_env* e, const uint8_t* mask, const float* poses, const fl
  * (stage_world1.py:180-211) -> episode bookkeeping -> observe */
 void oc_step(const oc_env* e, const float* actions) {
     const int R = e->R;
+    const int big = R > OC_BIG_WORLD;
+    const int cap = big ? R : 64;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int world = 0; world < e->W; ++world) {
-        float x[64], y[64], th[64], s[64], c[64], nx[64], ny[64], nth[64], ns[64], nc[64], v[64], w[64];
-        char moving[64], shit[64], moved[64], lv[64], dn[64];
+        float* fbuf = (float*)malloc(sizeof(float) * 12 * (size_t)cap);
+        char* cbuf = (char*)malloc(5 * (size_t)cap);
+        float *x = fbuf, *y = x + cap, *th = y + cap, *s = th + cap, *c = s + cap, *nx = c + cap, *ny = nx + cap,
+              *nth = ny + cap, *ns = nth + cap, *nc = ns + cap, *v = nc + cap, *w = v + cap;
+        char *moving = cbuf, *shit = moving + cap, *moved = shit + cap, *lv = moved + cap, *dn = lv + cap;
         for (int l = 0; l < R; ++l) {
             const int n = world * R + l;
             x[l] = e->pose[n * 3]; y[l] = e->pose[n * 3 + 1]; th[l] = e->pose[n * 3 + 2];
@@ -286,14 +381,38 @@ void oc_step(const oc_env* e, const float* actions) {
             shit[l] = (char)oc_static_hit(e, nx[l], ny[l], ns[l], nc[l]);
             moved[l] = 0;
         }
+        oc_hash* ch = 0;
+        if (big) { /* current centres of this world's robots, kept up to date as robots commit their moves */
+            ch = oc_hash_new(R, 0.7f);
+            for (int l = 0; l < R; ++l) oc_hash_insert(ch, l, x[l], y[l]);
+        }
         for (int i = 0; i < R; ++i) {
             if (!moving[i]) continue;
             int hit = shit[i];
-            for (int j = 0; j < R && !hit; ++j)
-                if (j != i && oc_overlap(nx[i], ny[i], ns[i], nc[i], x[j], y[j], s[j], c[j])) hit = 1;
-            if (!hit) { x[i] = nx[i]; y[i] = ny[i]; th[i] = nth[i]; s[i] = ns[i]; c[i] = nc[i]; moved[i] = 1; }
+            if (big) {
+                const int32_t ix = (int32_t)floorf(nx[i] * ch->inv_cs), iy = (int32_t)floorf(ny[i] * ch->inv_cs);
+                for (int dy = -1; dy <= 1 && !hit; ++dy)
+                    for (int dx = -1; dx <= 1 && !hit; ++dx) {
+                        const uint32_t b = oc_hash_of(ix + dx, iy + dy) & (uint32_t)ch->mask;
+                        for (int32_t j = ch->head[b]; j >= 0 && !hit; j = ch->next[j]) {
+                            if (j == i) continue;
+                            const float ax = x[j] - nx[i], ay = y[j] - ny[i];
+                            if (!(ax * ax + ay * ay <= CULL_COLLIDE * CULL_COLLIDE)) continue;
+                            if (oc_overlap(nx[i], ny[i], ns[i], nc[i], x[j], y[j], s[j], c[j])) hit = 1;
+                        }
+                    }
+            } else {
+                for (int j = 0; j < R && !hit; ++j)
+                    if (j != i && oc_overlap(nx[i], ny[i], ns[i], nc[i], x[j], y[j], s[j], c[j])) hit = 1;
+            }
+            if (!hit) {
+                if (big) oc_hash_remove(ch, i);
+                x[i] = nx[i]; y[i] = ny[i]; th[i] = nth[i]; s[i] = ns[i]; c[i] = nc[i]; moved[i] = 1;
+                if (big) oc_hash_insert(ch, i, x[i], y[i]);
+            }
             e->crashed[world * R + i] = (uint8_t)hit;
         }
+        oc_hash_free(ch);
         for (int l = 0; l < R; ++l) {
             const int n = world * R + l;
             e->pose[n * 3] = x[l]; e->pose[n * 3 + 1] = y[l]; e->pose[n * 3 + 2] = th[l];
@@ -338,6 +457,8 @@ void oc_step(const oc_env* e, const float* actions) {
             const int n = world * R + l;
             if (e->fresh[n]) { e->episode[n] += 1; oc_begin(e, n, 0, 0); }
         }
+        free(fbuf);
+        free(cbuf);
     }
     oc_observe(e, 0);
 }

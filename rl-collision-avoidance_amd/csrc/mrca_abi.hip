@@ -41,6 +41,9 @@ struct Layout {
     size_t field_bytes[MRCA_F_COUNT];
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
     size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield, off_head;
+    // big worlds (robots_per_world > 64) only
+    size_t off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted;
+    int32_t bw_cmask, bw_lmask;
     size_t total;
 };
 
@@ -50,8 +53,13 @@ int validate(const mrca_config* c) {
         return fail(MRCA_ERR_INVALID, "abi_version %d != %d", c->abi_version, MRCA_ABI_VERSION);
     if (c->num_worlds < 1) return fail(MRCA_ERR_INVALID, "num_worlds must be >= 1");
     if (c->robots_per_world < 1) return fail(MRCA_ERR_INVALID, "robots_per_world must be >= 1");
-    if (c->robots_per_world > 64)
-        return fail(MRCA_ERR_UNSUPPORTED, "robots_per_world %d > 64 (one wavefront per world)", c->robots_per_world);
+    // more than 64 robots per world: the per-robot-thread path with a per-tick broad phase (bw_* kernels).  Its
+    // episodes restart per robot or not at all; group-synchronous episodes (Stage-2) need the one-wave-per-world path
+    if (c->robots_per_world > 64 && c->auto_reset == MRCA_AUTO_GROUP)
+        return fail(MRCA_ERR_UNSUPPORTED, "robots_per_world %d > 64 with group-synchronous episodes (auto_reset 2)",
+                    c->robots_per_world);
+    if ((int64_t)c->num_worlds * c->robots_per_world > (1 << 24))
+        return fail(MRCA_ERR_UNSUPPORTED, "more than 2^24 robots in one environment");
     if (c->beams < 64 || c->beams > 1024 || c->beams % 64)
         return fail(MRCA_ERR_INVALID, "beams %d must be a multiple of 64 in [64,1024]", c->beams);
     if (c->frames < 1 || c->frames > 8) return fail(MRCA_ERR_INVALID, "frames %d out of [1,8]", c->frames);
@@ -126,6 +134,21 @@ void make_layout(const mrca_config* c, Layout* L) {
                             sizeof(uint32_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->off_head = take(N * sizeof(float4));
+    L->bw_cmask = L->bw_lmask = 0;
+    if (c->robots_per_world > 64) {
+        size_t mc = 1, ml = 1;
+        while (mc < 4 * N) mc <<= 1;      // 2N entries (pose at tick start + provisional pose): load factor <= 0.5
+        while (ml < 2 * N) ml <<= 1;
+        L->bw_cmask = (int32_t)(mc - 1);
+        L->bw_lmask = (int32_t)(ml - 1);
+        L->off_bw_prov = take(N * 2 * sizeof(float4));
+        L->off_bw_state = take(N * 4);
+        L->off_bw_chead = take(mc * 4);
+        L->off_bw_cnext = take(2 * N * 4);
+        L->off_bw_lstart = take((ml + 2) * 4);
+        L->off_bw_lcount = take((ml + 1) * 4);
+        L->off_bw_lsorted = take(N * 4);
+    }
     L->total = off;
 }
 
@@ -340,6 +363,20 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.free_rect_pitch = free_rect_pitch;
     v.cellfield = reinterpret_cast<const uint8_t*>(a + L.off_cellfield);
     v.head = reinterpret_cast<float4*>(a + L.off_head);
+    v.big = R > 64 ? 1 : 0;
+    if (v.big) {
+        v.bw_prov = reinterpret_cast<float4*>(a + L.off_bw_prov);
+        v.bw_state = reinterpret_cast<int32_t*>(a + L.off_bw_state);
+        v.bw_chead = reinterpret_cast<int32_t*>(a + L.off_bw_chead);
+        v.bw_cnext = reinterpret_cast<int32_t*>(a + L.off_bw_cnext);
+        v.bw_lstart = reinterpret_cast<int32_t*>(a + L.off_bw_lstart);
+        v.bw_lcount = reinterpret_cast<int32_t*>(a + L.off_bw_lcount);
+        v.bw_lsorted = reinterpret_cast<int32_t*>(a + L.off_bw_lsorted);
+        v.bw_cmask = L.bw_cmask;
+        v.bw_lmask = L.bw_lmask;
+    }
+    v.ray_first = 0;
+    v.ray_count = (int32_t)N;
     v.g.x0 = cfg->map_x0;
     v.g.y0 = cfg->map_y0;
     v.g.cell = cfg->map_cell;
@@ -361,7 +398,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
     v.ray_prep_wave = 1;
     env->lds_bytes = mrca::ray_lds_bytes(v);
-    if (mrca::move_lds_bytes(v) > 64 * 1024)
+    if (!v.big && mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
                          (double)cfg->map_cell));
     if (env->lds_bytes > 160 * 1024)
@@ -397,28 +434,43 @@ int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, c
     DeviceGuard guard(env->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     mrca::launch_reset(env->view, mask_dev, poses_dev, goals_dev, s);
+    mrca::launch_lidar_grid(env->view, s);
     mrca::launch_raycast(env->view, /*only_fresh=*/1, s);
     HIP_TRY(hipGetLastError());
     return MRCA_OK;
 }
 
-int mrca_step(mrca_env* env, const float* actions_dev, void* stream) {
+static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int32_t count, void* stream) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     if (!actions_dev) return fail(MRCA_ERR_INVALID, "actions_dev is NULL");
+    if (first < 0 || count < 0 || first + count > env->view.N)
+        return fail(MRCA_ERR_INVALID, "ray-cast slice [%d, %d) outside [0, %d)", first, first + count, env->view.N);
     DeviceGuard guard(env->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool rec = env->timing > 0 && (env->step_count++ % env->timing) == 0 &&
                      env->ev_used + 3 <= (int)env->ev.size();
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 0], s));
     mrca::launch_move(env->view, actions_dev, s);
+    mrca::launch_lidar_grid(env->view, s);
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
-    mrca::launch_raycast(env->view, /*only_fresh=*/0, s);
+    mrca::EnvView v = env->view;
+    v.ray_first = first;
+    v.ray_count = count;
+    mrca::launch_raycast(v, /*only_fresh=*/0, s);
     if (rec) {
         HIP_TRY(hipEventRecord(env->ev[env->ev_used + 2], s));
         env->ev_used += 3;
     }
     HIP_TRY(hipGetLastError());
     return MRCA_OK;
+}
+
+int mrca_step(mrca_env* env, const float* actions_dev, void* stream) {
+    return step_impl(env, actions_dev, 0, env ? env->view.N : 0, stream);
+}
+
+int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream) {
+    return step_impl(env, actions_dev, first_robot, num_robots, stream);
 }
 
 int mrca_gae(const float* rewards_dev, const float* values_dev, const float* last_value_dev,

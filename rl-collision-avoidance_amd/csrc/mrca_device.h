@@ -539,6 +539,19 @@ MRCA_HD void beam_interval(float lx, float ly, int beams, int* lo, int* hi) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Spatial hashes of the big-world broad phase (worlds with more than 64 robots).  A point goes to the cell
+// (floor(x / cs), floor(y / cs)); a query looks at the 3 x 3 cells around its own, which contain every point
+// within `reach` of it as long as cs exceeds reach by the rounding slack of the fp32 quotient (cs = 0.7 m for the
+// 0.5824 m collision reach, 6.5 m for the 6.3 m lidar reach: 20 % / 3 % of margin against ~1e-7 relative error).
+constexpr float kCollideCell = 0.7f, kLidarCell = 6.5f;
+constexpr float kCollideReach2 = 0.3392f;   // (2 * 0.2907 + 0.001)^2, the move kernel's broad-phase radius
+constexpr float kLidarReach2 = 39.69f;      // (6 + 0.3)^2, the ray cast's neighbour cull
+MRCA_HD int hash_cell_coord(float x, float cs) { return (int)floorf(x * (1.0f / cs)); }
+MRCA_HD uint32_t hash_cell(int ix, int iy, int world) {
+    return ((uint32_t)ix * 73856093u) ^ ((uint32_t)iy * 19349663u) ^ ((uint32_t)world * 83492791u);
+}
+
+// ------------------------------------------------------------------------------------------
 // reset_pose / generate_goal_point
 MRCA_HD void region_xy(float ua, float ub, float* x, float* y) {  // stage_world2.py:252-257
     *x = 9.0f + 10.0f * ua;

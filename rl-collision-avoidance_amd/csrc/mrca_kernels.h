@@ -34,6 +34,19 @@ struct EnvView {
     // cos of the heading (deterministic sincos_det) and the free-rectangle field entry of the cell the robot
     // stands in (as float bits).  The ray cast starts from it instead of recomputing all three per wave.
     float4* head;       // [N] (sin, cos, bits(v0), 0)
+    // worlds with more than 64 robots ("big" worlds: one wavefront no longer holds a world): scratch of the
+    // per-tick broad phase, see the bw_* kernels.  All NULL / 0 otherwise.
+    int32_t big;            // 1: robots_per_world > 64
+    float4* bw_prov;        // [N][2] provisional pose of the tick: (nx, ny, nth, bits(flags)), (ns, nc, v, w)
+    int32_t* bw_state;      // [N] ordered collision pass: 0 undecided, 1 stays, 2 moved
+    int32_t* bw_chead;      // [bw_cmask+1] collision hash (0.7 m cells): bucket -> first entry, -1 = empty
+    int32_t* bw_cnext;      // [2N] entry e = 2*robot + (0: pose at tick start | 1: provisional pose) -> next entry
+    int32_t bw_cmask;
+    int32_t* bw_lstart;     // [bw_lmask+2] lidar hash (6.5 m cells) over the FINAL poses: bucket -> first slot
+    int32_t* bw_lcount;     // [bw_lmask+1] bucket population / fill cursor
+    int32_t* bw_lsorted;    // [N] robots ordered by bucket
+    int32_t bw_lmask;
+    int32_t ray_first, ray_count;   // the ray cast covers robots [ray_first, ray_first + ray_count) (mrca_step_slice)
     // scenario tables, per local index
     const int32_t* reset_mode;
     const int32_t* goal_mode;
@@ -76,6 +89,7 @@ size_t move_lds_bytes(const EnvView& e);
 void launch_move(const EnvView& e, const float* actions, hipStream_t s);
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s);
 void launch_head_init(const EnvView& e, hipStream_t s);
+void launch_lidar_grid(const EnvView& e, hipStream_t s);   // big worlds: hash of the current poses for the ray cast
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
                 float lam, int T, int N, float* targets, float* advs, hipStream_t s);

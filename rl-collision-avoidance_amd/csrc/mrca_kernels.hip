@@ -474,10 +474,10 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
 // no difference.)  What a chain of dependent lookups wants is more of them in flight: each thread marches its
 // K beams in lock step (grid_march_skip_n), so one wait covers K lookups.
-template <int K>
+template <int K, bool BIG>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int n = block_to_robot(blockIdx.x, e.N);
+    const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
     const int tid = threadIdx.x;
     // the fresh flag comes through the scalar cache (n is block-uniform; the aligned word holding the byte),
     // so nothing below queues behind it in the vector-memory counter
@@ -492,6 +492,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
     float* obuf = rbuf + e.B;                                         // [B] normalised ranges
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(obuf + e.B);   // [B] neighbours per beam
+    int* nb_more = nb_count + 1;                                      // big worlds: another chunk of neighbours follows
 
     const int T = e.B / K;                    // marching threads
     const bool extra = (int)blockDim.x > T;   // a dedicated preparation wave sits behind the marching ones
@@ -506,11 +507,11 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const float s = hd.x, c = hd.y;
     // the preparation wave requests "its" neighbour candidate in the same memory round trip
     const int pl = tid - prep_base;
-    const bool cand = is_prep && (pl < e.R) && (pl != local);
+    const bool cand = !BIG && is_prep && (pl < e.R) && (pl != local);
     const int jn = world * e.R + (cand ? pl : local);
     float xj = 0.0f, yj = 0.0f;
     float4 hj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (is_prep) {
+    if (!BIG && is_prep) {
         xj = e.pose[jn * 3 + 0];
         yj = e.pose[jn * 3 + 1];
         hj = e.head[jn];
@@ -548,7 +549,67 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     }
     // --- preparation wave: compact the world's other robots within lidar reach into LDS, each with the
     //     (conservative) interval of beams that can touch it.  It alone touches the masks before the barrier.
+    // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
+    // exceed the 64 a chunk holds: the preparation wave walks the nine bucket ranges 64 entries at a time and hands
+    // the marching threads one chunk of <= 64 neighbours per barrier pair (see the chunk loop below)
+    int big_cell = 0, big_off = 0;     // enumeration state of the preparation wave (wave-uniform)
+    auto big_chunk = [&]() {
+        const int icx = hash_cell_coord(x, kLidarCell), icy = hash_cell_coord(y, kLidarCell);
+        for (int b = pl; b < e.B; b += kWave) nbmask[b] = 0ull;
+        int cnt = 0;
+        while (big_cell < 9) {
+            const int qx = icx + big_cell % 3 - 1, qy = icy + big_cell / 3 - 1;
+            const uint32_t h = hash_cell(qx, qy, world) & (uint32_t)e.bw_lmask;
+            const int rs = e.bw_lstart[h] + big_off, re = e.bw_lstart[h + 1];
+            if (rs >= re) {
+                ++big_cell;
+                big_off = 0;
+                continue;
+            }
+            const int idx = rs + pl;
+            const int j = idx < re ? e.bw_lsorted[idx] : -1;
+            bool keep = false;
+            float cxj = 0.0f, cyj = 0.0f;
+            float4 chj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int lo = 0, hi = -1;
+            if (j >= 0 && j != n && j / e.R == world) {
+                cxj = e.pose[j * 3 + 0];
+                cyj = e.pose[j * 3 + 1];
+                // a bucket may hold other cells too (hash collisions) and the same bucket may serve two of the nine
+                // cells: a robot counts only for the cell it really is in, so nobody is listed twice
+                if (hash_cell_coord(cxj, kLidarCell) == qx && hash_cell_coord(cyj, kLidarCell) == qy) {
+                    const float ddx = cxj - x, ddy = cyj - y;
+                    if (ddx * ddx + ddy * ddy <= kLidarReach2) {
+                        beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, &lo, &hi);
+                        keep = lo <= hi;
+                        if (keep) chj = e.head[j];
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            const int add = __popcll(m);
+            if (cnt + add > kWave) break;          // this batch opens the next chunk
+            if (keep) {
+                const int idx2 = cnt + __popcll(m & ((1ull << pl) - 1ull));
+                nb[idx2] = make_float4(cxj, cyj, chj.x, chj.y);
+                nbi[idx2] = make_int2(lo, hi);
+            }
+            cnt += add;
+            big_off += kWave;
+        }
+        if (pl == 0) {
+            *nb_count = MRCA_DBG(e, 1) ? 0 : cnt;
+            *nb_more = big_cell < 9 ? 1 : 0;
+        }
+        for (int k = 0; k < cnt; ++k) {
+            const int2 iv = nbi[k];
+            for (int b = iv.x + pl; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
+        }
+    };
     if (is_prep) {
+      if constexpr (BIG) {
+        big_chunk();
+      } else {
         for (int b = pl; b < e.B; b += kWave) nbmask[b] = 0ull;
         const float ddx = xj - x, ddy = yj - y;
         // conservative cull: a hit below 6 m needs the centre within 6 + circumradius(0.2907) m
@@ -572,6 +633,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             const int2 iv = nbi[k];
             for (int b = iv.x + pl; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
         }
+      }
         // frame-stack shift: a lane only ever touches "its" float4 columns, so reads and writes of different
         // lanes never meet, and within a lane every store waits for the loads it depends on
         if (shifter && chunks <= 2) {
@@ -607,21 +669,38 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         grid_march_skip_n<K>(field, e.g, org, dx, dy, kRangeMax, rng);
     }
     __syncthreads();  // neighbour list ready (the preparation wave built it while the others marched)
-    if (!marches) return;  // the dedicated preparation wave is done (whole wave: the barrier below counts live waves)
-    const int cnt = *nb_count;
+    if constexpr (!BIG) {
+        if (!marches) return;  // the dedicated preparation wave is done (whole wave: the barrier below counts live waves)
+    }
+    for (;;) {
+        const int cnt = *nb_count;
+        const int more = BIG ? *nb_more : 0;
+        if (marches) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int b = tid + k * T;
+                float r = rng[k];
+                unsigned long long m = cnt > 0 ? nbmask[b] : 0ull;
+                while (m) {
+                    const int q = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float4 nbq = nb[q];
+                    const float t = ray_box(x, y, dx[k], dy[k], nbq.x, nbq.y, nbq.z, nbq.w);
+                    r = t < r ? t : r;
+                }
+                rng[k] = r;
+            }
+        }
+        if (!more) break;
+        __syncthreads();          // everybody is through with this chunk ...
+        if (is_prep) big_chunk();
+        __syncthreads();          // ... and the next one is ready
+    }
+    if (!marches) return;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int b = tid + k * T;
-        float r = rng[k];
-        unsigned long long m = cnt > 0 ? nbmask[b] : 0ull;
-        while (m) {
-            const int q = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const float4 nbq = nb[q];
-            const float t = ray_box(x, y, dx[k], dy[k], nbq.x, nbq.y, nbq.z, nbq.w);
-            r = t < r ? t : r;
-        }
-        r = r < kRangeMax ? r : kRangeMax;
+        const float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
         rbuf[b] = r;
         obuf[b] = norm_obs(r);     // stage_world1.py:140, once per value, spread over all marching threads
     }
@@ -644,6 +723,272 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         e.local_goal[n * 2 + 0] = gx * c + gy * s;
         e.local_goal[n * 2 + 1] = gy * c - gx * s;
     }
+}
+
+
+// ================================================================================================================
+// Worlds with more than 64 robots (a single 500 / 50 000-robot circle): the tick of move_kernel
+// spread over per-robot threads.  Same rules, same arithmetic, same ORDER: robots are tested one after another in
+// index order against the poses the others have at that point (Stage's sequential model loop).
+//
+//   bw_integrate  thread per robot: latch, integrate, outline-vs-grid test, provisional pose -> bw_prov; both the
+//                 pose at tick start and the provisional pose go into the collision hash (0.7 m cells, chained).
+//   bw_collide    thread per robot, the ordered pass as DEPENDENCY ROUNDS: robot i looks at the 3 x 3 cells around
+//                 its provisional centre; anybody listed there within 2 x circumradius can matter.  i is decided once
+//                 every such lower-indexed moving robot is (their outcome tells which of their two poses counts);
+//                 then it runs the SAT tests and publishes its own outcome (release / acquire on bw_state).  The
+//                 lowest undecided robot never waits, so the loop terminates; workgroups are dispatched in index
+//                 order and only ever wait for lower indices, so a waiting wave never starves the one it waits for.
+//                 Robots with nobody in reach decide in their first round.
+//   bw_finish     thread per robot: commit, GT velocity, reward / terminal, episode bookkeeping (per-robot resets),
+//                 head record.
+//   bw_lidar_*    counting sort of the FINAL poses into the lidar hash (6.5 m cells) the ray cast enumerates.
+// ================================================================================================================
+constexpr int kFlagMoving = 1, kFlagStaticHit = 2, kFlagLive = 4;
+
+__global__ void bw_integrate_kernel(EnvView e, const float* __restrict__ actions) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
+    const float4 hd = e.head[n];
+    const bool live = e.live[n] != 0;
+    const float v = live ? sane_cmd(actions[n * 2 + 0]) : 0.0f;
+    const float w = live ? sane_cmd(actions[n * 2 + 1]) : 0.0f;
+    const float s = hd.x, c = hd.y;
+    const float d = v * kDt;
+    const float nx = x + d * c;
+    const float ny = y + d * s;
+    const float nth = wrap_angle(th + w * kDt);
+    float ns, nc;
+    sincos_det(nth, &ns, &nc);
+    const bool moving = (v != 0.0f) || (w != 0.0f);
+    // outline-vs-grid test: free for sure when the footprint's patch lies outside the map (cells outside are
+    // free) or the distance field clears it; otherwise the four outline edges are walked in the bitmap
+    const int hc = e.foot_hc;
+    const int pix = (int)floorf((nx - e.g.x0) * e.g.inv_cell);
+    const int piy = (int)floorf((ny - e.g.y0) * e.g.inv_cell);
+    const bool touches = pix + hc >= 0 && piy + hc >= 0 && pix - hc < e.g.width && piy - hc < e.g.height;
+    const bool inside = pix >= 0 && piy >= 0 && pix < e.g.width && piy < e.g.height;
+    bool shit = false;
+    if (touches && !MRCA_DBG(e, 8)) {
+        const bool clear = inside && e.cellfield[(size_t)piy * e.g.width + pix] > hc;
+        if (!clear) shit = static_hit(GlobalGrid{e.map_bits, e.g.width, e.g.height, e.g.wpr}, e.g, nx, ny, ns, nc);
+    }
+    const int flags = (moving ? kFlagMoving : 0) | (shit ? kFlagStaticHit : 0) | (live ? kFlagLive : 0);
+    e.bw_prov[2 * n + 0] = make_float4(nx, ny, nth, __int_as_float(flags));
+    e.bw_prov[2 * n + 1] = make_float4(ns, nc, v, w);
+    e.bw_state[n] = moving ? 0 : 1;
+    const int world = n / e.R;
+    {
+        const uint32_t h = hash_cell(hash_cell_coord(x, kCollideCell), hash_cell_coord(y, kCollideCell), world) &
+                           (uint32_t)e.bw_cmask;
+        e.bw_cnext[2 * n] = atomicExch(&e.bw_chead[h], 2 * n);
+    }
+    if (moving) {
+        const uint32_t h = hash_cell(hash_cell_coord(nx, kCollideCell), hash_cell_coord(ny, kCollideCell), world) &
+                           (uint32_t)e.bw_cmask;
+        e.bw_cnext[2 * n + 1] = atomicExch(&e.bw_chead[h], 2 * n + 1);
+    }
+}
+
+__global__ void bw_collide_kernel(EnvView e) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    const float4 p0 = e.bw_prov[2 * n], p1 = e.bw_prov[2 * n + 1];
+    const int flags = __float_as_int(p0.w);
+    if (!(flags & kFlagMoving)) return;               // stays where it is; its stall flag is left alone
+    const float nx = p0.x, ny = p0.y, ns = p1.x, nc = p1.y;
+    const int world = n / e.R;
+    const int icx = hash_cell_coord(nx, kCollideCell), icy = hash_cell_coord(ny, kCollideCell);
+    for (int guard = 0; guard < (1 << 22); ++guard) {   // the guard only bounds a launch that could never finish
+        bool ready = true;
+        bool hit = (flags & kFlagStaticHit) != 0;
+        if (!MRCA_DBG(e, 16)) {
+            for (int q = 0; q < 9 && ready; ++q) {
+                const uint32_t h = hash_cell(icx + q % 3 - 1, icy + q / 3 - 1, world) & (uint32_t)e.bw_cmask;
+                for (int en = e.bw_chead[h]; en >= 0 && ready; en = e.bw_cnext[en]) {
+                    const int j = en >> 1;
+                    if (j == n || j / e.R != world) continue;
+                    const float4 q0 = e.bw_prov[2 * j], q1 = e.bw_prov[2 * j + 1];
+                    const float ox = e.pose[j * 3 + 0], oy = e.pose[j * 3 + 1];
+                    // the centre this entry stands for: within reach of my provisional centre?
+                    const float ax = nx - ((en & 1) ? q0.x : ox), ay = ny - ((en & 1) ? q0.y : oy);
+                    if (!(ax * ax + ay * ay <= kCollideReach2)) continue;
+                    // the pose j has when it is my turn: robots after me have not moved yet; a robot before me is
+                    // at its provisional pose iff its own test came out free
+                    int sj = 1;
+                    if (j < n && (__float_as_int(q0.w) & kFlagMoving)) {
+                        sj = __hip_atomic_load(&e.bw_state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sj == 0) {
+                            ready = false;
+                            break;
+                        }
+                    }
+                    const float4 hj = e.head[j];
+                    const bool at_new = sj == 2;
+                    hit = obb_overlap(nx, ny, ns, nc, at_new ? q0.x : ox, at_new ? q0.y : oy, at_new ? q1.x : hj.x,
+                                      at_new ? q1.y : hj.y) || hit;
+                }
+            }
+        }
+        if (ready) {
+            e.crashed[n] = hit ? 1 : 0;
+            __hip_atomic_store(&e.bw_state[n], hit ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+__global__ void bw_finish_kernel(EnvView e) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    const int local = n % e.R;
+    const float4 p0 = e.bw_prov[2 * n], p1 = e.bw_prov[2 * n + 1];
+    const int flags = __float_as_int(p0.w);
+    const bool live = (flags & kFlagLive) != 0;
+    const bool moved = e.bw_state[n] == 2;
+    const float4 hd = e.head[n];
+    float x = moved ? p0.x : e.pose[n * 3 + 0];
+    float y = moved ? p0.y : e.pose[n * 3 + 1];
+    float th = moved ? p0.z : e.pose[n * 3 + 2];
+    float s = moved ? p1.x : hd.x, c = moved ? p1.y : hd.y;
+    const float v = p1.z, w = p1.w;
+    float gx = e.goal[n * 2 + 0], gy = e.goal[n * 2 + 1];
+    float pdist = e.prev_dist[n];
+    int t = e.t[n];
+    float reward = e.reward[n];
+    uint8_t done = e.done[n], res = e.result[n], first = e.first_result[n], crashed = e.crashed[n];
+    int ep = e.episode[n];
+
+    // GT velocity = finite difference of the pose (stageros.cpp:585-590)
+    const float vgt = moved ? fabsf(v) : 0.0f;
+    const float wgt = moved ? w : 0.0f;
+    // reward / terminal (stage_world1.py:180-211)
+    const float ddx = gx - x, ddy = gy - y;
+    const float dist = sqrtf(ddx * ddx + ddy * ddy);
+    float rg = (pdist - dist) * kKProgress;
+    const bool reach = dist < kGoalRadius;
+    rg = reach ? kRArrive : rg;
+    const bool crash = crashed == 1;
+    const float rc = crash ? kRCrash : 0.0f;
+    const float aw = fabsf(wgt);
+    const float rw = (aw > e.w_thresh) ? kKOmega * aw : 0.0f;
+    const bool tout = t > e.timeout;
+    uint8_t result = reach ? 1 : 0;
+    result = crash ? 2 : result;
+    result = tout ? 3 : result;
+    const bool done_now = reach || crash || tout;
+    uint8_t lv = live ? 1 : 0;
+    if (live) {
+        reward = (rg + rc) + rw;
+        done = done_now ? 1 : 0;
+        res = result;
+        pdist = dist;
+        t = t + 1;
+        if (done_now && first == 0) first = result;
+    }
+    float spv = v, spw = w, ovgt = vgt, owgt = wgt;
+    const bool fresh = e.auto_reset == 1 && live && done_now && !MRCA_DBG(e, 32);
+    if (fresh) {   // new episode (ppo_stage1.py:51-58): the one-lane form of the sampling loops
+        ep = ep + 1;
+        const int rm = e.reset_mode[local], gm = e.goal_mode[local];
+        float px, py, pth, qx, qy;
+        if (rm == 0) {
+            px = e.init_table[local * 3 + 0];
+            py = e.init_table[local * 3 + 1];
+            pth = wrap_angle(e.init_table[local * 3 + 2]);
+        } else {
+            sample_pose(rm, (uint32_t)n, (uint32_t)ep, e.key0, e.key1, x, y, &px, &py, &pth);
+        }
+        if (gm == 0) {
+            qx = e.goal_table[local * 2 + 0];
+            qy = e.goal_table[local * 2 + 1];
+        } else {
+            sample_goal(gm, (uint32_t)n, (uint32_t)ep, e.key0, e.key1, px, py, &qx, &qy);
+        }
+        x = px;
+        y = py;
+        th = pth;
+        sincos_det(pth, &s, &c);
+        gx = qx;
+        gy = qy;
+        const float ex = qx - px, ey = qy - py;
+        pdist = e.pre_dist_zero ? 0.0f : sqrtf(ex * ex + ey * ey);
+        e.init_pose[n * 3 + 0] = px;
+        e.init_pose[n * 3 + 1] = py;
+        e.init_pose[n * 3 + 2] = pth;
+        t = 1;
+        crashed = 0;
+        lv = 1;
+        spv = spw = ovgt = owgt = 0.0f;
+    }
+    const FreeRectField rect_field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
+    const uint32_t cellv = rect_field((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell));
+    e.pose[n * 3 + 0] = x;
+    e.pose[n * 3 + 1] = y;
+    e.pose[n * 3 + 2] = th;
+    e.speed[n * 2 + 0] = spv;
+    e.speed[n * 2 + 1] = spw;
+    e.speed_gt[n * 2 + 0] = ovgt;
+    e.speed_gt[n * 2 + 1] = owgt;
+    e.goal[n * 2 + 0] = gx;
+    e.goal[n * 2 + 1] = gy;
+    e.prev_dist[n] = pdist;
+    e.t[n] = t;
+    e.reward[n] = reward;
+    e.done[n] = done;
+    e.result[n] = res;
+    e.first_result[n] = first;
+    e.crashed[n] = crashed;
+    e.live[n] = lv;
+    e.episode[n] = ep;
+    e.fresh[n] = fresh ? 1 : 0;
+    e.head[n] = make_float4(s, c, __uint_as_float(cellv), 0.0f);
+}
+
+// lidar hash = counting sort of the robots by the bucket of their (final) cell
+__global__ void bw_lidar_count_kernel(EnvView e) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    const uint32_t h = hash_cell(hash_cell_coord(e.pose[n * 3 + 0], kLidarCell), hash_cell_coord(e.pose[n * 3 + 1], kLidarCell),
+                                 n / e.R) & (uint32_t)e.bw_lmask;
+    atomicAdd(&e.bw_lcount[h], 1);
+}
+
+__global__ __launch_bounds__(1024) void bw_lidar_scan_kernel(EnvView e) {   // one workgroup: exclusive scan of the counts
+    __shared__ int part[1024];
+    const int M = e.bw_lmask + 1;
+    const int per = (M + 1023) / 1024;
+    const int b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+        if (b0 + k < M) sum += e.bw_lcount[b0 + k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int k = 0; k < per; ++k)
+        if (b0 + k < M) {
+            const int cnt = e.bw_lcount[b0 + k];
+            e.bw_lstart[b0 + k] = run;
+            e.bw_lcount[b0 + k] = 0;           // becomes the fill cursor
+            run += cnt;
+        }
+    if (threadIdx.x == 1023) e.bw_lstart[M] = part[1023];
+}
+
+__global__ void bw_lidar_fill_kernel(EnvView e) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    const uint32_t h = hash_cell(hash_cell_coord(e.pose[n * 3 + 0], kLidarCell), hash_cell_coord(e.pose[n * 3 + 1], kLidarCell),
+                                 n / e.R) & (uint32_t)e.bw_lmask;
+    e.bw_lsorted[e.bw_lstart[h] + atomicAdd(&e.bw_lcount[h], 1)] = n;
 }
 
 // generate_train_data (model/ppo.py:122-139)
@@ -681,7 +1026,24 @@ size_t move_lds_bytes(const EnvView& e) {
 }
 
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
-    hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), move_lds_bytes(e), s, e, actions);
+    if (!e.big) {
+        hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), move_lds_bytes(e), s, e, actions);
+        return;
+    }
+    const int bs = 256, nb = (e.N + bs - 1) / bs;
+    (void)hipMemsetAsync(e.bw_chead, 0xFF, sizeof(int32_t) * (size_t)(e.bw_cmask + 1), s);
+    hipLaunchKernelGGL(bw_integrate_kernel, dim3(nb), dim3(bs), 0, s, e, actions);
+    hipLaunchKernelGGL(bw_collide_kernel, dim3(nb), dim3(bs), 0, s, e);
+    hipLaunchKernelGGL(bw_finish_kernel, dim3(nb), dim3(bs), 0, s, e);
+}
+
+void launch_lidar_grid(const EnvView& e, hipStream_t s) {
+    if (!e.big) return;
+    const int bs = 256, nb = (e.N + bs - 1) / bs;
+    (void)hipMemsetAsync(e.bw_lcount, 0, sizeof(int32_t) * (size_t)(e.bw_lmask + 1), s);
+    hipLaunchKernelGGL(bw_lidar_count_kernel, dim3(nb), dim3(bs), 0, s, e);
+    hipLaunchKernelGGL(bw_lidar_scan_kernel, dim3(1), dim3(1024), 0, s, e);
+    hipLaunchKernelGGL(bw_lidar_fill_kernel, dim3(nb), dim3(bs), 0, s, e);
 }
 
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s) {
@@ -697,10 +1059,20 @@ void launch_head_init(const EnvView& e, hipStream_t s) {
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
     const int threads = (e.B >> e.ray_shift) + (e.ray_prep_wave ? kWave : 0);
     const size_t lds = ray_lds_bytes(e);
+    const dim3 grid(e.ray_count);
+    if (e.ray_count <= 0) return;
+    if (e.big) {
+        switch (e.ray_shift) {
+            case 0: hipLaunchKernelGGL((raycast_kernel<1, true>), grid, dim3(threads), lds, s, e, only_fresh); break;
+            case 1: hipLaunchKernelGGL((raycast_kernel<2, true>), grid, dim3(threads), lds, s, e, only_fresh); break;
+            default: hipLaunchKernelGGL((raycast_kernel<4, true>), grid, dim3(threads), lds, s, e, only_fresh); break;
+        }
+        return;
+    }
     switch (e.ray_shift) {
-        case 0: hipLaunchKernelGGL(raycast_kernel<1>, dim3(e.N), dim3(threads), lds, s, e, only_fresh); break;
-        case 1: hipLaunchKernelGGL(raycast_kernel<2>, dim3(e.N), dim3(threads), lds, s, e, only_fresh); break;
-        default: hipLaunchKernelGGL(raycast_kernel<4>, dim3(e.N), dim3(threads), lds, s, e, only_fresh); break;
+        case 0: hipLaunchKernelGGL((raycast_kernel<1, false>), grid, dim3(threads), lds, s, e, only_fresh); break;
+        case 1: hipLaunchKernelGGL((raycast_kernel<2, false>), grid, dim3(threads), lds, s, e, only_fresh); break;
+        default: hipLaunchKernelGGL((raycast_kernel<4, false>), grid, dim3(threads), lds, s, e, only_fresh); break;
     }
 }
 

@@ -19,7 +19,7 @@ FIELDS = [  # order = enum mrca_field
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
-           "mrca_step", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing"]
+           "mrca_step", "mrca_step_slice", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing"]
 
 
 class MrcaConfig(C.Structure):
@@ -58,6 +58,7 @@ def load(path=None):
     lib.mrca_destroy.argtypes = [C.c_void_p]
     lib.mrca_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_step_slice.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.mrca_get_field.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_size_t)]
     lib.mrca_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,

@@ -136,3 +136,27 @@ def circle(num_worlds=1, seed=0, grid=None):
                     pre_dist_zero=True, auto_reset=AUTO_NONE, seed=seed, reset_mode=mode, goal_mode=mode.copy(),
                     init_table=np.asarray(tb["init_pose"], np.float64),
                     goal_table=np.asarray(tb["goal_point"], np.float64))
+
+
+def empty_grid(cells=8, cell=1.0):
+    """An open world: a tiny all-free grid at the origin (cells outside a grid are free)."""
+    return GridData.from_dense(np.zeros((cells, cells), bool), cell, -0.5 * cells * cell, -0.5 * cells * cell)
+
+
+def circle_big(num_robots, num_worlds=1, seed=0, spacing=None, grid=None):
+    """The circle test as ONE circle of ``num_robots`` robots with the radius scaled so that the neighbour spacing
+    of the reference's 50-robot / 25 m circle (2*pi*25/50 = 3.14 m) is kept: radius = 25 * num_robots / 50
+    (SURVEY 8d C5 "single circles with radius proportional to R").  Poses as in model/utils.py:6-38: robot i at
+    angle 2*pi*i/R facing the centre, goal = the antipodal point.  The reference's rink (60 m for r = 25 m) would
+    be a 60 * R/50 m map -- 6000^2 cells at 500 robots -- whose wall sits 5 m BEHIND every robot; the scaled
+    scenario runs in an open world instead (``grid`` overrides)."""
+    R = int(num_robots)
+    sp = 2.0 * np.pi * 25.0 / 50.0 if spacing is None else float(spacing)
+    radius = sp * R / (2.0 * np.pi)
+    ang = 2.0 * np.pi * np.arange(R) / R
+    init = np.stack([radius * np.cos(ang), radius * np.sin(ang), ang + np.pi], 1)
+    goal = -init[:, :2]
+    mode = np.full(R, RESET_TABLE, np.int32)
+    return Scenario("circle_big", num_worlds, R, grid or empty_grid(), timeout=1000000, w_thresh=0.7,
+                    pre_dist_zero=True, auto_reset=AUTO_NONE, seed=seed, reset_mode=mode, goal_mode=mode.copy(),
+                    init_table=init, goal_table=goal)

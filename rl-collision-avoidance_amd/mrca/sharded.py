@@ -1,0 +1,53 @@
+"""One world on several GPUs (a single circle of 50 000 robots).
+
+Every rank holds the WHOLE world and owns a contiguous slice of its robots.  Per tick there is exactly one
+exchange step: an all-gather of the commands ``act[N,2]`` (400 kB at 50 000 robots).  Each rank then advances all
+robots -- the collision pass is sequential in robot order and needs every provisional pose, it costs ~1 % of a tick,
+and identical arithmetic on identical inputs keeps the replicas bit-identical, so no pose ever has to travel --
+and casts the 512-beam lidar only for its own slice (``mrca_step_slice``), which is where the time goes.
+"""
+import torch
+
+
+def slice_bounds(n, size, rank):
+    """Contiguous slices of ceil(n / size) robots; trailing ranks may be short or empty."""
+    per = -(-n // size)
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n), per
+
+
+class ShardedWorld:
+    def __init__(self, env, dist=None):
+        self.env, self.dist = env, dist
+        self.size = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.size > 1 else 0
+        self.lo, self.hi, self.per = slice_bounds(env.N, self.size, self.rank)
+        self._pad = torch.zeros(self.per, 2, dtype=torch.float32, device=env.device)
+        self._all = torch.zeros(self.size * self.per, 2, dtype=torch.float32, device=env.device)
+
+    @property
+    def count(self):
+        return self.hi - self.lo
+
+    def local(self, field):
+        """This rank's rows of a per-robot field of the replicated world."""
+        return getattr(self.env, field)[self.lo:self.hi]
+
+    def reset(self):
+        self.env.reset()        # replicated: every rank resets the whole world (same seeds -> same poses)
+        return self.local("obs"), self.local("local_goal"), self.local("speed")
+
+    def gather_actions(self, local_actions):
+        """The exchange step: act[count,2] of every rank -> act[N,2] on every rank."""
+        if self.size == 1:
+            return local_actions.contiguous()
+        self._pad.zero_()
+        self._pad[: self.count].copy_(local_actions)
+        self.dist.all_gather_into_tensor(self._all, self._pad)
+        return self._all[: self.env.N].contiguous()   # short slices sit at the end: the first N rows are the world
+
+    def step(self, local_actions):
+        full = self.gather_actions(local_actions)
+        self.env.step(full, ray_slice=(self.lo, self.count))
+        return (self.local("obs"), self.local("local_goal"), self.local("speed"), self.local("reward"),
+                self.local("done"), self.local("result"))

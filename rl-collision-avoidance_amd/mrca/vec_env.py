@@ -106,11 +106,17 @@ class VecStageWorld:
                                        self._ptr(goals, torch.float32, self.N * 2), self._stream()), "mrca_reset")
         return self.obs, self.local_goal, self.speed
 
-    def step(self, actions):
+    def step(self, actions, ray_slice=None):
         """control_vel + one Stage tick + get_reward_and_terminate + next observation for every
-        robot (ppo_stage1.py:75-91).  ``actions`` f32[N,2] = clipped (v, omega)."""
-        _lib.check(self.lib.mrca_step(self._h, self._ptr(actions, torch.float32, self.N * 2), self._stream()),
-                   "mrca_step")
+        robot (ppo_stage1.py:75-91).  ``actions`` f32[N,2] = clipped (v, omega).
+        ``ray_slice=(first, count)``: one world sharded over ranks (mrca_step_slice) -- all robots advance, the
+        lidar is cast for robots [first, first + count) only."""
+        a = self._ptr(actions, torch.float32, self.N * 2)
+        if ray_slice is None:
+            _lib.check(self.lib.mrca_step(self._h, a, self._stream()), "mrca_step")
+        else:
+            _lib.check(self.lib.mrca_step_slice(self._h, a, int(ray_slice[0]), int(ray_slice[1]), self._stream()),
+                       "mrca_step_slice")
         return self.obs, self.local_goal, self.speed, self.reward, self.done, self.result
 
     # ------------------------------------------------------------------ timing (bench / profiles)

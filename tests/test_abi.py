@@ -57,7 +57,7 @@ def test_arena_bytes_and_layout(built_lib):
 
 
 @pytest.mark.parametrize("field,value,code", [
-    ("robots_per_world", 65, -4), ("robots_per_world", 0, -1), ("beams", 500, -1), ("frames", 0, -1),
+    ("robots_per_world", 0, -1), ("beams", 500, -1), ("frames", 0, -1),
     ("abi_version", 99, -1), ("map_cell", 0.0, -1), ("auto_reset", 7, -1), ("num_worlds", 0, -1),
     ("map_width", 0, -1), ("map_height", 20000, -4),
 ])
@@ -67,6 +67,15 @@ def test_config_validation_errors(built_lib, field, value, code):
     n = C.c_size_t()
     assert built_lib.mrca_arena_bytes(C.byref(cfg), C.byref(n)) == code
     assert len(built_lib.mrca_last_error()) > 0
+
+
+def test_big_worlds_validate(built_lib):
+    """More than 64 robots per world: accepted with per-robot or no restarts, refused with group-synchronous ones."""
+    cfg, _keep = _cfg(S.stage1(num_worlds=2, robots_per_world=300))
+    n = C.c_size_t()
+    assert built_lib.mrca_arena_bytes(C.byref(cfg), C.byref(n)) == 0 and n.value > 600 * 512 * 16
+    cfg.auto_reset = 2
+    assert built_lib.mrca_arena_bytes(C.byref(cfg), C.byref(n)) == -4
 
 
 def test_product_has_no_cpu_fallback():

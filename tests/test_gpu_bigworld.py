@@ -1,0 +1,127 @@
+"""GPU: worlds with more than 64 robots -- per-robot threads, per-tick spatial hashes, the
+ordered collision pass as dependency rounds, chunked lidar neighbour lists -- bit-exact against the C oracle, and
+the sharded tick (mrca_step_slice)."""
+import numpy as np
+import pytest
+import torch
+
+import util as U
+from util import S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    from mrca import vec_env
+    return vec_env
+
+
+def _exact(hip, sc, steps, seed, poses=None, check_every=4, actions=None):
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    if poses is None:
+        env.reset()
+        ora.reset()
+    else:
+        mask = np.ones(sc.num_robots, np.uint8)
+        env.reset(torch.from_numpy(mask).cuda(), torch.from_numpy(poses).cuda(), None)
+        ora.reset(mask, poses, None)
+    torch.cuda.synchronize()
+    U.assert_state_equal(U.HostView(env), ora, what=f"{sc.name} reset")
+    rng = np.random.default_rng(seed)
+    for k in range(steps):
+        a = U.random_actions(rng, sc.num_robots) if actions is None else actions(k, ora)
+        env.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+        if k % check_every == check_every - 1 or k == steps - 1:
+            torch.cuda.synchronize()
+            U.assert_state_equal(U.HostView(env), ora, what=f"{sc.name} step {k}")
+    env.close()
+    return ora
+
+
+def test_crowded_rink_200_robots_bit_exact(hip):
+    """200 robots in the 9 m Stage-1 disc (per-robot restarts): constant collisions, long dependency chains in the
+    ordered pass, > 64 lidar neighbours per robot (chunked lists)."""
+    o = _exact(hip, S.stage1(num_worlds=2, robots_per_world=200, seed=3), 24, 1)
+    assert o.episode.max() >= 3
+
+
+def test_single_circle_500_robots_bit_exact(hip):
+    """One circle of 500 robots, radius proportional to R (250 m, spacing 3.14 m), open world, the commands of a
+    go-to-goal controller: the scenario of SURVEY 8d C5."""
+    sc = S.circle_big(500)
+
+    def act(k, ora):
+        lg = ora.local_goal
+        bearing = np.arctan2(lg[:, 1], lg[:, 0])
+        return np.stack([np.full(sc.num_robots, 1.0), np.clip(2.0 * bearing, -1, 1)], 1).astype(np.float32)
+
+    _exact(hip, sc, 40, 0, actions=act, check_every=8)
+
+
+def test_jam_of_500_robots_bit_exact(hip):
+    """The end game of the big circle: 500 robots packed on a jittered 0.8 m lattice (the centre of the circle when
+    everybody arrives), random commands: > 150 robots within lidar reach of each other, collisions everywhere."""
+    sc = S.circle_big(500)
+    rng = np.random.default_rng(11)
+    side = 23
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:500]
+    xy = (ij - side / 2) * 0.8 + rng.uniform(-0.12, 0.12, (500, 2))
+    poses = np.concatenate([xy, rng.uniform(-np.pi, np.pi, (500, 1))], 1).astype(np.float32)
+    o = _exact(hip, sc, 20, 2, poses=poses)
+    assert o.crashed.sum() > 20
+
+
+def test_two_big_worlds_are_independent(hip):
+    sc2 = S.circle_big(100, num_worlds=2, spacing=0.9)
+    sc1 = S.circle_big(100, num_worlds=1, spacing=0.9)
+    a, b = hip.VecStageWorld(sc2), hip.VecStageWorld(sc1)
+    a.reset()
+    b.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for _ in range(10):
+        act = torch.stack([torch.rand(200, generator=g), torch.rand(200, generator=g) * 2 - 1], 1).float().cuda()
+        a.step(act)
+        b.step(act[:100].contiguous())
+    for f in ("pose", "scan", "reward", "crashed"):
+        assert torch.equal(getattr(a, f)[:100], getattr(b, f)), f
+    a.close()
+    b.close()
+
+
+def test_step_slice_casts_only_the_slice(hip):
+    """mrca_step_slice: every robot advances (state identical to a full step), the lidar outputs change only for the
+    robots of the slice -- and there they equal the full step's."""
+    sc = S.circle_big(150, spacing=0.9)
+    full, part = hip.VecStageWorld(sc), hip.VecStageWorld(sc)
+    full.reset()
+    part.reset()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    lo, cnt = 40, 70
+    for _ in range(6):
+        act = torch.stack([torch.rand(150, generator=g), torch.rand(150, generator=g) * 2 - 1], 1).float().cuda()
+        before = part.obs.clone()
+        full.step(act)
+        part.step(act, ray_slice=(lo, cnt))
+        for f in ("pose", "speed", "speed_gt", "reward", "done", "crashed", "t"):
+            assert torch.equal(getattr(full, f), getattr(part, f)), f
+        assert torch.equal(part.scan[lo:lo + cnt], full.scan[lo:lo + cnt])
+        assert torch.equal(part.obs[lo:lo + cnt, -1], full.obs[lo:lo + cnt, -1])
+        assert torch.equal(part.obs[:lo], before[:lo]) and torch.equal(part.obs[lo + cnt:], before[lo + cnt:])
+    with pytest.raises(RuntimeError, match="slice"):
+        part.step(act, ray_slice=(100, 100))
+    full.close()
+    part.close()
+
+
+def test_group_synchronous_big_worlds_are_refused(hip):
+    sc = S.stage1(num_worlds=1, robots_per_world=65)
+    sc.auto_reset = S.AUTO_GROUP
+    with pytest.raises(RuntimeError, match="robots_per_world"):
+        hip.VecStageWorld(sc)
