@@ -160,6 +160,17 @@ const char* mrca_last_error(void);
  * recorded launches in milliseconds and clears the ring. */
 int mrca_enable_timing(mrca_env* env, int32_t on); /* on = n > 0: time every n-th step; 0: off */
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
+/* Rollout-path front end of the lidar actor-critic (model/net.py:19-25,37-49,57-69: Conv1d(3,32,k5,s2,p1) -> ReLU ->
+ * Conv1d(32,32,k3,s2,p1) -> ReLU for the actor and the critic tower), fused into one kernel: fp32 in, fp32 MFMA
+ * accumulate, the 32 x 255 intermediate never leaves the CU.  Inference only -- training keeps the PyTorch layers.
+ *   obs_dev  f32[N,3,512]   the env's observation stack (field MRCA_F_OBS)
+ *   w1_dev   f32[2,32,3,5]  b1_dev f32[2,32]    act_fea_cv1 / crt_fea_cv1 weight and bias, tower-major
+ *   w2_dev   f32[2,32,32,3] b2_dev f32[2,32]    act_fea_cv2 / crt_fea_cv2
+ *   feat_dev f32[2,N,4096]  out: tower-major, each row in the flatten order of [32,128] (what act_fc1 / crt_fc1 eat)
+ * frames must be 3 and beams 512 (MRCA_ERR_UNSUPPORTED otherwise). */
+int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams, const float* w1_dev,
+                        const float* b1_dev, const float* w2_dev, const float* b2_dev, float* feat_dev, void* stream);
+
 #ifdef MRCA_PROFILING
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product
  * library neither exports this symbol nor contains the switches.  Results are WRONG while any of bits 0-5 is

@@ -19,7 +19,8 @@ FIELDS = [  # order = enum mrca_field
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
-           "mrca_step", "mrca_step_slice", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing"]
+           "mrca_step", "mrca_step_slice", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
+           "mrca_lidar_features"]
 
 
 class MrcaConfig(C.Structure):
@@ -63,6 +64,8 @@ def load(path=None):
                                    C.POINTER(C.c_size_t)]
     lib.mrca_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_lidar_features.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only
         lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]

@@ -66,6 +66,41 @@ class CNNPolicy(nn.Module):
         v = self.critic(self._tower("crt", x, goal, speed))
         return mean, v
 
+    # ------------------------------------------------------------------ rollout fast path (inference only)
+    def refresh_rollout_cache(self):
+        """Tower-major copies of the parameters the fused rollout path reads (call after every optimiser step
+        sequence, i.e. once per PPO update): the two conv layers for the HIP front end, fc1 / fc2 / heads stacked for
+        batched GEMMs.  Same parameters, same state_dict keys -- these are derived buffers, never saved."""
+        with torch.no_grad():
+            st = lambda a, c: torch.stack([a.detach(), c.detach()]).contiguous()   # noqa: E731
+            self._rc = {
+                "w1": st(self.act_fea_cv1.weight, self.crt_fea_cv1.weight), "b1": st(self.act_fea_cv1.bias, self.crt_fea_cv1.bias),
+                "w2": st(self.act_fea_cv2.weight, self.crt_fea_cv2.weight), "b2": st(self.act_fea_cv2.bias, self.crt_fea_cv2.bias),
+                "fc1_w": st(self.act_fc1.weight.t(), self.crt_fc1.weight.t()),        # [2, 4096, 256]
+                "fc1_b": st(self.act_fc1.bias, self.crt_fc1.bias).unsqueeze(1),      # [2, 1, 256]
+                "fc2_w": st(self.act_fc2.weight.t(), self.crt_fc2.weight.t()),        # [2, 260, 128]
+                "fc2_b": st(self.act_fc2.bias, self.crt_fc2.bias).unsqueeze(1),      # [2, 1, 128]
+                "head_w": torch.cat([self.actor1.weight, self.actor2.weight]).detach().t().contiguous(),   # [128, 2]
+                "head_b": torch.cat([self.actor1.bias, self.actor2.bias]).detach(),
+            }
+        return self._rc
+
+    def mean_value_fused(self, x, goal, speed):
+        """mean_value for the rollout: the conv front end of BOTH towers in one HIP kernel (csrc/mrca_policy.hip,
+        fp32 MFMA), fc1 / fc2 of both towers as batched fp32 GEMMs.  fp32 throughout; differs from mean_value by
+        summation order only (tests/test_gpu_policy_ops.py: 1e-5).  No autograd."""
+        from . import policy_ops
+        rc = getattr(self, "_rc", None) or self.refresh_rollout_cache()
+        with torch.no_grad():
+            feat = policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"])        # [2, N, 4096]
+            h = torch.relu(torch.baddbmm(rc["fc1_b"], feat, rc["fc1_w"]))                      # [2, N, 256]
+            gs = torch.cat((goal, speed), dim=-1).unsqueeze(0).expand(2, -1, -1)
+            h = torch.relu(torch.baddbmm(rc["fc2_b"], torch.cat((h, gs), dim=-1), rc["fc2_w"]))   # [2, N, 128]
+            m = torch.addmm(rc["head_b"], h[0], rc["head_w"])
+            mean = torch.stack((torch.sigmoid(m[:, 0]), torch.tanh(m[:, 1])), dim=-1)
+            v = self.critic(h[1])
+        return mean, v
+
     def forward(self, x, goal, speed, generator=None):
         """-> (value, sampled action, logprob, mean)   (model/net.py:37-70)"""
         mean, v = self.mean_value(x, goal, speed)

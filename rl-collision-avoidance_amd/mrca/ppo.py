@@ -23,31 +23,34 @@ def _bounds(action_bound, device, dtype):
 
 
 # ---------------------------------------------------------------------------------------------
-def generate_action(policy, obs, goal, speed, action_bound, generator=None, autocast_dtype=None):
+def generate_action(policy, obs, goal, speed, action_bound, generator=None, autocast_dtype=None, fused=False):
     """model/ppo.py:57-82: sample a ~ N(mean, std); the UNclipped action and its logprob are what
-    the buffer stores, the clipped one drives the robot.  ``autocast_dtype=torch.bfloat16`` runs the
-    towers on the bf16 MFMA path (opt-in; the reference and the default here are fp32)."""
+    the buffer stores, the clipped one drives the robot.  ``fused=True`` evaluates the policy through its fp32
+    rollout path (HIP conv front end + batched GEMMs, net.CNNPolicy.mean_value_fused; same numbers to 1e-5);
+    ``autocast_dtype=torch.bfloat16`` runs the stock towers on the bf16 MFMA path (opt-in)."""
+    from .net import gaussian_logprob
     with torch.no_grad():
-        if autocast_dtype is not None:
+        if fused:
+            mean, v = policy.mean_value_fused(obs, goal, speed)
+        elif autocast_dtype is not None:
             with torch.autocast(obs.device.type, dtype=autocast_dtype):
                 mean, v = policy.mean_value(obs, goal, speed)
             mean, v = mean.float(), v.float()
-            logstd = policy.logstd.expand_as(mean)
-            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
-            a = mean + torch.exp(logstd) * noise
-            from .net import gaussian_logprob
-            logprob = gaussian_logprob(a, mean, logstd)
         else:
-            v, a, logprob, _mean = policy(obs, goal, speed, generator=generator)
+            mean, v = policy.mean_value(obs, goal, speed)
+        logstd = policy.logstd.expand_as(mean)
+        noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        a = mean + torch.exp(logstd) * noise
+        logprob = gaussian_logprob(a, mean, logstd)
         lo, hi = _bounds(action_bound, a.device, a.dtype)
         scaled = torch.minimum(torch.maximum(a, lo), hi)
     return v, a, logprob, scaled
 
 
-def generate_action_no_sampling(policy, obs, goal, speed, action_bound):
+def generate_action_no_sampling(policy, obs, goal, speed, action_bound, fused=False):
     """model/ppo.py:84-107: deterministic mean action (circle_test.py:58-59)."""
     with torch.no_grad():
-        mean, _v = policy.mean_value(obs, goal, speed)
+        mean, _v = policy.mean_value_fused(obs, goal, speed) if fused else policy.mean_value(obs, goal, speed)
         lo, hi = _bounds(action_bound, mean.device, mean.dtype)
         scaled = torch.minimum(torch.maximum(mean, lo), hi)
     return mean, scaled

@@ -32,6 +32,7 @@ class HParams:
     action_bound: tuple = ((0.0, -1.0), (1.0, 1.0))   # ppo_stage1.py:170
     inference_dtype: object = None    # None = fp32 like the reference; torch.bfloat16 = opt-in fast rollouts
     update_dtype: object = None       # autocast dtype of the PPO update's forward/backward (opt-in)
+    rollout_fused: bool = False       # rollout inference through the HIP conv front end (net.mean_value_fused, fp32)
     kl_target: float = 0.0            # > 0: KL-adaptive learning rate (ppo.KLAdaptiveLR; opt-in, large-batch regime)
     lr_max: float = 1e-3
 
@@ -73,7 +74,7 @@ class Stage1Trainer:
         """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
         env, hp, buf = self.env, self.hp, self.buffer
         v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
-                                                    hp.action_bound, self.gen, hp.inference_dtype)
+                                                    hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused)
         buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v)
         env.step(scaled.contiguous())
         buf.store_outcome(self.t, env.reward, env.done)
@@ -84,8 +85,9 @@ class Stage1Trainer:
 
     def update(self):
         env, hp, buf = self.env, self.hp, self.buffer
-        with torch.no_grad():
-            _mean, last_v = self.policy.mean_value(env.obs, env.local_goal, env.speed)   # ppo_stage1.py:94-97
+        with torch.no_grad():                                                           # ppo_stage1.py:94-97
+            _mean, last_v = (self.policy.mean_value_fused if hp.rollout_fused else self.policy.mean_value)(
+                env.obs, env.local_goal, env.speed)
         targets, advs = ppo.generate_train_data(buf.reward, hp.gamma, buf.value, last_v, buf.done, hp.lam)
         memory = (buf.obs, buf.goal, buf.speed, buf.action, buf.logprob, targets, buf.value, buf.reward, advs)
         kw = dict(policy=self.policy, optimizer=self.optimizer, batch_size=hp.batch_size, memory=memory,
@@ -97,6 +99,8 @@ class Stage1Trainer:
             ppo.ppo_update_stage2(filter_index=ppo.get_filter_index(buf.done), **kw)
         else:
             ppo.ppo_update_stage1(**kw)
+        if hp.rollout_fused:
+            self.policy.refresh_rollout_cache()      # the rollout path reads tower-major copies of the parameters
         self.global_update += 1
 
     @property
@@ -110,15 +114,15 @@ class Stage1Trainer:
             self.tick()
 
 
-def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, update_dtype=None):
+def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, update_dtype=None, fused=False):
     """bench.py --mode rollout|train: returns step_fn(k) doing one tick for all robots."""
-    hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype, update_dtype=update_dtype)
+    hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype, update_dtype=update_dtype, rollout_fused=fused)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0)
     tr.started = True  # bench.py resets the env itself
     if mode == "rollout":
         def step_fn(_k):
             _v, _a, _lp, scaled = ppo.generate_action(tr.policy, env.obs, env.local_goal, env.speed,
-                                                      hp.action_bound, tr.gen, hp.inference_dtype)
+                                                      hp.action_bound, tr.gen, hp.inference_dtype, hp.rollout_fused)
             env.step(scaled.contiguous())
         return step_fn
 
