@@ -129,6 +129,11 @@ def main():
                     help="rollout/train: dtype of the policy INFERENCE pass (update stays fp32); f32 = the reference's")
     ap.add_argument("--update-dtype", default="f32", choices=["f32", "bf16"],
                     help="train: autocast dtype of the PPO update (master weights stay fp32); f32 = the reference's")
+    ap.add_argument("--policy-path", default="fused", choices=["fused", "stock"],
+                    help="rollout/train: policy INFERENCE through the fp32 HIP conv front end + batched GEMMs (fused, "
+                         "default) or through the stock PyTorch layers (stock); the PPO update always uses the latter")
+    ap.add_argument("--no-graph", action="store_true", help="rollout/train: launch the tick kernel by kernel instead of "
+                                                             "replaying it as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the rollout/train side figures")
     args = ap.parse_args()
@@ -192,7 +197,9 @@ def main():
         from mrca.trainer import make_bench_step
         step_fn = make_bench_step(env, args.mode, dist,
                                   inference_dtype=torch.bfloat16 if args.policy_dtype == "bf16" else None,
-                                  update_dtype=torch.bfloat16 if args.update_dtype == "bf16" else None)
+                                  update_dtype=torch.bfloat16 if args.update_dtype == "bf16" else None,
+                                  fused=(args.policy_path == "fused" and args.policy_dtype == "f32"),
+                                  graph=not args.no_graph)
 
     if args.mode == "train":
         # warm-up must cover whole horizons so that MIOpen tuning / allocator growth of the FIRST update
@@ -212,12 +219,23 @@ def main():
     elapsed = time.perf_counter() - t0
     mv_ms, ray_ms, launches = env.read_timing()
     env.enable_timing(False)
+    kernel_timing_note = "HIP events around the kernels of every 8th step of the timed region"
+    if launches == 0:
+        # the tick was replayed as a hipGraph (the library's event records are not part of a captured tick): time the
+        # two env kernels in a short eager pass AFTER the timed region instead
+        env.enable_timing(1)
+        for k in range(64):
+            env.step(pool[k % len(pool)])
+        torch.cuda.synchronize()
+        mv_ms, ray_ms, launches = env.read_timing()
+        env.enable_timing(False)
+        kernel_timing_note = "HIP events around the env kernels in a separate eager pass of 64 ticks after the timed region"
 
     # side figure (single GPU, env mode only, outside the timed region above): the same world driven by the
     # fp32 policy instead of the action pool -- SURVEY 8d (ii).  `--mode rollout|train` time these properly.
     if args.mode == "env" and world_size == 1 and not args.no_extra:
         from mrca.trainer import make_bench_step
-        roll = make_bench_step(env, "rollout", None)
+        roll = make_bench_step(env, "rollout", None, fused=True, graph=True)
         for k in range(10):
             roll(k)
         torch.cuda.synchronize()
@@ -227,8 +245,9 @@ def main():
             roll(k)
         torch.cuda.synchronize()
         extra["rollout_side_figure"] = {"value": N * n_roll / (time.perf_counter() - tr0), "unit": "agent-steps/s",
-                                        "note": "env + fp32 CNNPolicy inference per tick, 100 ticks after 10 warm-up "
-                                                "ticks; not part of `value`"}
+                                        "note": "env + fp32 CNNPolicy inference per tick (HIP conv front end + batched "
+                                                "GEMMs, tick replayed as a hipGraph), 100 ticks after 10 warm-up ticks; not "
+                                                "part of `value`"}
 
     # multi-GPU side figure: a few PPO updates with the flat-bucket gradient all-reduce on the measured path
     # (the env tick itself needs no collective, so `value` alone would never touch RCCL)
@@ -280,15 +299,28 @@ def main():
                                    f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}",
                        "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode,
                        "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
+                       "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
+                       if args.mode != "env" else None,
+                       "tick_as_hipgraph": (not args.no_graph) if args.mode != "env" else None,
                        "ppo_update_dtype": args.update_dtype if args.mode == "train" else None},
             "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "bytes_per_agent_step": BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
-                         "launches_timed": launches,
+                         "launches_timed": launches, "kernel_timing": kernel_timing_note,
                          "note": "HBM is the nominal roof (SURVEY 8d); the kernel is bound by VALU issue and dependent L2 lookups in the ray march, see DESIGN.md 5"},
         }
+        if args.mode == "rollout":
+            # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2
+            # 1.57 + fc1 4.19 + fc2/heads 0.13, both towers), fp32 on the MFMA / vector pipes (157.3 TFLOP/s dense)
+            flops = 6.4e6 * N
+            tick_s = elapsed / args.steps
+            out["roofline_rollout"] = {
+                "bound": "mfma", "achieved": flops / tick_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": flops / tick_s / 1e12 / 157.3,
+                "note": "policy FLOPs of one tick / the WHOLE tick time (env kernels, sampling and launch gaps "
+                        "included): a lower bound on the policy kernels' own rate; fp32 in, fp32 accumulate"}
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(args.scenario, args.worlds, args.robots_per_world)
             out["cpu_baseline"]["reference_structural_cap"] = "240 agent-steps/s (24 robots x 10 Hz, stageros.cpp:819-828)"

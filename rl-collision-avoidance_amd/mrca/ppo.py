@@ -86,6 +86,20 @@ class RolloutBuffer:
         self.reward[t].copy_(reward)
         self.done[t].copy_(done)
 
+    # the same two stores with the row given as a DEVICE index tensor (int64[1]): no host value enters the launch, so a
+    # whole tick can be captured once as a hipGraph and replayed for every row of the horizon
+    def store_state_at(self, t_idx, obs, goal, speed, action, logprob, value):
+        self.obs.index_copy_(0, t_idx, obs.unsqueeze(0))
+        self.goal.index_copy_(0, t_idx, goal.unsqueeze(0))
+        self.speed.index_copy_(0, t_idx, speed.unsqueeze(0))
+        self.action.index_copy_(0, t_idx, action.unsqueeze(0))
+        self.logprob.index_copy_(0, t_idx, logprob.view(1, -1, 1))
+        self.value.index_copy_(0, t_idx, value.view(1, -1))
+
+    def store_outcome_at(self, t_idx, reward, done):
+        self.reward.index_copy_(0, t_idx, reward.unsqueeze(0))
+        self.done.index_copy_(0, t_idx, done.unsqueeze(0))
+
 
 def generate_train_data(rewards, gamma, values, last_value, dones, lam):
     """model/ppo.py:122-139 on device through the HIP GAE kernel (mrca_gae)."""

@@ -32,6 +32,7 @@ class HParams:
     action_bound: tuple = ((0.0, -1.0), (1.0, 1.0))   # ppo_stage1.py:170
     inference_dtype: object = None    # None = fp32 like the reference; torch.bfloat16 = opt-in fast rollouts
     update_dtype: object = None       # autocast dtype of the PPO update's forward/backward (opt-in)
+    graph_tick: bool = False          # capture the rollout tick (policy + sampling + env tick + buffer stores) in a hipGraph
     rollout_fused: bool = False       # rollout inference through the HIP conv front end (net.mean_value_fused, fp32)
     kl_target: float = 0.0            # > 0: KL-adaptive learning rate (ppo.KLAdaptiveLR; opt-in, large-batch regime)
     lr_max: float = 1e-3
@@ -65,23 +66,63 @@ class Stage1Trainer:
         self.global_update = 0
         self.loss_log = []
         self.started = False
+        self._graph = None
+        self._t_idx = torch.zeros(1, dtype=torch.int64, device=dev)     # buffer row of the next tick, on the device
 
     def start(self):
         self.env.reset()
         self.started = True
 
-    def tick(self):
-        """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
+    def _tick_body(self):
+        """The device work of one tick with the buffer row taken from ``self._t_idx`` (a device tensor): nothing in
+        here depends on a host value, so it can be captured as a hipGraph."""
         env, hp, buf = self.env, self.hp, self.buffer
         v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
                                                     hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused)
-        buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v)
+        buf.store_state_at(self._t_idx, env.obs, env.local_goal, env.speed, a, logprob, v)
         env.step(scaled.contiguous())
-        buf.store_outcome(self.t, env.reward, env.done)
+        buf.store_outcome_at(self._t_idx, env.reward, env.done)
+        self._t_idx.add_(1)
+
+    def _capture(self):
+        """One tick as a hipGraph: ~50 launches (policy layers, sampling, the two env kernels, eight buffer stores)
+        become one graph launch.  The policy's parameters, the env's arena and the rollout buffer are all at fixed
+        addresses, the action-noise generator is registered with the graph, the buffer row is a device counter."""
+        if hasattr(self.env, "enable_timing"):
+            self.env.enable_timing(False)               # event records cannot be part of the captured tick
+        if self.hp.rollout_fused:
+            self.policy.refresh_rollout_cache()
+        side = torch.cuda.Stream(device=self.env.device)
+        side.wait_stream(torch.cuda.current_stream(self.env.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):                          # warm-up on the capture stream (lazy inits, workspace allocs)
+                self._tick_body()
+        torch.cuda.current_stream(self.env.device).wait_stream(side)
+        self._t_idx.fill_(self.t)
+        g = torch.cuda.CUDAGraph()
+        g.register_generator_state(self.gen)
+        with torch.cuda.graph(g, stream=side):
+            self._tick_body()
+        self._graph = g
+
+    def tick(self):
+        """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
+        env, hp, buf = self.env, self.hp, self.buffer
+        if hp.graph_tick:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
+                                                        hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused)
+            buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v)
+            env.step(scaled.contiguous())
+            buf.store_outcome(self.t, env.reward, env.done)
         self.t += 1
         if self.t == hp.horizon:
             self.update()
             self.t = 0
+            self._t_idx.zero_()
 
     def update(self):
         env, hp, buf = self.env, self.hp, self.buffer
@@ -114,11 +155,34 @@ class Stage1Trainer:
             self.tick()
 
 
-def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, update_dtype=None, fused=False):
+def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, update_dtype=None, fused=False,
+                    graph=False):
     """bench.py --mode rollout|train: returns step_fn(k) doing one tick for all robots."""
-    hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype, update_dtype=update_dtype, rollout_fused=fused)
+    hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype, update_dtype=update_dtype, rollout_fused=fused,
+                 graph_tick=graph)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0)
     tr.started = True  # bench.py resets the env itself
+    if mode == "rollout" and graph:
+        # the rollout of bench.py: policy + sampling + env tick (no buffer stores), captured once, replayed per tick
+        if fused:
+            tr.policy.refresh_rollout_cache()
+
+        def body():
+            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, env.obs, env.local_goal, env.speed,
+                                                      hp.action_bound, tr.gen, hp.inference_dtype, hp.rollout_fused)
+            env.step(scaled.contiguous())
+        env.enable_timing(False)
+        side = torch.cuda.Stream(device=env.device)
+        side.wait_stream(torch.cuda.current_stream(env.device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream(env.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        g.register_generator_state(tr.gen)
+        with torch.cuda.graph(g, stream=side):
+            body()
+        return lambda _k: g.replay()
     if mode == "rollout":
         def step_fn(_k):
             _v, _a, _lp, scaled = ppo.generate_action(tr.policy, env.obs, env.local_goal, env.speed,

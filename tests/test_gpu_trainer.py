@@ -101,3 +101,37 @@ def test_train_cli_checkpoint_and_resume(hip, tmp_path, monkeypatch):
     train.main(["--stage", "1", "--worlds", "2", "--robots-per-world", "6", "--updates", "1", "--save-every", "1",
                 "--batch-size", "256"])
     assert os.path.exists(tmp_path / "policy" / "Stage1_3")      # global_update continued from 2
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_graph_captured_tick_fills_the_buffer_consistently(hip, fused):
+    """The rollout tick replayed as a hipGraph (device-side buffer row, registered noise generator): every stored row
+    must be self-consistent -- the stored log-probability is the policy's density of the stored action at the stored
+    state, the stored value its value -- and rows, rewards and done flags must line up with the env's own fields."""
+    from mrca.trainer import HParams, Stage1Trainer
+    sc = S.stage1(num_worlds=4, robots_per_world=8, seed=5)
+    env = hip.VecStageWorld(sc)
+    hp = HParams(horizon=12, batch_size=128, epoch=1, graph_tick=True, rollout_fused=fused)
+    tr = Stage1Trainer(env, hp=hp, seed=2)
+    tr.start()
+    for _ in range(11):
+        tr.tick()
+    torch.cuda.synchronize()
+    buf = tr.buffer
+    assert tr.global_update == 0 and int(tr._t_idx) == 11
+    with torch.no_grad():
+        for t in range(11):
+            v, lp, _ent = tr.policy.evaluate_actions(buf.obs[t], buf.goal[t], buf.speed[t], buf.action[t])
+            assert float((lp - buf.logprob[t]).abs().max()) < 2e-5, t
+            assert float((v.view(-1) - buf.value[t]).abs().max()) < 1e-4, t
+    assert torch.equal(buf.reward[10], env.reward) and torch.equal(buf.done[10], env.done)
+    assert float(buf.action[:11].std()) > 0.3                    # the noise generator advances between replays
+    assert not torch.equal(buf.action[3], buf.action[4])
+    # consecutive rows of a robot that did not restart share two of their three frames
+    keep = ~(buf.done[4].bool())
+    assert torch.equal(buf.obs[5][keep][:, :2], buf.obs[4][keep][:, 1:])
+    tr.tick()                                                    # 12th tick: the update runs, the row counter rewinds
+    assert tr.global_update == 1 and int(tr._t_idx) == 0
+    tr.tick()
+    assert int(tr._t_idx) == 1
+    env.close()
