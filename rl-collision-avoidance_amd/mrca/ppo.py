@@ -57,14 +57,59 @@ def generate_action_no_sampling(policy, obs, goal, speed, action_bound, fused=Fa
 
 
 # ---------------------------------------------------------------------------------------------
+class FrameRows:
+    """The observation stacks of a rollout as a lazily gathered [T*N, frames, beams] tensor: ``rows[index]`` builds
+    the minibatch from the one-frame-per-tick store (RolloutBuffer, ``single_frame=True``).  Supports the two ways
+    the update addresses its memory: integer index tensors and a boolean keep-mask (Stage-2 filtering)."""
+
+    def __init__(self, frames, fidx, rowmap=None):
+        self.frames, self.fidx, self.rowmap = frames, fidx, rowmap      # [T+2,N,B], [T,N,F] int64, optional [n'] -> t*N+i
+        self.N = fidx.shape[1]
+
+    @property
+    def shape(self):
+        n = self.fidx.shape[0] * self.N if self.rowmap is None else self.rowmap.numel()
+        return (n, self.fidx.shape[2], self.frames.shape[2])
+
+    def __getitem__(self, index):
+        if index.dtype == torch.bool:
+            base = torch.arange(self.fidx.shape[0] * self.N, device=index.device) if self.rowmap is None else self.rowmap
+            return FrameRows(self.frames, self.fidx, base[index])
+        flat = index if self.rowmap is None else self.rowmap[index]
+        t, i = flat // self.N, flat % self.N
+        fi = self.fidx[t, i]                                   # [mb, F]
+        return self.frames[fi, i.unsqueeze(1)]                 # [mb, F, B]
+
+    def materialise(self):
+        T, N, Fr = self.fidx.shape
+        i = torch.arange(N, device=self.fidx.device).view(1, N, 1).expand(T, N, Fr)
+        return self.frames[self.fidx, i]                       # [T, N, F, B]
+
+
 class RolloutBuffer:
     """Preallocated [T, N, ...] device tensors replacing the list-of-tuples ``buff`` +
-    ``transform_buffer`` (ppo_stage1.py:102-103, model/ppo.py:22-54)."""
+    ``transform_buffer`` (ppo_stage1.py:102-103, model/ppo.py:22-54).
 
-    def __init__(self, horizon, num_env, frames, beams, device, act_size=2):
+    ``single_frame=True`` stores ONE lidar frame per tick instead of the whole 3-frame stack (the stack at tick t
+    shares two frames with the stack at t-1: SURVEY 8a a13): ``frames[T+2,N,B]`` (rows 0, 1 = the two older frames of
+    the first tick's stack) plus, per tick and robot, which rows make up its stack (``fidx``; a robot that restarted
+    has all three pointing at its fresh scan, ppo_stage1.py:59-60).  A third of the write traffic per tick and of the
+    3.2 GB the stacks of a 128 x 4096 horizon take; minibatches are gathered through ``FrameRows``."""
+
+    def __init__(self, horizon, num_env, frames, beams, device, act_size=2, single_frame=False):
         T, N = horizon, num_env
         f32 = dict(dtype=torch.float32, device=device)
-        self.obs = torch.empty(T, N, frames, beams, **f32)
+        self.single_frame = single_frame
+        if single_frame:
+            self.frames = torch.empty(T + 2, N, beams, **f32)
+            self.fidx = torch.zeros(T, N, frames, dtype=torch.int64, device=device)
+            self._cur = torch.zeros(N, frames, dtype=torch.int64, device=device)
+            self._first = torch.arange(frames, dtype=torch.int64, device=device).view(1, frames)
+            self._two = torch.full((1,), frames - 1, dtype=torch.int64, device=device)
+            self._rows01 = torch.arange(frames - 1, dtype=torch.int64, device=device)
+            self.obs = None
+        else:
+            self.obs = torch.empty(T, N, frames, beams, **f32)
         self.goal = torch.empty(T, N, 2, **f32)
         self.speed = torch.empty(T, N, 2, **f32)
         self.action = torch.empty(T, N, act_size, **f32)
@@ -72,10 +117,40 @@ class RolloutBuffer:
         self.done = torch.empty(T, N, dtype=torch.uint8, device=device)
         self.logprob = torch.empty(T, N, 1, **f32)
         self.value = torch.empty(T, N, **f32)
-        self.horizon, self.num_env = T, N
+        self.horizon, self.num_env, self.nframes = T, N, frames
 
-    def store_state(self, t, obs, goal, speed, action, logprob, value):
-        self.obs[t].copy_(obs)
+    # ---- observation stacks
+    def begin_horizon(self, obs):
+        """single_frame: the older frames of the stack the first tick of a horizon will see (call before tick 0)."""
+        if self.single_frame:
+            self.frames[: self.nframes - 1].copy_(obs[:, : self.nframes - 1].transpose(0, 1))
+            self._cur.copy_(self._first.expand_as(self._cur))
+
+    def _store_obs_at(self, t_idx, obs, fresh):
+        if not self.single_frame:
+            self.obs.index_copy_(0, t_idx, obs.unsqueeze(0))
+            return
+        row = t_idx + self._two                                         # the newest frame of tick t lives in row t+F-1
+        self.frames.index_copy_(0, row, obs[:, -1].unsqueeze(0))
+        shifted = torch.cat((self._cur[:, 1:], row.view(1, 1).expand(self.num_env, 1)), dim=1)
+        # tick 0 of a horizon: rows 0..F-1 whatever the flags say (begin_horizon copied the real older frames)
+        at_start = (t_idx == 0).view(1, 1)
+        restarted = fresh.bool().view(-1, 1) & ~at_start
+        self._cur.copy_(torch.where(at_start, self._first, torch.where(restarted, row.view(1, 1), shifted)))
+        self.fidx.index_copy_(0, t_idx, self._cur.unsqueeze(0))
+
+    def obs_rows(self):
+        """[T*N, F, B] view of the stored stacks, however they are stored."""
+        if self.single_frame:
+            return FrameRows(self.frames, self.fidx)
+        T, N = self.horizon, self.num_env
+        return self.obs.reshape(T * N, self.nframes, -1)
+
+    def store_state(self, t, obs, goal, speed, action, logprob, value, fresh=None):
+        if self.single_frame:
+            self._store_obs_at(torch.tensor([t], dtype=torch.int64, device=obs.device), obs, fresh)
+        else:
+            self.obs[t].copy_(obs)
         self.goal[t].copy_(goal)
         self.speed[t].copy_(speed)
         self.action[t].copy_(action)
@@ -88,8 +163,8 @@ class RolloutBuffer:
 
     # the same two stores with the row given as a DEVICE index tensor (int64[1]): no host value enters the launch, so a
     # whole tick can be captured once as a hipGraph and replayed for every row of the horizon
-    def store_state_at(self, t_idx, obs, goal, speed, action, logprob, value):
-        self.obs.index_copy_(0, t_idx, obs.unsqueeze(0))
+    def store_state_at(self, t_idx, obs, goal, speed, action, logprob, value, fresh=None):
+        self._store_obs_at(t_idx, obs, fresh)
         self.goal.index_copy_(0, t_idx, goal.unsqueeze(0))
         self.speed.index_copy_(0, t_idx, speed.unsqueeze(0))
         self.action.index_copy_(0, t_idx, action.unsqueeze(0))
@@ -253,12 +328,13 @@ def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entrop
                       num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *, value_coef=20.0,
                       index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None, kl_ctl=None):
     """model/ppo.py:143-194.  ``memory`` = (obss, goals, speeds, actions, logprobs, targets, values,
-    rewards, advs) as device tensors shaped [T, N, ...]."""
+    rewards, advs) as device tensors shaped [T, N, ...] (obss may be a FrameRows: one stored frame per tick)."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
     mean, std = _global_mean_std(advs, dist)
     advs = (advs - mean) / std
     n = num_step * num_env
-    flat = (obss.reshape(n, frames, obs_size), goals.reshape(n, 2), speeds.reshape(n, 2),
+    obs_rows = obss if isinstance(obss, FrameRows) else obss.reshape(n, frames, obs_size)
+    flat = (obs_rows, goals.reshape(n, 2), speeds.reshape(n, 2),
             actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1), advs.reshape(n, 1))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, False, value_coef,
                 index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl)
@@ -277,7 +353,8 @@ def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch
     keep = torch.ones(n, dtype=torch.bool, device=advs.device)
     if filter_index is not None and len(filter_index):
         keep[torch.as_tensor(filter_index, device=advs.device, dtype=torch.long)] = False
-    flat = tuple(x[keep] for x in (obss.reshape(n, frames, obs_size), goals.reshape(n, 2), speeds.reshape(n, 2),
+    obs_rows = obss if isinstance(obss, FrameRows) else obss.reshape(n, frames, obs_size)
+    flat = tuple(x[keep] for x in (obs_rows, goals.reshape(n, 2), speeds.reshape(n, 2),
                                    actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1),
                                    advs.reshape(n, 1)))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, True, value_coef,

@@ -32,6 +32,7 @@ class HParams:
     action_bound: tuple = ((0.0, -1.0), (1.0, 1.0))   # ppo_stage1.py:170
     inference_dtype: object = None    # None = fp32 like the reference; torch.bfloat16 = opt-in fast rollouts
     update_dtype: object = None       # autocast dtype of the PPO update's forward/backward (opt-in)
+    single_frame_buffer: bool = True  # rollout buffer keeps one lidar frame per tick, not the 3-frame stack (ppo.RolloutBuffer)
     graph_tick: bool = False          # capture the rollout tick (policy + sampling + env tick + buffer stores) in a hipGraph
     rollout_fused: bool = False       # rollout inference through the HIP conv front end (net.mean_value_fused, fp32)
     kl_target: float = 0.0            # > 0: KL-adaptive learning rate (ppo.KLAdaptiveLR; opt-in, large-batch regime)
@@ -58,7 +59,7 @@ class Stage1Trainer:
         self.flat_grads = ppo.FlatGrads(self.policy.parameters())
         self.kl_ctl = ppo.KLAdaptiveLR(self.hp.kl_target, lr_max=self.hp.lr_max) if self.hp.kl_target > 0 else None
         self.buffer = ppo.RolloutBuffer(self.hp.horizon, env.N, self.hp.laser_hist, self.hp.obs_size, dev,
-                                        self.hp.act_size)
+                                        self.hp.act_size, single_frame=self.hp.single_frame_buffer)
         self.gen = torch.Generator(device=dev)
         rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
         self.gen.manual_seed(seed * 1000 + rank)
@@ -79,7 +80,7 @@ class Stage1Trainer:
         env, hp, buf = self.env, self.hp, self.buffer
         v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
                                                     hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused)
-        buf.store_state_at(self._t_idx, env.obs, env.local_goal, env.speed, a, logprob, v)
+        buf.store_state_at(self._t_idx, env.obs, env.local_goal, env.speed, a, logprob, v, env.fresh)
         env.step(scaled.contiguous())
         buf.store_outcome_at(self._t_idx, env.reward, env.done)
         self._t_idx.add_(1)
@@ -108,6 +109,8 @@ class Stage1Trainer:
     def tick(self):
         """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
         env, hp, buf = self.env, self.hp, self.buffer
+        if self.t == 0:
+            buf.begin_horizon(env.obs)      # one-frame store: the older frames of the stack the first tick sees
         if hp.graph_tick:
             if self._graph is None:
                 self._capture()
@@ -115,7 +118,7 @@ class Stage1Trainer:
         else:
             v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
                                                         hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused)
-            buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v)
+            buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v, env.fresh)
             env.step(scaled.contiguous())
             buf.store_outcome(self.t, env.reward, env.done)
         self.t += 1
@@ -130,7 +133,7 @@ class Stage1Trainer:
             _mean, last_v = (self.policy.mean_value_fused if hp.rollout_fused else self.policy.mean_value)(
                 env.obs, env.local_goal, env.speed)
         targets, advs = ppo.generate_train_data(buf.reward, hp.gamma, buf.value, last_v, buf.done, hp.lam)
-        memory = (buf.obs, buf.goal, buf.speed, buf.action, buf.logprob, targets, buf.value, buf.reward, advs)
+        memory = (buf.obs_rows(), buf.goal, buf.speed, buf.action, buf.logprob, targets, buf.value, buf.reward, advs)
         kw = dict(policy=self.policy, optimizer=self.optimizer, batch_size=hp.batch_size, memory=memory,
                   epoch=hp.epoch, coeff_entropy=hp.coeff_entropy, clip_value=hp.clip_value, num_step=hp.horizon,
                   num_env=env.N, frames=hp.laser_hist, obs_size=hp.obs_size, act_size=hp.act_size,

@@ -30,7 +30,8 @@ def test_stage1_trainer_one_update_and_gae_consistency(hip):
     assert tr.global_update == 0
     buf = tr.buffer
     # what the buffer holds at t is the state the action was computed from
-    assert torch.isfinite(buf.obs[:15]).all() and float(buf.obs[:15].abs().max()) <= 0.5
+    stacks = buf.obs_rows().materialise()
+    assert torch.isfinite(stacks[:15]).all() and float(stacks[:15].abs().max()) <= 0.5
     tr.run(1)                                   # 16th tick triggers the update
     assert tr.global_update == 1 and len(tr.loss_log) == 2 * 4     # 512 samples / 128 x 2 epochs
     after = torch.cat([p.detach().reshape(-1) for p in tr.policy.parameters()])
@@ -119,9 +120,10 @@ def test_graph_captured_tick_fills_the_buffer_consistently(hip, fused):
     torch.cuda.synchronize()
     buf = tr.buffer
     assert tr.global_update == 0 and int(tr._t_idx) == 11
+    stacks = buf.obs_rows().materialise()
     with torch.no_grad():
         for t in range(11):
-            v, lp, _ent = tr.policy.evaluate_actions(buf.obs[t], buf.goal[t], buf.speed[t], buf.action[t])
+            v, lp, _ent = tr.policy.evaluate_actions(stacks[t], buf.goal[t], buf.speed[t], buf.action[t])
             assert float((lp - buf.logprob[t]).abs().max()) < 2e-5, t
             assert float((v.view(-1) - buf.value[t]).abs().max()) < 1e-4, t
     assert torch.equal(buf.reward[10], env.reward) and torch.equal(buf.done[10], env.done)
@@ -129,9 +131,38 @@ def test_graph_captured_tick_fills_the_buffer_consistently(hip, fused):
     assert not torch.equal(buf.action[3], buf.action[4])
     # consecutive rows of a robot that did not restart share two of their three frames
     keep = ~(buf.done[4].bool())
-    assert torch.equal(buf.obs[5][keep][:, :2], buf.obs[4][keep][:, 1:])
+    assert torch.equal(stacks[5][keep][:, :2], stacks[4][keep][:, 1:])
     tr.tick()                                                    # 12th tick: the update runs, the row counter rewinds
     assert tr.global_update == 1 and int(tr._t_idx) == 0
     tr.tick()
     assert int(tr._t_idx) == 1
     env.close()
+
+
+def test_single_frame_buffer_equals_the_stack_buffer(hip):
+    """Two trainers on identical envs and seeds, one storing the whole 3-frame stack per tick, the other one frame per
+    tick + the row indices: every minibatch the update would draw must be identical, restarts included."""
+    from mrca.trainer import HParams, Stage1Trainer
+    sc = S.stage1(num_worlds=4, robots_per_world=16, seed=8)
+    envs = [hip.VecStageWorld(sc) for _ in range(2)]
+    trs = [Stage1Trainer(e, hp=HParams(horizon=40, batch_size=512, epoch=1, single_frame_buffer=sf), seed=4)
+           for e, sf in zip(envs, (False, True))]
+    for tr in trs:
+        tr.start()
+    for _ in range(39):
+        for tr in trs:
+            tr.tick()
+    torch.cuda.synchronize()
+    a, b = trs[0].buffer, trs[1].buffer
+    assert int(a.done[:39].sum()) > 0                                   # robots did restart inside the horizon
+    assert torch.equal(a.action[:39], b.action[:39])
+    full = b.obs_rows().materialise()
+    assert torch.equal(full[:39], a.obs[:39])
+    idx = torch.randperm(39 * sc.num_robots, device="cuda")[:500]
+    assert torch.equal(b.obs_rows()[idx], a.obs_rows()[idx])
+    keep = torch.rand(40 * sc.num_robots, device="cuda") < 0.7
+    keep[39 * sc.num_robots:] = False
+    sub = torch.arange(int(keep.sum()), device="cuda")[::7]
+    assert torch.equal(b.obs_rows()[keep][sub], a.obs_rows()[keep][sub])
+    for e in envs:
+        e.close()

@@ -31,7 +31,7 @@ class CpuEnv:
         self.env = util.COracleEnv(sc)
         self.device = torch.device("cpu")
         self.N, self.R, self.W = sc.num_robots, sc.robots_per_world, sc.num_worlds
-        for k in util.STATE_FIELDS:
+        for k in util.STATE_FIELDS + ["fresh"]:
             setattr(self, k, torch.from_numpy(getattr(self.env, k)))
 
     def reset(self, mask=None, poses=None, goals=None):
