@@ -397,6 +397,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     // list while the others march (variants measured in profiles/: threads per robot, with / without that wave)
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
     v.ray_prep_wave = 1;
+    v.ray_sequential = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (!v.big && mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
@@ -449,13 +450,13 @@ static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool rec = env->timing > 0 && (env->step_count++ % env->timing) == 0 &&
                      env->ev_used + 3 <= (int)env->ev.size();
-    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 0], s));
-    mrca::launch_move(env->view, actions_dev, s);
-    mrca::launch_lidar_grid(env->view, s);
-    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
     mrca::EnvView v = env->view;
-    v.ray_first = first;
+    v.ray_first = first;      // the robots whose lidar outputs (scan, frame stack, local goal) this call produces
     v.ray_count = count;
+    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 0], s));
+    mrca::launch_move(v, actions_dev, s);
+    mrca::launch_lidar_grid(v, s);
+    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
     mrca::launch_raycast(v, /*only_fresh=*/0, s);
     if (rec) {
         HIP_TRY(hipEventRecord(env->ev[env->ev_used + 2], s));
@@ -499,11 +500,12 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 
 #if defined(MRCA_PROFILING)
 // Profiling build only (libmrca_env_prof.so): ablation switches (results are WRONG while bits 0-5 are set) and
-// launch-shape knobs (results unchanged): bits 8-10 = k > 0: 1 << (k-1) beams per marching thread; bit 11: no
-// dedicated preparation wave.
+// launch-shape knobs (results unchanged): bit 6: the frame-stack shift as a launch of its own; bits 8-10 = k > 0:
+// 1 << (k-1) beams per marching thread; bit 11: no dedicated preparation wave; bit 12: two beams marched one after the
+// other instead of in lock step.
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
-    env->view.debug_flags = flags & 0x3F;
+    env->view.debug_flags = flags & 0x7F;
     const int knob = (flags >> 8) & 7;
     if (knob) {
         const int shift = knob - 1;
@@ -515,6 +517,7 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
         env->view.ray_shift = (env->cfg.beams >= 256) ? 1 : 0;   // the product's launch shape
     }
     env->view.ray_prep_wave = (flags & 0x800) ? 0 : 1;
+    env->view.ray_sequential = (flags & 0x1000) ? 1 : 0;
     return MRCA_OK;
 }
 #endif

@@ -71,6 +71,7 @@ struct EnvView {
     uint32_t key0, key1;
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel marches 1 << ray_shift beams per thread in lock step
+    int32_t ray_sequential; // 1 (with ray_shift 1): the two beams of a thread are marched one after the other
     int32_t ray_prep_wave;  // 1: a dedicated wave prepares the neighbour list (blockDim = beams >> ray_shift + 64)
     int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
 };

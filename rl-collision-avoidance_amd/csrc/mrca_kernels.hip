@@ -127,8 +127,63 @@ struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
     }
 };
 
+// The frame-stack shift of the tick (ppo_stage1.py:87-89: popleft / append), frames 1.. -> 0.. for robots
+// [ray_first, ray_first + ray_count): two thirds of the observation traffic of a tick (33 MB at 4096 robots) and
+// independent of everything the tick computes -- a robot that restarts this tick gets all its frames rewritten by the
+// ray cast afterwards.  It therefore rides in the SAME launch as move_kernel (blocks behind the per-world ones):
+// the move kernel is one latency chain per world on 128 of 1024 SIMDs, and the copy streams through the rest of the
+// chip underneath it.  (Measured before, when the ray cast did the shift itself: the kernel's memory phase did not
+// overlap its own compute phase, 14 us of 33.)  A thread owns float4 columns: it loads them from every frame, then
+// stores them one frame down, so reads and writes of different threads never meet.
+__device__ __forceinline__ void shift_frames(const EnvView& e, int block, int nblocks, int tid, int nthreads) {
+    const int fstride = e.B >> 2;
+    const long long total = (long long)e.ray_count * fstride;
+    float4* base = reinterpret_cast<float4*>(e.obs) + (size_t)e.ray_first * e.F * fstride;
+    if (e.F == 3) {
+        // four columns in flight per thread (strided by the launch width, so every load instruction is coalesced)
+        const long long stride = (long long)nblocks * nthreads;
+        for (long long k0 = (long long)block * nthreads + tid; k0 < total; k0 += 4 * stride) {
+            const long long ka = k0, kb = k0 + stride, kc = k0 + 2 * stride, kd = k0 + 3 * stride;
+            const bool hb = kb < total, hc = kc < total, hd = kd < total;
+            float4* oa = base + (ka / fstride) * 3 * fstride + (ka % fstride);
+            float4* ob = base + ((hb ? kb : ka) / fstride) * 3 * fstride + ((hb ? kb : ka) % fstride);
+            float4* oc = base + ((hc ? kc : ka) / fstride) * 3 * fstride + ((hc ? kc : ka) % fstride);
+            float4* od = base + ((hd ? kd : ka) / fstride) * 3 * fstride + ((hd ? kd : ka) % fstride);
+            const float4 a1 = oa[fstride], a2 = oa[2 * fstride];
+            const float4 b1 = ob[fstride], b2 = ob[2 * fstride];
+            const float4 c1 = oc[fstride], c2 = oc[2 * fstride];
+            const float4 d1 = od[fstride], d2 = od[2 * fstride];
+            oa[0] = a1;
+            oa[fstride] = a2;
+            if (hb) {
+                ob[0] = b1;
+                ob[fstride] = b2;
+            }
+            if (hc) {
+                oc[0] = c1;
+                oc[fstride] = c2;
+            }
+            if (hd) {
+                od[0] = d1;
+                od[fstride] = d2;
+            }
+        }
+    } else {
+        for (long long k = (long long)block * nthreads + tid; k < total; k += (long long)nblocks * nthreads) {
+            float4* ob = base + (k / fstride) * e.F * fstride + (k % fstride);
+            for (int f = 0; f + 1 < e.F; ++f) ob[f * fstride] = ob[(f + 1) * fstride];
+        }
+    }
+}
+
+__global__ void shift_frames_kernel(EnvView e) { shift_frames(e, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x); }
+
 __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
+    if ((int)blockIdx.x >= e.W) {   // the blocks behind the per-world ones: this tick's frame-stack shift
+        shift_frames(e, blockIdx.x - e.W, gridDim.x - e.W, threadIdx.x, kWave);
+        return;
+    }
     const int world = blockIdx.x;
     const int lane = threadIdx.x;
     const bool valid = lane < e.R;
@@ -474,7 +529,7 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
 // no difference.)  What a chain of dependent lookups wants is more of them in flight: each thread marches its
 // K beams in lock step (grid_march_skip_n), so one wait covers K lookups.
-template <int K, bool BIG>
+template <int K, bool BIG, bool SEQ>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
@@ -527,28 +582,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const bool wide = tid < (e.B >> 2);
     const int fstride = e.B >> 2;
     float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B);
-    // The frame-stack shift (ppo_stage1.py:87-89: popleft / append) does not depend on this tick's ranges at all:
-    // the preparation wave moves frames 1.. down to 0.. on its own -- requested here, in the same round trip as its
-    // neighbour candidate, stored as soon as they arrive -- while the other waves march.  The marching waves never
-    // wait on an HBM load and carry no frame registers; they only append the newest frame.  (A robot that started
-    // an episode gets all its frames from the epilogue instead.)
-    const bool shifter = is_prep && !fresh && e.F == 3;
-    const int chunks = (fstride + kWave - 1) / kWave;          // float4 chunks per lane and frame (2 at 512 beams)
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const bool sh0 = shifter && chunks <= 2 && pl < fstride;            // this lane's first / second column
-    const bool sh1 = shifter && chunks <= 2 && pl + kWave < fstride;
-    const int j0 = sh0 ? pl : 0, j1 = sh1 ? pl + kWave : 0;
-    float4 keep1a = zero4, keep2a = zero4, keep1b = zero4, keep2b = zero4;
-    if (sh0) {
-        keep1a = ob4[fstride + j0];
-        keep2a = ob4[2 * fstride + j0];
-    }
-    if (sh1) {
-        keep1b = ob4[fstride + j1];
-        keep2b = ob4[2 * fstride + j1];
-    }
-    // --- preparation wave: compact the world's other robots within lidar reach into LDS, each with the
-    //     (conservative) interval of beams that can touch it.  It alone touches the masks before the barrier.
+    // (The frame-stack shift -- ppo_stage1.py:87-89: popleft / append -- does not depend on this tick's ranges: it ran
+    // before this kernel, next to the move kernel, see shift_frames.  Here only the newest frame is appended.)
     // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
     // exceed the 64 a chunk holds: the preparation wave walks the nine bucket ranges 64 entries at a time and hands
     // the marching threads one chunk of <= 64 neighbours per barrier pair (see the chunk loop below)
@@ -634,21 +669,6 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             for (int b = iv.x + pl; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
         }
       }
-        // frame-stack shift: a lane only ever touches "its" float4 columns, so reads and writes of different
-        // lanes never meet, and within a lane every store waits for the loads it depends on
-        if (shifter && chunks <= 2) {
-            if (sh0) {
-                ob4[j0] = keep1a;
-                ob4[fstride + j0] = keep2a;
-            }
-            if (sh1) {
-                ob4[j1] = keep1b;
-                ob4[fstride + j1] = keep2b;
-            }
-        } else if (is_prep && !fresh) {   // any other stack depth / beam count: frame by frame, column by column
-            for (int j = pl; j < fstride; j += kWave)
-                for (int f = 0; f + 1 < e.F; ++f) ob4[f * fstride + j] = ob4[(f + 1) * fstride + j];
-        }
     }
     // --- the march: K beams per thread in lock step
     float dx[K], dy[K], rng[K];
@@ -666,7 +686,12 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         org.ix0 = (int)floorf(org.fx);
         org.iy0 = (int)floorf(org.fy);
         org.v0 = __float_as_uint(hd.z);
-        grid_march_skip_n<K>(field, e.g, org, dx, dy, kRangeMax, rng);
+        if constexpr (K == 1 || SEQ) {   // one ray at a time: the hand-tuned single-ray loop (54 VALU per jump)
+#pragma unroll
+            for (int k = 0; k < K; ++k) rng[k] = grid_march_skip(field, e.g, org, dx[k], dy[k], kRangeMax);
+        } else {                         // K rays in lock step: K lookups in flight per wait
+            grid_march_skip_n<K>(field, e.g, org, dx, dy, kRangeMax, rng);
+        }
     }
     __syncthreads();  // neighbour list ready (the preparation wave built it while the others marched)
     if constexpr (!BIG) {
@@ -715,7 +740,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         if (fresh) {
             for (int f = 0; f < e.F; ++f) ob4[f * fstride + tid] = o4;
         } else {
-            ob4[(e.F - 1) * fstride + tid] = o4;      // frames below were shifted by the preparation wave
+            ob4[(e.F - 1) * fstride + tid] = o4;      // the older frames were shifted down by shift_frames
         }
     }
     if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
@@ -1025,12 +1050,24 @@ size_t move_lds_bytes(const EnvView& e) {
     return (size_t)kWave * rows * words * 4 + 2 * kWave * sizeof(int);
 }
 
+// blocks of 64 threads x 4 float4 columns per pass for the frame-stack shift that rides behind the move kernel
+static int shift_blocks(const EnvView& e) {
+    const long long cols = (long long)e.ray_count * (e.B >> 2);
+    long long nb = (cols + kWave * 4 - 1) / (kWave * 4);
+    if (nb > 8192) nb = 8192;
+    return e.F > 1 ? (int)nb : 0;
+}
+
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
     if (!e.big) {
-        hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), move_lds_bytes(e), s, e, actions);
+        const int extra = MRCA_DBG(e, 64) ? 0 : shift_blocks(e);
+        hipLaunchKernelGGL(move_kernel, dim3(e.W + extra), dim3(kWave), move_lds_bytes(e), s, e, actions);
+        if (MRCA_DBG(e, 64) && shift_blocks(e) > 0)      // profiling: the shift as a launch of its own, after the move
+            hipLaunchKernelGGL(shift_frames_kernel, dim3(shift_blocks(e)), dim3(kWave), 0, s, e);
         return;
     }
     const int bs = 256, nb = (e.N + bs - 1) / bs;
+    if (shift_blocks(e) > 0) hipLaunchKernelGGL(shift_frames_kernel, dim3(shift_blocks(e)), dim3(kWave), 0, s, e);
     (void)hipMemsetAsync(e.bw_chead, 0xFF, sizeof(int32_t) * (size_t)(e.bw_cmask + 1), s);
     hipLaunchKernelGGL(bw_integrate_kernel, dim3(nb), dim3(bs), 0, s, e, actions);
     hipLaunchKernelGGL(bw_collide_kernel, dim3(nb), dim3(bs), 0, s, e);
@@ -1061,19 +1098,25 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
     const size_t lds = ray_lds_bytes(e);
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
+    const bool seq = e.ray_sequential != 0;
+#define MRCA_RAY(K, BIG, SEQ) hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, e, only_fresh)
     if (e.big) {
         switch (e.ray_shift) {
-            case 0: hipLaunchKernelGGL((raycast_kernel<1, true>), grid, dim3(threads), lds, s, e, only_fresh); break;
-            case 1: hipLaunchKernelGGL((raycast_kernel<2, true>), grid, dim3(threads), lds, s, e, only_fresh); break;
-            default: hipLaunchKernelGGL((raycast_kernel<4, true>), grid, dim3(threads), lds, s, e, only_fresh); break;
+            case 0: MRCA_RAY(1, true, false); break;
+            case 1: MRCA_RAY(2, true, false); break;
+            default: MRCA_RAY(4, true, false); break;
         }
         return;
     }
     switch (e.ray_shift) {
-        case 0: hipLaunchKernelGGL((raycast_kernel<1, false>), grid, dim3(threads), lds, s, e, only_fresh); break;
-        case 1: hipLaunchKernelGGL((raycast_kernel<2, false>), grid, dim3(threads), lds, s, e, only_fresh); break;
-        default: hipLaunchKernelGGL((raycast_kernel<4, false>), grid, dim3(threads), lds, s, e, only_fresh); break;
+        case 0: MRCA_RAY(1, false, false); break;
+        case 1:
+            if (seq) MRCA_RAY(2, false, true);
+            else MRCA_RAY(2, false, false);
+            break;
+        default: MRCA_RAY(4, false, false); break;
     }
+#undef MRCA_RAY
 }
 
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,

@@ -1,0 +1,48 @@
+"""Several batched worlds of DIFFERENT scenarios behind one VecStageWorld-like surface, for curricula that mix
+scenarios under one policy (e.g. Stage-2 worlds + circle worlds).  The envs step one after another on the same
+stream; the per-robot fields the learner reads are concatenated into preallocated tensors after every tick."""
+import torch
+
+_FIELDS = ("obs", "local_goal", "speed", "reward", "done", "result", "live", "fresh", "first_result")
+
+
+class ConcatEnv:
+    def __init__(self, envs):
+        self.envs = list(envs)
+        self.device = self.envs[0].device
+        self.N = sum(e.N for e in self.envs)
+        self.bounds = []
+        lo = 0
+        for e in self.envs:
+            self.bounds.append((lo, lo + e.N))
+            lo += e.N
+        for k in _FIELDS:
+            ref = getattr(self.envs[0], k)
+            setattr(self, k, torch.empty((self.N,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=self.device))
+        self._gather()
+
+    def _gather(self):
+        for k in _FIELDS:
+            out = getattr(self, k)
+            for e, (lo, hi) in zip(self.envs, self.bounds):
+                out[lo:hi].copy_(getattr(e, k))
+
+    def reset(self):
+        for e in self.envs:
+            e.reset()
+        self._gather()
+        return self.obs, self.local_goal, self.speed
+
+    def step(self, actions):
+        for e, (lo, hi) in zip(self.envs, self.bounds):
+            e.step(actions[lo:hi].contiguous())
+        self._gather()
+        return self.obs, self.local_goal, self.speed, self.reward, self.done, self.result
+
+    def enable_timing(self, on=True):
+        for e in self.envs:
+            e.enable_timing(on)
+
+    def close(self):
+        for e in self.envs:
+            e.close()

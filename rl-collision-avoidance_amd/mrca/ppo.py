@@ -255,9 +255,24 @@ class KLAdaptiveLR:
     minibatches is compared with ``target``; above 2x the lr is divided by ``factor``, below 0.5x multiplied.
     The KL is averaged over ranks so that every rank's optimizer takes the same decision."""
 
-    def __init__(self, target, lr_min=1e-6, lr_max=1e-3, factor=1.5):
+    def __init__(self, target, lr_min=1e-6, lr_max=1e-3, factor=1.5, stop_factor=0.0):
         self.target, self.lr_min, self.lr_max, self.factor = float(target), lr_min, lr_max, factor
+        # stop_factor > 0: the rest of an update is abandoned as soon as one minibatch reports KL > stop_factor x target
+        # (the trust region is enforced inside the update, not only by next update's learning rate)
+        self.stop_factor = float(stop_factor)
         self.last_kl = None
+        self.stopped_early = 0
+
+    def should_stop(self, kl_minibatch, dist):
+        if self.stop_factor <= 0:
+            return False
+        k = kl_minibatch.detach().double().reshape(1)
+        if _world_size(dist) > 1:
+            dist.all_reduce(k)
+            k = k / _world_size(dist)
+        stop = float(k) > self.stop_factor * self.target
+        self.stopped_early += int(stop)
+        return stop
 
     def step(self, optimizer, kl_sum, count, dist):
         s = torch.stack([kl_sum.double(), torch.as_tensor(float(count), dtype=torch.float64, device=kl_sum.device)])
@@ -274,7 +289,7 @@ class KLAdaptiveLR:
 
 
 def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, drop_last, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype=None, kl_ctl=None):
+                index_batches, dist, flat_grads, log, autocast_dtype=None, kl_ctl=None, max_grad_norm=0.0):
     obss, goals, speeds, actions, logprobs, targets, advs = flat
     n = advs.shape[0]
     multi = _world_size(dist) > 1
@@ -294,6 +309,7 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
                                    "lower --batch-size")
             batches = batches[:int(s.item())]
         kl_sum = torch.zeros((), device=advs.device)
+        n_done, stop = 0, False
         for index in batches:
             with torch.autocast(advs.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
                 new_value, new_logprob, dist_entropy = policy.evaluate_actions(obss[index], goals[index],
@@ -314,19 +330,33 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
             loss.backward()
             if flat_grads is not None:
                 flat_grads.all_reduce_mean(dist)
+            if max_grad_norm > 0:       # opt-in (not in the reference): global-norm clipping of the (averaged) gradient
+                if flat_grads is not None:
+                    flat_grads.flat.mul_(torch.clamp(max_grad_norm / (flat_grads.flat.norm() + 1e-6), max=1.0))
+                else:
+                    torch.nn.utils.clip_grad_norm_(policy.parameters(), max_grad_norm)
             optimizer.step()
+            stop = False
             if kl_ctl is not None:
                 with torch.no_grad():
-                    kl_sum += ((ratio - 1.0) - log_ratio).mean()      # k3 estimator of KL(old || new), >= 0
+                    kl_mb = ((ratio - 1.0) - log_ratio).mean()        # k3 estimator of KL(old || new), >= 0
+                    kl_sum += kl_mb
+                n_done += 1
+                stop = kl_ctl.should_stop(kl_mb, dist)
             if log is not None:
                 log.append((policy_loss.detach(), value_loss.detach(), dist_entropy.detach()))
-        if kl_ctl is not None and len(batches):
-            kl_ctl.step(optimizer, kl_sum, len(batches), dist)
+            if stop:
+                break
+        if kl_ctl is not None and n_done:
+            kl_ctl.step(optimizer, kl_sum, n_done, dist)
+        if stop:
+            break
 
 
 def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entropy=0.02, clip_value=0.2,
                       num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *, value_coef=20.0,
-                      index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None, kl_ctl=None):
+                      index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None, kl_ctl=None,
+                      max_grad_norm=0.0):
     """model/ppo.py:143-194.  ``memory`` = (obss, goals, speeds, actions, logprobs, targets, values,
     rewards, advs) as device tensors shaped [T, N, ...] (obss may be a FrameRows: one stored frame per tick)."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -337,13 +367,13 @@ def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entrop
     flat = (obs_rows, goals.reshape(n, 2), speeds.reshape(n, 2),
             actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1), advs.reshape(n, 1))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, False, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl)
+                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl, max_grad_norm)
 
 
 def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch, coeff_entropy=0.02,
                       clip_value=0.2, num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *,
                       value_coef=20.0, index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None,
-                      kl_ctl=None):
+                      kl_ctl=None, max_grad_norm=0.0):
     """model/ppo.py:197-259: the advantage statistics use ALL transitions, then the filtered rows
     are deleted and minibatches use drop_last=True."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -358,4 +388,4 @@ def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch
                                    actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1),
                                    advs.reshape(n, 1)))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, True, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl)
+                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl, max_grad_norm)

@@ -160,3 +160,13 @@ def circle_big(num_robots, num_worlds=1, seed=0, spacing=None, grid=None):
     return Scenario("circle_big", num_worlds, R, grid or empty_grid(), timeout=1000000, w_thresh=0.7,
                     pre_dist_zero=True, auto_reset=AUTO_NONE, seed=seed, reset_mode=mode, goal_mode=mode.copy(),
                     init_table=init, goal_table=goal)
+
+
+def circle_train(num_worlds=1, seed=0, timeout=900, grid=None):
+    """The circle scenario as a TRAINING world (not in the reference, whose circle_world.py is evaluation only): same
+    map, poses, goals and reward constants as ``circle`` (circle_world.py:164-208), but episodes end -- the 50 robots
+    form one group that restarts together once every robot is done (Stage-2's group-synchronous rule,
+    ppo_stage2.py:72-107) or after ``timeout`` ticks (50 m at 1 m/s are 500)."""
+    sc = circle(num_worlds, seed, grid)
+    sc.name, sc.timeout, sc.auto_reset = "circle_train", int(timeout), AUTO_GROUP
+    return sc

@@ -76,6 +76,14 @@ def main(argv=None):
     ap.add_argument("--circle-worlds", type=int, default=20)
     ap.add_argument("--circle-ticks", type=int, default=1500)
     ap.add_argument("--max-seconds", type=float, default=0.0, help="stop after this much wall time (0 = no limit)")
+    ap.add_argument("--kl-stop", type=float, default=0.0, help="abandon an update when a minibatch's KL exceeds this x kl-target")
+    ap.add_argument("--max-grad-norm", type=float, default=0.0, help="> 0: global-norm gradient clipping (opt-in)")
+    ap.add_argument("--mix-circle", type=int, default=0, help="stage 2: add this many 50-robot circle worlds "
+                                                                "(scenario.circle_train) to the training mix")
+    ap.add_argument("--stock-policy-path", action="store_true", help="rollout inference through the stock PyTorch layers "
+                                                                       "instead of the fused fp32 HIP front end")
+    ap.add_argument("--no-graph", action="store_true", help="launch the rollout tick kernel by kernel, not as a hipGraph")
+    ap.add_argument("--log-every", type=int, default=1)
     a = ap.parse_args(argv)
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +110,9 @@ def main(argv=None):
                  ("coeff_entropy", a.coeff_entropy)):
         if v is not None:
             setattr(hp, k, v)
-    hp.kl_target, hp.lr_max = a.kl_target, a.lr_max
+    hp.kl_target, hp.lr_max, hp.kl_stop, hp.max_grad_norm = a.kl_target, a.lr_max, a.kl_stop, a.max_grad_norm
+    hp.rollout_fused = not a.stock_policy_path and not a.bf16_inference
+    hp.graph_tick = not a.no_graph
     if a.bf16_update:
         hp.update_dtype = torch.bfloat16
     if a.bf16_inference:
@@ -115,6 +125,11 @@ def main(argv=None):
         # epoch per rank; the global batch of one optimiser step is world_size x this.
         hp.batch_size = max(hp.batch_size, sc.num_robots * hp.horizon // 32)
     env = VecStageWorld(sc)
+    if a.mix_circle > 0:
+        from .multi_env import ConcatEnv
+        env = ConcatEnv([env, VecStageWorld(scenario.circle_train(num_worlds=a.mix_circle, seed=a.seed * 1000 + rank))])
+        out.info("training mix: %d robots of %s + %d robots in %d circle worlds", sc.num_robots, sc.name,
+                 env.N - sc.num_robots, a.mix_circle)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=a.seed, stage2=(a.stage == 2))
     out.info("per-rank minibatch %d rows, global batch per optimiser step %d, lr %g, epochs %d, horizon %d",
              hp.batch_size, hp.batch_size * world_size, hp.learning_rate, hp.epoch, hp.horizon)
@@ -151,6 +166,8 @@ def main(argv=None):
     tr.start()
     n_logged = 0
     t_start = time.perf_counter()
+    acc_done = torch.zeros(3, device=env.device)       # terminal events since the last log line
+    acc_steps, acc_time = 0, 0.0
     for _ in range(a.updates):
         if a.max_seconds:
             stop = torch.tensor([float(time.perf_counter() - t_start > a.max_seconds)], device=env.device)
@@ -177,6 +194,10 @@ def main(argv=None):
         dt = time.perf_counter() - t0
         if dist is not None:
             dist.all_reduce(ep_done)
+        acc_done += ep_done
+        acc_steps += env.N * world_size * hp.horizon
+        acc_time += dt
+        ep_done = acc_done
         tot = max(float(ep_done.sum()), 1.0)
         for row in tr.loss_log[n_logged:]:
             ppo_log.info("{}, {}, {}".format(*[float(x) for x in row]))
@@ -184,9 +205,12 @@ def main(argv=None):
         for v in last_return[~torch.isnan(last_return)][:8].tolist():
             cal.info(v)
         kl = "" if tr.last_kl is None else "  kl %.4f  lr %.2e" % (tr.last_kl, tr.optimizer.param_groups[0]["lr"])
-        out.info("update %05d  %.0f agent-steps/s  episodes %d  reach %.3f  crash %.3f  timeout %.3f%s",
-                 tr.global_update, env.N * world_size * hp.horizon / dt, int(tot), float(ep_done[0]) / tot,
-                 float(ep_done[1]) / tot, float(ep_done[2]) / tot, kl)
+        if tr.global_update % a.log_every == 0:
+            out.info("update %05d  %.0f agent-steps/s  episodes %d  reach %.3f  crash %.3f  timeout %.3f%s",
+                     tr.global_update, acc_steps / acc_time, int(tot), float(ep_done[0]) / tot,
+                     float(ep_done[1]) / tot, float(ep_done[2]) / tot, kl)
+            acc_done = torch.zeros(3, device=env.device)
+            acc_steps, acc_time = 0, 0.0
         if tr.global_update % a.save_every == 0:
             gens = gather_generators()          # collective: every rank takes part
             if rank == 0:

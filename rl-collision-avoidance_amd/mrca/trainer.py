@@ -37,6 +37,8 @@ class HParams:
     rollout_fused: bool = False       # rollout inference through the HIP conv front end (net.mean_value_fused, fp32)
     kl_target: float = 0.0            # > 0: KL-adaptive learning rate (ppo.KLAdaptiveLR; opt-in, large-batch regime)
     lr_max: float = 1e-3
+    kl_stop: float = 0.0              # > 0: abandon the rest of an update when a minibatch reports KL > kl_stop x kl_target
+    max_grad_norm: float = 0.0        # > 0: global-norm gradient clipping (opt-in; the reference clips nothing)
 
 
 def broadcast_parameters(module, dist):
@@ -57,7 +59,8 @@ class Stage1Trainer:
         broadcast_parameters(self.policy, dist)
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate)
         self.flat_grads = ppo.FlatGrads(self.policy.parameters())
-        self.kl_ctl = ppo.KLAdaptiveLR(self.hp.kl_target, lr_max=self.hp.lr_max) if self.hp.kl_target > 0 else None
+        self.kl_ctl = ppo.KLAdaptiveLR(self.hp.kl_target, lr_max=self.hp.lr_max, stop_factor=self.hp.kl_stop) \
+            if self.hp.kl_target > 0 else None
         self.buffer = ppo.RolloutBuffer(self.hp.horizon, env.N, self.hp.laser_hist, self.hp.obs_size, dev,
                                         self.hp.act_size, single_frame=self.hp.single_frame_buffer)
         self.gen = torch.Generator(device=dev)
@@ -138,7 +141,7 @@ class Stage1Trainer:
                   epoch=hp.epoch, coeff_entropy=hp.coeff_entropy, clip_value=hp.clip_value, num_step=hp.horizon,
                   num_env=env.N, frames=hp.laser_hist, obs_size=hp.obs_size, act_size=hp.act_size,
                   value_coef=hp.value_coef, dist=self.dist, flat_grads=self.flat_grads, log=self.loss_log,
-                  autocast_dtype=hp.update_dtype, kl_ctl=self.kl_ctl)
+                  autocast_dtype=hp.update_dtype, kl_ctl=self.kl_ctl, max_grad_norm=hp.max_grad_norm)
         if self.stage2:
             ppo.ppo_update_stage2(filter_index=ppo.get_filter_index(buf.done), **kw)
         else:

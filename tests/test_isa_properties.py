@@ -43,7 +43,7 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
     assert fused and anchors
     # norm_obs: v_mul x, RN(1/6); v_fmamk .., -6.0, ..; v_fmac .., RN(1/6), ..   (explicit __builtin_fmaf)
     norm = [i for i in fused if "0xc0c00000" in device_asm[i] or "0x3e2aaaab" in device_asm[i]]
-    assert len(norm) == 2 * 2 * (1 + 2 + 4), len(norm)      # two per beam of raycast_kernel<1|2|4, small|big>
+    assert len(norm) == 2 * ((1 + 2 + 2 + 4) + (1 + 2 + 4)), len(norm)      # two per beam of every raycast_kernel variant
     for i in norm:
         assert any("0x3e2aaaab" in device_asm[j] and "v_mul_f32" in device_asm[j] for j in range(i - 8, i)), i
     fused = [i for i in fused if i not in set(norm)]
@@ -56,7 +56,8 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
 def test_register_budget_and_no_scratch(device_asm):
     text = "\n".join(device_asm)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
-    assert len(kernels) == 16, [k for k, _ in kernels]   # move, head_init, reset, gae, 6 x bw_*, raycast<1|2|4> x <small|big>
+    # move, shift_frames, head_init, reset, gae, 6 x bw_*, raycast<1 | 2 lock-step | 2 sequential | 4> + big-world <1|2|4>
+    assert len(kernels) == 18, [k for k, _ in kernels]
     for name, body in kernels:
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
