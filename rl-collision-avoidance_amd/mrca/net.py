@@ -73,7 +73,7 @@ class CNNPolicy(nn.Module):
         batched GEMMs.  Same parameters, same state_dict keys -- these are derived buffers, never saved."""
         with torch.no_grad():
             st = lambda a, c: torch.stack([a.detach(), c.detach()]).contiguous()   # noqa: E731
-            self._rc = {
+            new = {
                 "w1": st(self.act_fea_cv1.weight, self.crt_fea_cv1.weight), "b1": st(self.act_fea_cv1.bias, self.crt_fea_cv1.bias),
                 "w2": st(self.act_fea_cv2.weight, self.crt_fea_cv2.weight), "b2": st(self.act_fea_cv2.bias, self.crt_fea_cv2.bias),
                 "fc1_w": st(self.act_fc1.weight.t(), self.crt_fc1.weight.t()),        # [2, 4096, 256]
@@ -83,6 +83,12 @@ class CNNPolicy(nn.Module):
                 "head_w": torch.cat([self.actor1.weight, self.actor2.weight]).detach().t().contiguous(),   # [128, 2]
                 "head_b": torch.cat([self.actor1.bias, self.actor2.bias]).detach(),
             }
+            old = getattr(self, "_rc", None)
+            if old is not None and all(old[k].shape == v.shape and old[k].device == v.device for k, v in new.items()):
+                for k, v in new.items():          # IN PLACE: a captured hipGraph keeps reading the same addresses
+                    old[k].copy_(v)
+            else:
+                self._rc = new
         return self._rc
 
     def mean_value_fused(self, x, goal, speed):

@@ -171,6 +171,7 @@ def run_script(path, nprocs, max_ticks=None, extra_argv=(), chdir=None):
     dropin = os.path.join(here, "dropin")
     script_dir = os.path.dirname(os.path.abspath(path))
     old_path, old_argv, old_cwd = list(sys.path), list(sys.argv), os.getcwd()
+    old_main = sys.modules.get("__main__")     # runpy installs the script as __main__: put the caller's back afterwards
     sys.path[:0] = [dropin, script_dir]
     for shadowed in ("rospy", "tf", "mpi4py", "mpi4py.MPI", "stage_world1", "stage_world2", "circle_world"):
         sys.modules.pop(shadowed, None)
@@ -214,6 +215,8 @@ def run_script(path, nprocs, max_ticks=None, extra_argv=(), chdir=None):
         sys.path[:] = old_path
         sys.argv = old_argv
         os.chdir(old_cwd)
+        if old_main is not None:
+            sys.modules["__main__"] = old_main
         _runtime = None
     return rt.errors
 
