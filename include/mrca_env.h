@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MRCA_ABI_VERSION 1
+#define MRCA_ABI_VERSION 2
 
 typedef struct mrca_env mrca_env; /* opaque */
 
@@ -108,6 +108,10 @@ typedef struct mrca_config {
     const float* init_table;  /* [R,3] */
     const float* goal_table;  /* [R,2] */
     const int32_t* group_id;  /* [R] in 0..15, model/utils.py:83 */
+    /* Fidelity mode (ABI 2).  0 = robots collide when their 0.44 x 0.38 rectangles overlap (exact, resolution-free).
+     * res > 0 [m] = Stage's rule on a raster of `res` metres (worlds/stage1.world:3: 0.2): robots collide when their
+     * OUTLINES SHARE A RASTER CELL, i.e. up to one cell apart.  res >= 0.1; not with robots_per_world > 64. */
+    float collision_raster;
 } mrca_config;
 
 /* Bytes of device arena an env with this config needs (256-byte granules). */

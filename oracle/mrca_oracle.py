@@ -249,6 +249,57 @@ def static_hit(gm, x, y, s, c, dtype):
     return (t < elen).any(axis=-1)
 
 
+def walk_cells(inv_res, ox, oy, dx, dy, tmax, f):
+    """Cells visited by the closed-form grid walk of ``grid_march`` on a raster of 1/inv_res metres aligned at the
+    world origin: the start cell, then every cell entered at t < tmax (scalar inputs of dtype f)."""
+    fx, fy = f(ox * inv_res), f(oy * inv_res)
+    ix, iy = int(np.floor(fx)), int(np.floor(fy))
+    tmax_c = f(tmax * inv_res)
+    out = [(ix, iy)]
+    if not tmax_c > 0:
+        return out
+    inf = f(np.inf)
+    xnz, ynz = dx != 0, dy != 0
+    inv_dx = f(f(1.0) / dx) if xnz else inf
+    inv_dy = f(f(1.0) / dy) if ynz else inf
+    sx, sy = (1 if dx > 0 else -1), (1 if dy > 0 else -1)
+    bx, by = (ix + 1 if dx > 0 else ix), (iy + 1 if dy > 0 else iy)
+    tx = f((f(bx) - fx) * inv_dx) if xnz else inf
+    ty = f((f(by) - fy) * inv_dy) if ynz else inf
+    while True:
+        if tx < ty:
+            t = tx
+            ix += sx
+            bx += sx
+            tx = f((f(bx) - fx) * inv_dx)
+        else:
+            t = ty
+            iy += sy
+            by += sy
+            ty = f((f(by) - fy) * inv_dy) if ynz else inf
+        if t >= tmax_c:
+            return out
+        out.append((ix, iy))
+
+
+def outline_cells(res, x, y, s, c, f):
+    """Fidelity mode: the raster cells (side ``res``) under the outline of the 0.44 x 0.38 footprint -- the cells the
+    grid walk visits along its four edges (corner k -> corner k+1 as in ``static_hit``).  [Stage maps a model's outline
+    into its world raster and reports a collision when a cell also holds another model -- SURVEY Appendix B; restated.]"""
+    inv_res = f(f(1.0) / f(res))
+    hx = [HALF_LEN, -HALF_LEN, -HALF_LEN, HALF_LEN]
+    hy = [HALF_WID, HALF_WID, -HALF_WID, -HALF_WID]
+    ex = [-c, s, c, -s]
+    ey = [-s, -c, s, c]
+    el = [2 * HALF_LEN, 2 * HALF_WID, 2 * HALF_LEN, 2 * HALF_WID]
+    cells = set()
+    for k in range(4):
+        cx = f(x + f(f(f(hx[k]) * c) - f(f(hy[k]) * s)))
+        cy = f(y + f(f(f(hx[k]) * s) + f(f(hy[k]) * c)))
+        cells.update(walk_cells(inv_res, cx, cy, f(ex[k]), f(ey[k]), f(el[k]), f))
+    return cells
+
+
 def obb_overlap(xi, yi, si, ci, xj, yj, sj, cj, dtype):
     """Separating-axis test of two 0.44 x 0.38 rectangles; touching counts as overlap."""
     f = dtype
@@ -302,7 +353,8 @@ class OracleConfig:
 
     def __init__(self, num_worlds, robots_per_world, grid, *, timeout=150, w_thresh=1.05,
                  pre_dist_zero=False, auto_reset=AUTO_ROBOT, seed=0, reset_mode=None,
-                 init_table=None, goal_table=None, group_id=None, beams=BEAMS, frames=3, first_world=0):
+                 init_table=None, goal_table=None, group_id=None, beams=BEAMS, frames=3, first_world=0,
+                 collision_raster=0.0):
         self.W, self.R = int(num_worlds), int(robots_per_world)
         self.grid = grid
         self.timeout, self.w_thresh = int(timeout), float(w_thresh)
@@ -315,6 +367,7 @@ class OracleConfig:
         self.group_id = np.zeros(R, np.int32) if group_id is None else np.asarray(group_id, np.int32)
         self.beams, self.frames = int(beams), int(frames)
         self.first_world = int(first_world)   # simulate worlds [first_world, first_world+W) of a larger batch
+        self.collision_raster = float(collision_raster)   # fidelity mode: > 0 = Stage-like raster collision between robots
 
 
 class OracleEnv:
@@ -497,9 +550,11 @@ class OracleEnv:
         cth = th.copy()
         moved = np.zeros(N, bool)
         base = np.arange(cfg.W) * R
-        if R > BIG_WORLD:
+        if cfg.collision_raster > 0:
+            self._collide_raster(nx, ny, nth, ns, nc, moving, shit, cx, cy, cth, cs, cc, moved)
+        elif R > BIG_WORLD:
             self._collide_big(nx, ny, nth, ns, nc, moving, shit, cx, cy, cth, cs, cc, moved)
-        for i in range(R if R <= BIG_WORLD else 0):
+        for i in range(R if (R <= BIG_WORLD and cfg.collision_raster <= 0) else 0):
             ii = base + i
             hit = shit[ii].copy()
             for j in range(R):
@@ -571,6 +626,26 @@ class OracleEnv:
             fresh[idx] = True
         self._observe(fresh)
         return self.obs, self.local_goal, self.speed, self.reward, self.done, self.result
+
+    # ---------------------------------------------------------------- fidelity mode
+    def _collide_raster(self, nx, ny, nth, ns, nc, moving, shit, cx, cy, cth, cs, cc, moved):
+        """The robot-order pass with Stage's raster rule: robot i, at its provisional pose, collides with robot j iff
+        their OUTLINES SHARE A RASTER CELL of ``collision_raster`` metres (j at the pose it has when it is i's turn)."""
+        f, cfg = self.f, self.cfg
+        R, res = cfg.R, cfg.collision_raster
+        for w in range(cfg.W):
+            cur = [outline_cells(res, cx[w * R + j], cy[w * R + j], cs[w * R + j], cc[w * R + j], f) for j in range(R)]
+            for i in range(R):
+                n = w * R + i
+                if not moving[n]:
+                    continue
+                mine = outline_cells(res, nx[n], ny[n], ns[n], nc[n], f)
+                hit = bool(shit[n]) or any((j != i) and not mine.isdisjoint(cur[j]) for j in range(R))
+                if not hit:
+                    cx[n], cy[n], cth[n], cs[n], cc[n] = nx[n], ny[n], nth[n], ns[n], nc[n]
+                    moved[n] = True
+                    cur[i] = mine
+                self.crashed[n] = 1 if hit else 0
 
     # ---------------------------------------------------------------- worlds with more than 64 robots
     def _collide_big(self, nx, ny, nth, ns, nc, moving, shit, cx, cy, cth, cs, cc, moved):

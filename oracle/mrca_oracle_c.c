@@ -38,6 +38,7 @@ typedef struct {
     int32_t pre_dist_zero, auto_reset, num_groups;
     uint32_t key0, key1;
     int32_t first_world;
+    float raster_res; /* fidelity mode: > 0 = robots collide when their outlines share a raster cell of this size */
 } oc_env;
 
 
@@ -189,6 +190,49 @@ static int oc_static_hit(const oc_env* e, float x, float y, float s, float c) {
         if (oc_march(e, cx, cy, ex[k], ey[k], el[k]) < el[k]) hit = 1;
     }
     return hit;
+}
+
+/* Fidelity mode (Stage's raster rule, restated -- SURVEY Appendix B): the cells of side `res`, aligned at the world
+ * origin, that the closed-form grid walk visits along the four outline edges of a pose (start cell, then every cell
+ * entered at t < edge length); two robots collide iff their outlines share a cell. */
+#define OC_MAX_CELLS 64
+static int oc_outline_cells(float res, float x, float y, float s, float c, int64_t* out) {
+    const float inv = 1.0f / res;
+    const float hx[4] = {HALF_LEN, -HALF_LEN, -HALF_LEN, HALF_LEN};
+    const float hy[4] = {HALF_WID, HALF_WID, -HALF_WID, -HALF_WID};
+    const float ex[4] = {-c, s, c, -s}, ey[4] = {-s, -c, s, c};
+    const float el[4] = {2.0f * HALF_LEN, 2.0f * HALF_WID, 2.0f * HALF_LEN, 2.0f * HALF_WID};
+    int n = 0;
+    for (int k = 0; k < 4; ++k) {
+        const float ox = x + (hx[k] * c - hy[k] * s), oy = y + (hx[k] * s + hy[k] * c);
+        const float dx = ex[k], dy = ey[k];
+        const float fx = ox * inv, fy = oy * inv;
+        int ix = (int)floorf(fx), iy = (int)floorf(fy);
+        const float tmax_c = el[k] * inv;
+        if (n < OC_MAX_CELLS) out[n++] = ((int64_t)ix << 32) | (uint32_t)iy;
+        if (!(tmax_c > 0.0f)) continue;
+        const int xnz = dx != 0.0f, ynz = dy != 0.0f;
+        const float inv_dx = xnz ? 1.0f / dx : INFINITY, inv_dy = ynz ? 1.0f / dy : INFINITY;
+        const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
+        int bx = dx > 0.0f ? ix + 1 : ix, by = dy > 0.0f ? iy + 1 : iy;
+        float tx = xnz ? ((float)bx - fx) * inv_dx : INFINITY;
+        float ty = ynz ? ((float)by - fy) * inv_dy : INFINITY;
+        for (;;) {
+            float t;
+            if (tx < ty) { t = tx; ix += sx; bx += sx; tx = ((float)bx - fx) * inv_dx; }
+            else { t = ty; iy += sy; by += sy; ty = ynz ? ((float)by - fy) * inv_dy : INFINITY; }
+            if (t >= tmax_c) break;
+            if (n < OC_MAX_CELLS) out[n++] = ((int64_t)ix << 32) | (uint32_t)iy;
+        }
+    }
+    return n;
+}
+
+static int oc_cells_meet(const int64_t* a, int na, const int64_t* b, int nb) {
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j)
+            if (a[i] == b[j]) return 1;
+    return 0;
 }
 
 static int oc_overlap(float xi, float yi, float si, float ci, float xj, float yj, float sj, float cj) {
@@ -381,6 +425,14 @@ void oc_step(const oc_env* e, const float* actions) {
             shit[l] = (char)oc_static_hit(e, nx[l], ny[l], ns[l], nc[l]);
             moved[l] = 0;
         }
+        const int raster = e->raster_res > 0.0f && !big;
+        int64_t* cells = 0;
+        int* ncell = 0;
+        if (raster) { /* outline cells of every robot at the pose it has now */
+            cells = (int64_t*)malloc(sizeof(int64_t) * OC_MAX_CELLS * (size_t)R);
+            ncell = (int*)malloc(sizeof(int) * (size_t)R);
+            for (int l = 0; l < R; ++l) ncell[l] = oc_outline_cells(e->raster_res, x[l], y[l], s[l], c[l], cells + (size_t)l * OC_MAX_CELLS);
+        }
         oc_hash* ch = 0;
         if (big) { /* current centres of this world's robots, kept up to date as robots commit their moves */
             ch = oc_hash_new(R, 0.7f);
@@ -401,6 +453,12 @@ void oc_step(const oc_env* e, const float* actions) {
                             if (oc_overlap(nx[i], ny[i], ns[i], nc[i], x[j], y[j], s[j], c[j])) hit = 1;
                         }
                     }
+            } else if (raster) {
+                int64_t mine[OC_MAX_CELLS];
+                const int nm = oc_outline_cells(e->raster_res, nx[i], ny[i], ns[i], nc[i], mine);
+                for (int j = 0; j < R && !hit; ++j)
+                    if (j != i && oc_cells_meet(mine, nm, cells + (size_t)j * OC_MAX_CELLS, ncell[j])) hit = 1;
+                if (!hit) { memcpy(cells + (size_t)i * OC_MAX_CELLS, mine, sizeof(mine)); ncell[i] = nm; }
             } else {
                 for (int j = 0; j < R && !hit; ++j)
                     if (j != i && oc_overlap(nx[i], ny[i], ns[i], nc[i], x[j], y[j], s[j], c[j])) hit = 1;
@@ -413,6 +471,8 @@ void oc_step(const oc_env* e, const float* actions) {
             e->crashed[world * R + i] = (uint8_t)hit;
         }
         oc_hash_free(ch);
+        free(cells);
+        free(ncell);
         for (int l = 0; l < R; ++l) {
             const int n = world * R + l;
             e->pose[n * 3] = x[l]; e->pose[n * 3 + 1] = y[l]; e->pose[n * 3 + 2] = th[l];

@@ -58,6 +58,12 @@ int validate(const mrca_config* c) {
     if (c->robots_per_world > 64 && c->auto_reset == MRCA_AUTO_GROUP)
         return fail(MRCA_ERR_UNSUPPORTED, "robots_per_world %d > 64 with group-synchronous episodes (auto_reset 2)",
                     c->robots_per_world);
+    if (!(c->collision_raster >= 0.0f)) return fail(MRCA_ERR_INVALID, "collision_raster must be >= 0");
+    if (c->collision_raster > 0.0f && c->collision_raster < 0.1f)
+        return fail(MRCA_ERR_UNSUPPORTED, "collision_raster %.3f m: the outline lists hold cells of >= 0.1 m",
+                    (double)c->collision_raster);
+    if (c->collision_raster > 0.0f && c->robots_per_world > 64)
+        return fail(MRCA_ERR_UNSUPPORTED, "collision_raster with robots_per_world > 64");
     if ((int64_t)c->num_worlds * c->robots_per_world > (1 << 24))
         return fail(MRCA_ERR_UNSUPPORTED, "more than 2^24 robots in one environment");
     if (c->beams < 64 || c->beams > 1024 || c->beams % 64)
@@ -392,6 +398,12 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.key0 = (uint32_t)(cfg->seed & 0xFFFFFFFFull);
     v.key1 = (uint32_t)(cfg->seed >> 32);
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
+    v.raster_inv = cfg->collision_raster > 0.0f ? 1.0f / cfg->collision_raster : 0.0f;
+    {   // broad phase: rectangles further apart than 2 x circumradius cannot overlap; outlines further apart than that
+        // plus one raster-cell diagonal cannot share a cell
+        const float reach = 2.0f * 0.2907f + 0.001f + (cfg->collision_raster > 0.0f ? 1.4143f * cfg->collision_raster : 0.0f);
+        v.collide_reach2 = cfg->collision_raster > 0.0f ? reach * reach : mrca::kCollideReach2;
+    }
     v.debug_flags = 0;
     // 256 marching threads per 512-beam robot, 2 beams each in lock step, plus one wave that prepares the neighbour
     // list while the others march (variants measured in profiles/: threads per robot, with / without that wave)

@@ -473,6 +473,77 @@ MRCA_HD bool static_hit(const Occ& occ, const GridGeom& g, float x, float y, flo
     return hit;
 }
 
+// ------------------------------------------------------------------------------------------
+// Stage-like RASTER collision between robots (fidelity mode, mrca_config.collision_raster = res > 0): Stage maps a
+// model's outline into its world raster (cells of `resolution` metres, 0.2 m in stage1/2.world:3) and reports a
+// collision when a cell of the outline also holds another model [libstage, SURVEY Appendix B].  Restated: the outline
+// cells of a pose are the cells the closed-form grid walk visits along its four edges (the walk of grid_march on a
+// raster of `res` metres aligned at the world origin, start cell included, cells entered at t < edge length); two
+// robots collide iff their outlines share a cell.  At most kMaxOutlineCells per robot (res >= 0.1 m).
+constexpr int kMaxOutlineCells = 40;
+MRCA_HD long long pack_cell(int ix, int iy) { return (long long)(((unsigned long long)(unsigned int)ix << 32) | (unsigned int)iy); }
+
+template <class Emit>
+MRCA_HD void walk_cells(float inv_res, float ox, float oy, float dx, float dy, float tmax, Emit&& emit) {
+    const float fx = ox * inv_res;
+    const float fy = oy * inv_res;
+    int ix = (int)floorf(fx);
+    int iy = (int)floorf(fy);
+    const float tmax_c = tmax * inv_res;
+    emit(ix, iy);
+    if (!(tmax_c > 0.0f)) return;
+    const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
+    const float inv_dx = xnz ? 1.0f / dx : kInf;
+    const float inv_dy = ynz ? 1.0f / dy : kInf;
+    const int sx = dx > 0.0f ? 1 : -1;
+    const int sy = dy > 0.0f ? 1 : -1;
+    int bx = dx > 0.0f ? ix + 1 : ix;
+    int by = dy > 0.0f ? iy + 1 : iy;
+    float tx = xnz ? ((float)bx - fx) * inv_dx : kInf;
+    float ty = ynz ? ((float)by - fy) * inv_dy : kInf;
+    for (int guard = 0; guard < 4 * kMaxOutlineCells; ++guard) {
+        float t;
+        if (tx < ty) {
+            t = tx;
+            ix += sx;
+            bx += sx;
+            tx = ((float)bx - fx) * inv_dx;
+        } else {
+            t = ty;
+            iy += sy;
+            by += sy;
+            ty = ynz ? ((float)by - fy) * inv_dy : kInf;
+        }
+        if (t >= tmax_c) return;
+        emit(ix, iy);
+    }
+}
+
+// outline cells of the 0.44 x 0.38 footprint at (x, y, sin, cos): edges as in static_edge_hit; returns the count
+MRCA_HD int outline_cells(float inv_res, float x, float y, float s, float c, long long* out) {
+    int n = 0;
+    for (int k = 0; k < 4; ++k) {
+        const float hx = (k == 0 || k == 3) ? kHalfLen : -kHalfLen;
+        const float hy = (k < 2) ? kHalfWid : -kHalfWid;
+        const float ex = (k == 0) ? -c : (k == 1) ? s : (k == 2) ? c : -s;
+        const float ey = (k == 0) ? -s : (k == 1) ? -c : (k == 2) ? s : c;
+        const float el = (k & 1) ? 2.0f * kHalfWid : 2.0f * kHalfLen;
+        const float cx = x + (hx * c - hy * s);
+        const float cy = y + (hx * s + hy * c);
+        walk_cells(inv_res, cx, cy, ex, ey, el, [&](int ix, int iy) {
+            if (n < kMaxOutlineCells) out[n++] = pack_cell(ix, iy);
+        });
+    }
+    return n;
+}
+
+MRCA_HD bool cells_intersect(const long long* a, int na, const long long* b, int nb) {
+    bool hit = false;
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) hit = hit || (a[i] == b[j]);
+    return hit;
+}
+
 // Separating-axis test of two robot rectangles; touching counts as overlap.
 MRCA_HD bool obb_overlap(float xi, float yi, float si, float ci, float xj, float yj, float sj, float cj) {
     const float tx = xj - xi;

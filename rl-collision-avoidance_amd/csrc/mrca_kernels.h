@@ -69,6 +69,8 @@ struct EnvView {
     int32_t auto_reset;
     int32_t num_groups;
     uint32_t key0, key1;
+    float raster_inv;     // fidelity mode: 1 / collision_raster (0 = exact rectangles), see mrca_device.h outline_cells
+    float collide_reach2; // squared centre distance beyond which two robots cannot collide (broad phase)
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel marches 1 << ray_shift beams per thread in lock step
     int32_t ray_sequential; // 1 (with ray_shift 1): the two beams of a thread are marched one after the other

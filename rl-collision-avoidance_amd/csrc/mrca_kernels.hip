@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
             const float ax = nx - fbcast(x, j), ay = ny - fbcast(y, j);
             const float bx2 = nx - fbcast(nx, j), by2 = ny - fbcast(ny, j);
             const float d_old = ax * ax + ay * ay, d_new = bx2 * bx2 + by2 * by2;
-            if (j != lane && (d_old <= 0.3392f || d_new <= 0.3392f)) involved = true;  // (2*0.2907 + 0.001)^2
+            if (j != lane && (d_old <= e.collide_reach2 || d_new <= e.collide_reach2)) involved = true;  // (2*0.2907 + 0.001)^2
         }
         involved = involved && valid;
     }
@@ -310,6 +310,19 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     __syncthreads();
     const bool shit = need && hit_flag[lane] != 0;
 
+    // --- fidelity mode (collision_raster): robots collide when their OUTLINES SHARE A RASTER CELL (Stage's rule) instead
+    //     of when their rectangles overlap.  Every robot's current outline cells live in LDS; a robot that commits a
+    //     move inside the ordered pass replaces its own.
+    const bool raster = e.raster_inv > 0.0f;
+    long long* cur_cells = reinterpret_cast<long long*>(hit_flag + kWave);      // [64][kMaxOutlineCells]
+    int* cur_n = reinterpret_cast<int*>(cur_cells + kWave * kMaxOutlineCells);   // [64]
+    long long* turn_cells = reinterpret_cast<long long*>(cur_n + kWave);         // [kMaxOutlineCells]
+    int* turn_n = reinterpret_cast<int*>(turn_cells + kMaxOutlineCells);
+    if (raster) {
+        if (valid) cur_n[lane] = outline_cells(e.raster_inv, x, y, s, c, cur_cells + lane * kMaxOutlineCells);
+        __syncthreads();
+    }
+
     // --- collision pass in robot order (Stage's sequential model loop)
     // committed pose of a robot that is not involved: moves unless the map stops it
     const float ox_ = x, oy_ = y, os_ = s, oc_ = c;  // pose at tick start
@@ -332,7 +345,18 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
             // robots after i in the order have not moved yet when i is tested
             const bool later = lane > i;
             const float cx_ = later ? ox_ : x, cy_ = later ? oy_ : y, cs_ = later ? os_ : s, cc_ = later ? oc_ : c;
-            const bool ov = valid && (lane != i) && obb_overlap(xi, yi, si, ci, cx_, cy_, cs_, cc_);
+            bool ov;
+            if (raster) {
+                // robot i's provisional outline goes to LDS, everybody in reach compares it with the outline of the
+                // pose they have now (cur_cells follows the commits, so "later" robots still hold their old outline)
+                if (lane == i) *turn_n = outline_cells(e.raster_inv, xi, yi, si, ci, turn_cells);
+                __syncthreads();
+                const float ax = cx_ - xi, ay = cy_ - yi;
+                ov = valid && (lane != i) && (ax * ax + ay * ay <= e.collide_reach2) &&
+                     cells_intersect(cur_cells + lane * kMaxOutlineCells, cur_n[lane], turn_cells, *turn_n);
+            } else {
+                ov = valid && (lane != i) && obb_overlap(xi, yi, si, ci, cx_, cy_, cs_, cc_);
+            }
             const unsigned long long m = __ballot(ov);
             if (lane == i && moving) {
                 const bool hit = shit || (m != 0ull);
@@ -344,9 +368,15 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
                     c = nc;
                     cellv = cellv_new;
                     moved = true;
+                    if (raster) {
+                        const int tn = *turn_n;
+                        for (int q = 0; q < tn; ++q) cur_cells[lane * kMaxOutlineCells + q] = turn_cells[q];
+                        cur_n[lane] = tn;
+                    }
                 }
                 crashed = hit ? 1 : 0;
             }
+            if (raster) __syncthreads();   // turn_cells / cur_cells settled before the next turn
         }
     }
 
@@ -838,7 +868,7 @@ __global__ void bw_collide_kernel(EnvView e) {
                     const float ox = e.pose[j * 3 + 0], oy = e.pose[j * 3 + 1];
                     // the centre this entry stands for: within reach of my provisional centre?
                     const float ax = nx - ((en & 1) ? q0.x : ox), ay = ny - ((en & 1) ? q0.y : oy);
-                    if (!(ax * ax + ay * ay <= kCollideReach2)) continue;
+                    if (!(ax * ax + ay * ay <= e.collide_reach2)) continue;
                     // the pose j has when it is my turn: robots after me have not moved yet; a robot before me is
                     // at its provisional pose iff its own test came out free
                     int sj = 1;
@@ -1047,7 +1077,10 @@ size_t ray_lds_bytes(const EnvView& e) {
 size_t move_lds_bytes(const EnvView& e) {
     const int rows = 2 * e.foot_hc + 1;
     const int words = (rows + 31) / 32 + 1;
-    return (size_t)kWave * rows * words * 4 + 2 * kWave * sizeof(int);
+    size_t b = (size_t)kWave * rows * words * 4 + 2 * kWave * sizeof(int);
+    if (e.raster_inv > 0.0f)   // outline cells of every robot + of the robot taking its turn (fidelity mode)
+        b = (b + 7) / 8 * 8 + (size_t)(kWave + 1) * kMaxOutlineCells * sizeof(long long) + (kWave + 2) * sizeof(int);
+    return b;
 }
 
 // blocks of 64 threads x 4 float4 columns per pass for the frame-stack shift that rides behind the move kernel

@@ -9,7 +9,7 @@ PROFILING_LIB_PATH = os.path.join(_HERE, "libmrca_env_prof.so")
 # libmrca_env_prof.so); whichever it is, it must exist -- there is no fallback
 LIB_PATH = os.environ.get("MRCA_ENV_LIB") or os.path.join(_HERE, "libmrca_env.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FIELDS = [  # order = enum mrca_field
     ("pose", "f32", 3), ("speed", "f32", 2), ("speed_gt", "f32", 2), ("goal", "f32", 2), ("init_pose", "f32", 3),
@@ -34,6 +34,7 @@ class MrcaConfig(C.Structure):
         ("seed", C.c_uint64),
         ("reset_mode", C.c_void_p), ("goal_mode", C.c_void_p), ("init_table", C.c_void_p),
         ("goal_table", C.c_void_p), ("group_id", C.c_void_p),
+        ("collision_raster", C.c_float),
     ]
 
 

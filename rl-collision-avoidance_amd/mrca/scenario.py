@@ -68,6 +68,7 @@ class Scenario:
     pre_dist_zero: bool = False   # stage_world2.py:170-171 / circle_world.py:166-167
     auto_reset: int = AUTO_ROBOT
     seed: int = 0
+    collision_raster: float = 0.0  # fidelity mode: > 0 = robots collide when their outlines share a raster cell of this size
     beams: int = 512              # stage1.world:14
     frames: int = 3               # LASER_HIST ppo_stage1.py:24
     reset_mode: np.ndarray = field(default=None)
@@ -99,14 +100,30 @@ class Scenario:
         return self.num_worlds * self.robots_per_world
 
 
-def stage1(num_worlds=1, robots_per_world=24, seed=0, grid=None):
+# The shipped maps exist at two cell sizes: the default (0.05 m for Stage-1/2, 0.1 m for the circle world: fine enough
+# that walls keep their bitmap shape, small enough to stay L2-resident) and the reference's OWN Stage ``resolution``
+# (worlds/stage1.world:3 and stage2.world:3: 0.2 m; circle.world:3: 0.01 m).  ``stage_resolution=True`` selects the
+# latter: lidar ranges against walls and robot-vs-wall clearances are then quantised exactly as coarsely (or, for the
+# circle world, as finely) as in Stage's raster.  Together with ``collision_raster`` (robot-robot collision by shared
+# raster cells instead of exact rectangles) this is the fidelity mode for evaluating a policy under
+# Stage-like clearances.
+_STAGE_RES_MAPS = {"stage1_rink": "stage1_rink_r0200", "stage2_testenv": "stage2_testenv_r0200",
+                   "circle_rink": "circle_rink_r0010"}
+
+
+def _map(name, stage_resolution):
+    return load_map(_STAGE_RES_MAPS[name] if stage_resolution else name)
+
+
+def stage1(num_worlds=1, robots_per_world=24, seed=0, grid=None, stage_resolution=False):
     """Stage-1 rink: random poses/goals in the 9 m disc (stage_world1.py), NUM_ENV=24
     (ppo_stage1.py:32), every robot restarts on its own (ppo_stage1.py:51-58)."""
-    return Scenario("stage1", num_worlds, robots_per_world, grid or load_map("stage1_rink"), timeout=150,
-                    w_thresh=1.05, pre_dist_zero=False, auto_reset=AUTO_ROBOT, seed=seed)
+    return Scenario("stage1", num_worlds, robots_per_world, grid or _map("stage1_rink", stage_resolution), timeout=150,
+                    w_thresh=1.05, pre_dist_zero=False, auto_reset=AUTO_ROBOT, seed=seed,
+                    collision_raster=0.2 if stage_resolution else 0.0)
 
 
-def stage2(num_worlds=1, seed=0, grid=None):
+def stage2(num_worlds=1, seed=0, grid=None, stage_resolution=False):
     """Stage-2 map: 44 robots, tables for 0..33, random region for 34..43 (stage_world2.py:164-171,
     210-221), group-synchronous episodes (ppo_stage2.py:72-107, model/utils.py:83)."""
     tb = load_tables()["stage2"]
@@ -121,18 +138,18 @@ def stage2(num_worlds=1, seed=0, grid=None):
     gid = np.zeros(R, np.int32)
     for g in range(len(bounds) - 1):
         gid[bounds[g]: bounds[g + 1]] = g
-    return Scenario("stage2", num_worlds, R, grid or load_map("stage2_testenv"), timeout=200, w_thresh=1.05,
+    return Scenario("stage2", num_worlds, R, grid or _map("stage2_testenv", stage_resolution), timeout=200, w_thresh=1.05,
                     pre_dist_zero=True, auto_reset=AUTO_GROUP, seed=seed, reset_mode=mode, goal_mode=mode.copy(),
-                    init_table=init, goal_table=goal, group_id=gid)
+                    init_table=init, goal_table=goal, group_id=gid, collision_raster=0.2 if stage_resolution else 0.0)
 
 
-def circle(num_worlds=1, seed=0, grid=None):
+def circle(num_worlds=1, seed=0, grid=None, stage_resolution=False):
     """Circle test: 50 robots on r = 25 m, antipodal goals (circle_world.py:164-167,205-208),
     omega-penalty threshold 0.7 (:195), timeout 10000 (:198), nothing resets (circle_test.py:36-83)."""
     tb = load_tables()["circle"]
     R = tb["num_agents"]
     mode = np.full(R, RESET_TABLE, np.int32)
-    return Scenario("circle", num_worlds, R, grid or load_map("circle_rink"), timeout=10000, w_thresh=0.7,
+    return Scenario("circle", num_worlds, R, grid or _map("circle_rink", stage_resolution), timeout=10000, w_thresh=0.7,
                     pre_dist_zero=True, auto_reset=AUTO_NONE, seed=seed, reset_mode=mode, goal_mode=mode.copy(),
                     init_table=np.asarray(tb["init_pose"], np.float64),
                     goal_table=np.asarray(tb["goal_point"], np.float64))

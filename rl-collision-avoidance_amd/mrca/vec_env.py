@@ -48,7 +48,8 @@ class VecStageWorld:
             timeout=sc.timeout, w_thresh=sc.w_thresh, pre_dist_zero=int(sc.pre_dist_zero),
             auto_reset=sc.auto_reset, seed=sc.seed, reset_mode=reset_mode.ctypes.data,
             goal_mode=goal_mode.ctypes.data, init_table=init_table.ctypes.data,
-            goal_table=goal_table.ctypes.data, group_id=group_id.ctypes.data)
+            goal_table=goal_table.ctypes.data, group_id=group_id.ctypes.data,
+            collision_raster=float(getattr(sc, "collision_raster", 0.0)))
         nbytes = C.c_size_t()
         _lib.check(self.lib.mrca_arena_bytes(C.byref(cfg), C.byref(nbytes)), "mrca_arena_bytes")
         # the arena is a torch allocation so that every field is a plain torch view (zero copy)

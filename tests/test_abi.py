@@ -30,7 +30,7 @@ def test_header_symbols_exported(built_lib):
 
 
 def test_abi_version(built_lib):
-    assert built_lib.mrca_abi_version() == 1
+    assert built_lib.mrca_abi_version() == 2
 
 
 def _cfg(sc):

@@ -211,6 +211,59 @@ def test_full_size_slice_exact_and_properties(hip, name, worlds, R):
     env2.close()
 
 
+@pytest.mark.parametrize("name", ["stage1", "stage2"])
+def test_fidelity_mode_bit_exact(hip, name):
+    """Fidelity mode: the maps at the reference's OWN Stage resolution (0.2 m, worlds/stage1.world:3) and robots
+    colliding when their outlines share a 0.2 m raster cell -- bit-exact against the C oracle, which must also see
+    more crashes than with exact rectangles."""
+    sc = S.stage1(num_worlds=6, robots_per_world=24, seed=21, stage_resolution=True) if name == "stage1" else \
+        S.stage2(num_worlds=2, seed=21, stage_resolution=True)
+    assert sc.grid.cell == 0.2 and sc.collision_raster == 0.2
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    env.reset()
+    ora.reset()
+    rng = np.random.default_rng(4)
+    crashes = 0
+    for k in range(80):
+        a = U.random_actions(rng, sc.num_robots)
+        env.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+        crashes += int(((ora.result == 2) & (ora.done == 1)).sum())
+        if k % 4 == 3:
+            torch.cuda.synchronize()
+            U.assert_state_equal(U.HostView(env), ora, what=f"fidelity {name} step {k}")
+    assert crashes > 5
+    env.close()
+
+
+def test_circle_world_at_stage_resolution_bit_exact(hip):
+    """circle.world:3 resolution 0.01 m: a 6000 x 6000 cell map (144 MB free-rectangle field: far beyond L2).  Twenty
+    ticks of the go-to-goal controller, bit-exact against the C oracle's plain cell walk; the launch times go to the
+    log (what the fine raster costs)."""
+    sc = S.circle(num_worlds=2, stage_resolution=True)
+    assert sc.grid.cell == 0.01 and sc.grid.width == 6000
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    env.reset()
+    ora.reset()
+    torch.cuda.synchronize()
+    U.assert_state_equal(U.HostView(env), ora, what="circle r0.01 reset")
+    env.enable_timing(1)
+    for k in range(20):
+        lg = ora.local_goal
+        bearing = np.arctan2(lg[:, 1], lg[:, 0])
+        a = np.stack([np.full(sc.num_robots, 1.0), np.clip(2.0 * bearing, -1, 1)], 1).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda())
+        ora.step(a)
+        if k % 5 == 4:
+            torch.cuda.synchronize()
+            U.assert_state_equal(U.HostView(env), ora, what=f"circle r0.01 step {k}")
+    mv, ry, n = env.read_timing()
+    print(f"circle world at 0.01 m cells, 100 robots: move {mv / n * 1e3:.1f} us, ray cast {ry / n * 1e3:.1f} us per tick")
+    env.close()
+
+
 def test_gae_kernel(hip):
     """mrca_gae vs generate_train_data (model/ppo.py:122-139) restated in the oracle."""
     rng = np.random.default_rng(0)

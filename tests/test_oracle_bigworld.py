@@ -141,3 +141,40 @@ def test_slice_bounds_cover_every_robot_once():
             seen += list(range(lo, hi))
             assert hi - lo <= per
         assert seen == list(range(n))
+
+
+# ------------------------------------------------------------------------------------------------
+# fidelity mode: Stage's raster rule for robot-robot collisions + maps at the reference's own Stage resolutions
+def test_raster_collision_c_oracle_equals_numpy_oracle_and_is_stricter():
+    sc = S.stage1(num_worlds=2, robots_per_world=24, seed=5, stage_resolution=True)
+    assert sc.grid.cell == 0.2 and sc.collision_raster == 0.2          # worlds/stage1.world:3
+    exact = S.stage1(num_worlds=2, robots_per_world=24, seed=5, stage_resolution=True)
+    exact.collision_raster = 0.0
+    a, b, c = U.oracle_env(sc, np.float32), U.COracleEnv(sc), U.oracle_env(exact, np.float32)
+    for e in (a, b, c):
+        e.reset()
+    rng = np.random.default_rng(1)
+    crashes_raster = crashes_exact = 0
+    for k in range(40):
+        act = U.random_actions(rng, sc.num_robots)
+        for e in (a, b, c):
+            e.step(act)
+        U.assert_state_equal(b, a, what=f"raster step {k}")
+        crashes_raster += int(((a.result == 2) & (a.done == 1)).sum())
+        crashes_exact += int(((c.result == 2) & (c.done == 1)).sum())
+    assert crashes_raster > crashes_exact > 0        # outlines that share a 0.2 m cell collide up to a cell apart
+
+
+def test_outline_cells_contain_the_corner_cells_and_stay_near_the_footprint():
+    f = np.float32
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        x, y, th = f(rng.uniform(-5, 5)), f(rng.uniform(-5, 5)), f(rng.uniform(-np.pi, np.pi))
+        s, c = O.sincos(np.array([th], f), f)
+        cells = O.outline_cells(0.2, x, y, s[0], c[0], f)
+        cx, cy = O.footprint_corners(np.array([x]), np.array([y]), s, c, f)
+        for k in range(4):
+            assert (int(np.floor(cx[0, k] * f(5.0))), int(np.floor(cy[0, k] * f(5.0)))) in cells
+        for (ix, iy) in cells:      # every cell lies within circumradius + one cell diagonal of the centre
+            assert np.hypot((ix + 0.5) * 0.2 - x, (iy + 0.5) * 0.2 - y) < 0.2907 + 0.2 * 1.4143
+        assert 6 <= len(cells) <= 24

@@ -26,7 +26,8 @@ def oracle_env(sc, dtype=np.float32, first_world=0, num_worlds=None):
                          timeout=sc.timeout, w_thresh=sc.w_thresh,
                          pre_dist_zero=sc.pre_dist_zero, auto_reset=sc.auto_reset, seed=sc.seed,
                          reset_mode=sc.reset_mode, init_table=sc.init_table, goal_table=sc.goal_table,
-                         group_id=sc.group_id, beams=sc.beams, frames=sc.frames, first_world=first_world)
+                         group_id=sc.group_id, beams=sc.beams, frames=sc.frames, first_world=first_world,
+                         collision_raster=getattr(sc, "collision_raster", 0.0))
     cfg.goal_mode = np.asarray(sc.goal_mode, np.int32)
     return O.OracleEnv(cfg, dtype)
 
@@ -194,7 +195,7 @@ class OracleBackend:
 
 # ------------------------------------------------------------------------------------------------
 class _OcEnvStruct(C.Structure):
-    _fields_ = _EmulEnvStruct._fields_ + [("first_world", C.c_int32)]
+    _fields_ = _EmulEnvStruct._fields_ + [("first_world", C.c_int32), ("raster_res", C.c_float)]
 
 
 _oc_lib = None
@@ -225,6 +226,7 @@ class COracleEnv(EmulEnv):
         for name, _t in _EmulEnvStruct._fields_:
             setattr(st, name, getattr(self._st, name))
         st.first_world = first_world
+        st.raster_res = float(getattr(sc, "collision_raster", 0.0))
         self._st = st
 
     def reset(self, mask=None, poses=None, goals=None):

@@ -76,6 +76,16 @@ def main():
     gc = raster_bitmap(os.path.join(REF, "worlds", wc["bitmap"]), wc["size"][:2], cell_c)
     save_map("circle_rink", gc, wc["size"][:2], cell_c, {"stage_resolution": wc["resolution"]})
 
+    # the same maps at the reference's OWN Stage resolutions (worlds/stage1.world:3, stage2.world:3: 0.2 m;
+    # circle.world:3: 0.01 m) for the fidelity scenarios (scenario.*(..., stage_resolution=True)): wall ranges and
+    # robot-vs-wall clearances are then quantised like Stage's raster
+    for name, w, cell_f, polys in (("stage1_rink_r0200", w1, 0.2, None), ("stage2_testenv_r0200", w2, 0.2, w2["obstacles"]),
+                                   ("circle_rink_r0010", wc, 0.01, None)):
+        g = raster_bitmap(os.path.join(REF, "worlds", w["bitmap"]), w["size"][:2], cell_f)
+        if polys:
+            g = raster_polygons(g, polys, w["size"][:2], cell_f)
+        save_map(name, g, w["size"][:2], cell_f, {"stage_resolution": w["resolution"]})
+
     def agents_xyth(w):
         # .world poses are [x y z yaw_deg]; wrap yaw to (-pi, pi] like the GT quaternion round trip
         out = []
