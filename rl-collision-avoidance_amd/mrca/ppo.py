@@ -289,7 +289,8 @@ class KLAdaptiveLR:
 
 
 def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, drop_last, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype=None, kl_ctl=None, max_grad_norm=0.0):
+                index_batches, dist, flat_grads, log, autocast_dtype=None, kl_ctl=None, max_grad_norm=0.0,
+                logstd_min=None):
     obss, goals, speeds, actions, logprobs, targets, advs = flat
     n = advs.shape[0]
     multi = _world_size(dist) > 1
@@ -336,6 +337,9 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
                 else:
                     torch.nn.utils.clip_grad_norm_(policy.parameters(), max_grad_norm)
             optimizer.step()
+            if logstd_min is not None:      # opt-in floor on the exploration noise (see trainer.HParams.logstd_min)
+                with torch.no_grad():
+                    policy.logstd.clamp_(min=logstd_min)
             stop = False
             if kl_ctl is not None:
                 with torch.no_grad():
@@ -356,7 +360,7 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
 def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entropy=0.02, clip_value=0.2,
                       num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *, value_coef=20.0,
                       index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None, kl_ctl=None,
-                      max_grad_norm=0.0):
+                      max_grad_norm=0.0, logstd_min=None):
     """model/ppo.py:143-194.  ``memory`` = (obss, goals, speeds, actions, logprobs, targets, values,
     rewards, advs) as device tensors shaped [T, N, ...] (obss may be a FrameRows: one stored frame per tick)."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -367,13 +371,13 @@ def ppo_update_stage1(policy, optimizer, batch_size, memory, epoch, coeff_entrop
     flat = (obs_rows, goals.reshape(n, 2), speeds.reshape(n, 2),
             actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1), advs.reshape(n, 1))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, False, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl, max_grad_norm)
+                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl, max_grad_norm, logstd_min)
 
 
 def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch, coeff_entropy=0.02,
                       clip_value=0.2, num_step=2048, num_env=12, frames=1, obs_size=24, act_size=4, *,
                       value_coef=20.0, index_batches=None, dist=None, flat_grads=None, log=None, autocast_dtype=None,
-                      kl_ctl=None, max_grad_norm=0.0):
+                      kl_ctl=None, max_grad_norm=0.0, logstd_min=None):
     """model/ppo.py:197-259: the advantage statistics use ALL transitions, then the filtered rows
     are deleted and minibatches use drop_last=True."""
     obss, goals, speeds, actions, logprobs, targets, _values, _rewards, advs = memory
@@ -388,4 +392,4 @@ def ppo_update_stage2(policy, optimizer, batch_size, memory, filter_index, epoch
                                    actions.reshape(n, act_size), logprobs.reshape(n, 1), targets.reshape(n, 1),
                                    advs.reshape(n, 1)))
     _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, True, value_coef,
-                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl, max_grad_norm)
+                index_batches, dist, flat_grads, log, autocast_dtype, kl_ctl, max_grad_norm, logstd_min)

@@ -78,6 +78,7 @@ def main(argv=None):
     ap.add_argument("--max-seconds", type=float, default=0.0, help="stop after this much wall time (0 = no limit)")
     ap.add_argument("--kl-stop", type=float, default=0.0, help="abandon an update when a minibatch's KL exceeds this x kl-target")
     ap.add_argument("--max-grad-norm", type=float, default=0.0, help="> 0: global-norm gradient clipping (opt-in)")
+    ap.add_argument("--logstd-min", type=float, default=None, help="floor of the policy's log std (opt-in; e.g. -1.2)")
     ap.add_argument("--mix-circle", type=int, default=0, help="stage 2: add this many 50-robot circle worlds "
                                                                 "(scenario.circle_train) to the training mix")
     ap.add_argument("--stock-policy-path", action="store_true", help="rollout inference through the stock PyTorch layers "
@@ -111,6 +112,8 @@ def main(argv=None):
         if v is not None:
             setattr(hp, k, v)
     hp.kl_target, hp.lr_max, hp.kl_stop, hp.max_grad_norm = a.kl_target, a.lr_max, a.kl_stop, a.max_grad_norm
+    if a.logstd_min is not None:
+        hp.logstd_min = a.logstd_min
     hp.rollout_fused = not a.stock_policy_path and not a.bf16_inference
     hp.graph_tick = not a.no_graph
     if a.bf16_update:

@@ -38,6 +38,10 @@ class HParams:
     kl_target: float = 0.0            # > 0: KL-adaptive learning rate (ppo.KLAdaptiveLR; opt-in, large-batch regime)
     lr_max: float = 1e-3
     kl_stop: float = 0.0              # > 0: abandon the rest of an update when a minibatch reports KL > kl_stop x kl_target
+    # > -inf: floor of the policy's log standard deviation.  The reference lets logstd run free (model/net.py:33) and
+    # trains ~30 k optimiser steps at lr 5e-5; at 10x the steps the noise of the speed channel collapses (sigma 0.05,
+    # then 0.003: profiles/r02_b_*), the importance ratios blow up and the policy degrades -- opt-in floor.
+    logstd_min: float = float("-inf")
     max_grad_norm: float = 0.0        # > 0: global-norm gradient clipping (opt-in; the reference clips nothing)
 
 
@@ -112,11 +116,11 @@ class Stage1Trainer:
     def tick(self):
         """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
         env, hp, buf = self.env, self.hp, self.buffer
+        if hp.graph_tick and self._graph is None:
+            self._capture()                 # (its warm-up ticks advance the env: before the horizon's first row is set up)
         if self.t == 0:
             buf.begin_horizon(env.obs)      # one-frame store: the older frames of the stack the first tick sees
         if hp.graph_tick:
-            if self._graph is None:
-                self._capture()
             self._graph.replay()
         else:
             v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
@@ -141,7 +145,8 @@ class Stage1Trainer:
                   epoch=hp.epoch, coeff_entropy=hp.coeff_entropy, clip_value=hp.clip_value, num_step=hp.horizon,
                   num_env=env.N, frames=hp.laser_hist, obs_size=hp.obs_size, act_size=hp.act_size,
                   value_coef=hp.value_coef, dist=self.dist, flat_grads=self.flat_grads, log=self.loss_log,
-                  autocast_dtype=hp.update_dtype, kl_ctl=self.kl_ctl, max_grad_norm=hp.max_grad_norm)
+                  autocast_dtype=hp.update_dtype, kl_ctl=self.kl_ctl, max_grad_norm=hp.max_grad_norm,
+                  logstd_min=hp.logstd_min if hp.logstd_min > float("-inf") else None)
         if self.stage2:
             ppo.ppo_update_stage2(filter_index=ppo.get_filter_index(buf.done), **kw)
         else:

@@ -28,15 +28,14 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
     env.reset()
     for k in range(50):
         env.step(pool[k % 8])
-    for flags, label in ((0, "full"), (1, "no neighbour tests"), (2, "no march"), (3, "no march, no neighbours"),
-                         (8, "move: no outline test"),
-                         (16, "move: no collision loop"), (32, "move: no resets"), (56, "move: none of the three"), 
-                         (256, "512 marching threads (1 beam each) + prep wave"),
-                         (512, "256 marching threads (2 beams in lock step) + prep wave"),
-                         (768, "128 marching threads (4 beams in lock step) + prep wave"),
-                         (256 + 2048, "512 threads, wave 0 prepares"), (512 + 2048, "256 threads, wave 0 prepares"),
-                         (768 + 2048, "128 threads, wave 0 prepares"),
-                         (0, "full again")):
+    for flags, label in ((0, "full (product shape)"), (1, "no neighbour tests"), (2, "no march"), (3, "no march, no neighbours"),
+                         (8, "move: no outline test"), (16, "move: no collision loop"), (32, "move: no resets"),
+                         (56, "move: none of the three"), (64, "frame-stack shift as a launch of its own"),
+                         (256, "1 beam/thread, 512 thr + prep wave"), (512, "2 beams lock-step, 256 thr + prep wave"),
+                         (512 + 4096, "2 beams sequential, 256 thr + prep wave"), (768, "4 beams lock-step, 128 thr + prep wave"),
+                         (256 + 2048, "1 beam/thread, wave 0 prepares"), (512 + 2048, "2 beams lock-step, wave 0 prepares"),
+                         (512 + 4096 + 2048, "2 beams sequential, wave 0 prepares (r01 structure)"),
+                         (768 + 2048, "4 beams lock-step, wave 0 prepares"), (0, "full again")):
         try:
             env.set_debug_flags(flags)
         except Exception as exc:  # a variant this build / map does not support
@@ -50,6 +49,7 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
             env.step(pool[k % 8])
         mv, ry, n = env.read_timing()
         env.enable_timing(False)
-        print(f"{name:<14} flags={flags} {label:<44} ray {ry / n * 1e3:8.1f} us   move {mv / n * 1e3:7.1f} us")
+        print(f"{name:<14} flags={flags:<5} {label:<52} ray {ry / n * 1e3:8.1f} us   move {mv / n * 1e3:7.1f} us   "
+              f"sum {(ry + mv) / n * 1e3:7.1f} us")
     env.set_debug_flags(0)
     env.close()

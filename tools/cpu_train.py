@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--load", default=None)
     ap.add_argument("--save", default=None)
     ap.add_argument("--circle-every", type=int, default=0)
+    ap.add_argument("--logstd-min", type=float, default=None)
+    ap.add_argument("--kl-stop", type=float, default=0.0)
+    ap.add_argument("--lr-max", type=float, default=1e-3)
+    ap.add_argument("--max-grad-norm", type=float, default=0.0)
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     os.environ.setdefault("OMP_NUM_THREADS", str(a.threads))
@@ -96,8 +100,10 @@ def main():
         hp.batch_size = a.batch_size
     if a.epoch:
         hp.epoch = a.epoch
-    if hasattr(hp, "kl_target"):
-        hp.kl_target = a.kl_target
+    hp.kl_target, hp.kl_stop, hp.lr_max, hp.max_grad_norm = a.kl_target, a.kl_stop, a.lr_max, a.max_grad_norm
+    hp.single_frame_buffer = True
+    if a.logstd_min is not None:
+        hp.logstd_min = a.logstd_min
     env = CpuEnv(sc)
     tr = Stage1Trainer(env, hp=hp, seed=a.seed, stage2=(a.stage == 2))
     if a.load:
