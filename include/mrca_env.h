@@ -179,8 +179,9 @@ int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32_t frames, 
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product
  * library neither exports this symbol nor contains the switches.  Results are WRONG while any of bits 0-5 is
  * set: 1 = skip robot-robot lidar tests, 2 = skip the grid march, 8 / 16 / 32 = move kernel without its outline
- * test / collision loop / resets.  Launch-shape knobs (results unchanged): bits 8-10 = k > 0: 1 << (k-1) beams per
- * marching thread; bit 11: no dedicated preparation wave.  0 restores the product path. */
+ * test / collision loop / resets.  Launch-shape knobs (results unchanged): bit 6: the frame-stack shift as a launch of its own;
+ * bits 8-10 = k > 0: 1 << (k-1) beams per marching thread; bit 11: a dedicated preparation wave; bit 12: the beams of a
+ * thread marched in lock step.  0 restores the product path. */
 int mrca_set_debug_flags(mrca_env* env, int32_t flags);
 #endif
 

@@ -405,11 +405,17 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
         v.collide_reach2 = cfg->collision_raster > 0.0f ? reach * reach : mrca::kCollideReach2;
     }
     v.debug_flags = 0;
-    // 256 marching threads per 512-beam robot, 2 beams each in lock step, plus one wave that prepares the neighbour
-    // list while the others march (variants measured in profiles/: threads per robot, with / without that wave)
+    // Launch shape of the ray cast, measured (profiles/r02_c_ablation_launch_shapes.txt, 4096 / 8228 robots, HIP events):
+    //   2 beams per thread one after the other, first wave prepares the neighbours   28.1 / 33.7 us   <- product
+    //   1 beam per thread (512 threads), first wave prepares                           31.6 / 41.1 us
+    //   2 beams per thread in lock step (two lookups in flight), first wave prepares   34.7 / 37.9 us
+    //   the same three with a dedicated fifth preparation wave                          31.5-37.8 / 39.9-48.5 us
+    // i.e. neither more lookups in flight per thread nor taking the preparation off the marching waves pays: the
+    // lock-step loop costs 62 instead of 54 VALU instructions per jump and keeps finished rays idling, the extra
+    // wave costs a resident workgroup per CU.
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
-    v.ray_prep_wave = 1;
-    v.ray_sequential = 0;
+    v.ray_prep_wave = 0;
+    v.ray_sequential = 1;
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (!v.big && mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
@@ -513,8 +519,8 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 #if defined(MRCA_PROFILING)
 // Profiling build only (libmrca_env_prof.so): ablation switches (results are WRONG while bits 0-5 are set) and
 // launch-shape knobs (results unchanged): bit 6: the frame-stack shift as a launch of its own; bits 8-10 = k > 0:
-// 1 << (k-1) beams per marching thread; bit 11: no dedicated preparation wave; bit 12: two beams marched one after the
-// other instead of in lock step.
+// 1 << (k-1) beams per marching thread; bit 11: a dedicated fifth preparation wave; bit 12: the beams of a thread marched
+// in lock step instead of one after the other.
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     env->view.debug_flags = flags & 0x7F;
@@ -528,8 +534,8 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     } else {
         env->view.ray_shift = (env->cfg.beams >= 256) ? 1 : 0;   // the product's launch shape
     }
-    env->view.ray_prep_wave = (flags & 0x800) ? 0 : 1;
-    env->view.ray_sequential = (flags & 0x1000) ? 1 : 0;
+    env->view.ray_prep_wave = (flags & 0x800) ? 1 : 0;
+    env->view.ray_sequential = (flags & 0x1000) ? 0 : 1;
     return MRCA_OK;
 }
 #endif

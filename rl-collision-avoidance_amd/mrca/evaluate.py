@@ -107,9 +107,13 @@ def main():
     ap.add_argument("--policy", default=None, help="state_dict file with the reference's keys (policy/stage2.pth)")
     ap.add_argument("--max-ticks", type=int, default=1200)   # circle_world.py:198 allows 10000
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--robots", type=int, default=50, help="robots per circle (50 = the reference's table; others: scenario.circle_n)")
+    ap.add_argument("--radius", type=float, default=25.0)
     a = ap.parse_args()
     from .vec_env import VecStageWorld
-    env = VecStageWorld(scenario.circle(num_worlds=a.circles, seed=a.seed))
+    sc = scenario.circle(num_worlds=a.circles, seed=a.seed) if (a.robots == 50 and a.radius == 25.0) else \
+        scenario.circle_n(a.robots, a.radius, num_worlds=a.circles, seed=a.seed)
+    env = VecStageWorld(sc)
     if a.policy:
         pol = CNNPolicy(3, 2).to(env.device)
         pol.load_state_dict(torch.load(a.policy, map_location=env.device))
@@ -118,6 +122,7 @@ def main():
         fn, name = staggered_roundabout_policy(env.N), "staggered-roundabout stand-in (no checkpoint given)"
     out = circle_test(env, fn, a.max_ticks)
     out["policy"] = name
+    out["robots_per_circle"], out["radius_m"] = a.robots, a.radius
     print(json.dumps(out))
 
 

@@ -187,3 +187,18 @@ def circle_train(num_worlds=1, seed=0, timeout=900, grid=None):
     sc = circle(num_worlds, seed, grid)
     sc.name, sc.timeout, sc.auto_reset = "circle_train", int(timeout), AUTO_GROUP
     return sc
+
+
+def circle_n(robots, radius, num_worlds=1, seed=0, train=False, timeout=None, grid=None):
+    """Smaller relatives of the circle test inside the same 60 m rink: ``robots`` (<= 64) robots evenly spaced on a
+    circle of ``radius`` metres (<= 27), facing the centre, antipodal goals; reward constants of circle_world.py.
+    ``train=True``: one group that restarts together (like ``circle_train``).  The paper's evaluation uses such circles
+    of 4 ... 20 robots (Long et al. 2018, Sec. V); the reference checkout only ships the 50-robot table."""
+    R = int(robots)
+    ang = 2.0 * np.pi * np.arange(R) / R
+    init = np.stack([radius * np.cos(ang), radius * np.sin(ang), ang + np.pi], 1)
+    mode = np.full(R, RESET_TABLE, np.int32)
+    t = int(timeout if timeout is not None else (40 * radius + 300 if train else 10000))
+    return Scenario("circle_train" if train else "circle", num_worlds, R, grid or load_map("circle_rink"), timeout=t,
+                    w_thresh=0.7, pre_dist_zero=True, auto_reset=AUTO_GROUP if train else AUTO_NONE, seed=seed,
+                    reset_mode=mode, goal_mode=mode.copy(), init_table=init, goal_table=-init[:, :2])

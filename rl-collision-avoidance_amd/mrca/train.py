@@ -81,6 +81,8 @@ def main(argv=None):
     ap.add_argument("--logstd-min", type=float, default=None, help="floor of the policy's log std (opt-in; e.g. -1.2)")
     ap.add_argument("--mix-circle", type=int, default=0, help="stage 2: add this many 50-robot circle worlds "
                                                                 "(scenario.circle_train) to the training mix")
+    ap.add_argument("--mix-circles", default="", help="stage 2: extra circle worlds as 'robots:radius:worlds,...' "
+                                                         "(scenario.circle_n, e.g. 10:8:40,20:12:30)")
     ap.add_argument("--stock-policy-path", action="store_true", help="rollout inference through the stock PyTorch layers "
                                                                        "instead of the fused fp32 HIP front end")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout tick kernel by kernel, not as a hipGraph")
@@ -128,11 +130,18 @@ def main(argv=None):
         # epoch per rank; the global batch of one optimiser step is world_size x this.
         hp.batch_size = max(hp.batch_size, sc.num_robots * hp.horizon // 32)
     env = VecStageWorld(sc)
-    if a.mix_circle > 0:
+    if a.mix_circle > 0 or a.mix_circles:
         from .multi_env import ConcatEnv
-        env = ConcatEnv([env, VecStageWorld(scenario.circle_train(num_worlds=a.mix_circle, seed=a.seed * 1000 + rank))])
-        out.info("training mix: %d robots of %s + %d robots in %d circle worlds", sc.num_robots, sc.name,
-                 env.N - sc.num_robots, a.mix_circle)
+        parts = [env]
+        if a.mix_circle > 0:
+            parts.append(VecStageWorld(scenario.circle_train(num_worlds=a.mix_circle, seed=a.seed * 1000 + rank)))
+        for spec in filter(None, a.mix_circles.split(",")):
+            r, rad, w = spec.split(":")
+            parts.append(VecStageWorld(scenario.circle_n(int(r), float(rad), num_worlds=int(w), seed=a.seed * 1000 + rank,
+                                                         train=True)))
+        env = ConcatEnv(parts)
+        out.info("training mix: %d robots of %s + %d robots in circle worlds (%s)", sc.num_robots, sc.name,
+                 env.N - sc.num_robots, ", ".join("%d x %d robots" % (p.W, p.R) for p in parts[1:]))
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=a.seed, stage2=(a.stage == 2))
     out.info("per-rank minibatch %d rows, global batch per optimiser step %d, lr %g, epochs %d, horizon %d",
              hp.batch_size, hp.batch_size * world_size, hp.learning_rate, hp.epoch, hp.horizon)
