@@ -32,7 +32,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BYTES_PER_AGENT_STEP = 10332   # SURVEY 8(d) B_env_stack: 2140 + frame-stack shift (4096 read + 4096 write)
+BYTES_PER_AGENT_STEP = 10332   # SURVEY 8(d) B_env_stack: 2140 + frame-stack shift (4096 read + 4096 write), per TICK
+# per LAUNCH, since round 2 (the frame-stack shift rides in the move kernel's launch):
+RAY_BYTES_PER_AGENT_STEP = 2 * 4 * 512 + 48    # scan + newest obs frame written, pose / head / goal / flag read, local goal
+MOVE_BYTES_PER_AGENT_STEP = 2 * 4096 + 108     # two frames read + written one slot down, ~0.1 kB of robot state
 
 
 def kernel_source_hash():
@@ -61,8 +64,12 @@ def pmc_traffic(robots, scenario):
     if d.get("scenario", "stage1") != scenario:
         return None, f"profiles/pmc_traffic.json is for scenario {d.get('scenario', 'stage1')}"
     per_robot = (2.0 * d["fetch_kib"] + d["write_kib"]) * 1024.0 / d["robots"]
-    return per_robot * robots, ("bytes/launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes on these "
-                                "kernel sources; 2*FETCH_SIZE + WRITE_SIZE)")
+    note = ("bytes/launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes on these kernel sources; "
+            "2*FETCH_SIZE + WRITE_SIZE)")
+    if d.get("move_fetch_kib") is not None:
+        mv = (2.0 * d["move_fetch_kib"] + d["move_write_kib"]) * 1024.0 / d["robots"] * robots
+        note += f"; the move kernel's launch (incl. the frame-stack shift): {mv / 1e6:.1f} MB"
+    return per_robot * robots, note
 
 
 def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
@@ -286,8 +293,11 @@ def main():
 
     if rank == 0:
         ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
+        mv_avg_s = (mv_ms / launches) * 1e-3 if launches else float("nan")
         traffic, traffic_note = pmc_traffic(N, args.scenario)
-        achieved = BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
+        achieved = RAY_BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
+        tick_achieved = BYTES_PER_AGENT_STEP * N / (ray_avg_s + mv_avg_s) / 1e9 if launches else None
+        move_achieved = MOVE_BYTES_PER_AGENT_STEP * N / mv_avg_s / 1e9 if launches else None
         out = {
             "metric": "agent-steps/s (N robots x 512-beam lidar)" if args.mode == "env" else
                       f"agent-steps/s ({args.mode}: env + policy" + (" + GAE + PPO update)" if args.mode == "train" else ")"),
@@ -306,10 +316,19 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_note": traffic_note,
-                         "bytes_per_agent_step": BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
+                         "bytes_per_agent_step": RAY_BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
+                         "tick": {"achieved": tick_achieved, "frac": tick_achieved / HBM_PEAK_GBS if tick_achieved else None,
+                                  "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
+                                  "note": "SURVEY 8d B_env_stack over BOTH launches of the tick (move + frame-stack "
+                                          "shift, ray cast)"},
+                         "move_launch": {"achieved": move_achieved,
+                                         "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
+                                         "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
-                         "note": "HBM is the nominal roof (SURVEY 8d); the kernel is bound by VALU issue and dependent L2 lookups in the ray march, see DESIGN.md 5"},
+                         "note": "HBM is the nominal roof (SURVEY 8d); the ray cast is bound by VALU issue in the march and by its "
+                                 "per-robot latency chain, not by traffic -- it no longer moves the frame stack (that is the "
+                                 "move launch's 8.2 kB per agent-step); see DESIGN.md 5"},
         }
         if args.mode == "rollout":
             # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2
