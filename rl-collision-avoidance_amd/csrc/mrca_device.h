@@ -587,9 +587,23 @@ MRCA_HD float ray_box(float ox, float oy, float dx, float dy, float xj, float yj
 
 // Conservative set of beams that can touch another robot: the rectangle lies inside its
 // circumscribed circle (radius 0.2907 m), so only beams within asin(r/dist) of the bearing of its
-// centre can hit it.  Two beam widths + 1 mm of slack absorb every rounding in here (atan2f/asinf
-// are only used for this cull, never for a reported value); culled beams provably miss, so the
-// minimum over the kept tests equals the minimum over all of them.
+// centre can hit it.  Only the cull uses these numbers, never a reported value, and culled beams provably miss,
+// so the minimum over the kept tests equals the minimum over all of them -- which is why the two angles may be
+// cheap UPPER / approximate bounds instead of libm calls (each ~100 instructions on the path of the preparing
+// wave): asin(x) <= x + (pi/2 - 1) x^3 on [0, 1] (the gap asin(x) - x over x^3 grows monotonically from 1/6 to
+// pi/2 - 1), and a degree-7 odd polynomial for atan (|error| < 1.2e-4 rad).  Two beam widths + 1 mm of radius +
+// 3e-3 rad of slack absorb the approximation and every rounding in here.
+MRCA_HD float atan2_approx(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    const float z = a * a;
+    float r = ((-0.0464964749f * z + 0.15931422f) * z - 0.327622764f) * z * a + a;
+    r = ay > ax ? 1.57079637f - r : r;
+    r = x < 0.0f ? 3.14159274f - r : r;
+    return y < 0.0f ? -r : r;
+}
+
 MRCA_HD void beam_interval(float lx, float ly, int beams, int* lo, int* hi) {
     const float dist = sqrtf(lx * lx + ly * ly);
     if (dist <= 0.30f) {
@@ -598,9 +612,10 @@ MRCA_HD void beam_interval(float lx, float ly, int beams, int* lo, int* hi) {
         return;
     }
     const float step = kPi / (float)(beams - 1);
-    const float ratio = 0.2917f / dist;
-    const float alpha = asinf(ratio < 1.0f ? ratio : 1.0f) + 2.0f * step;
-    const float phi = atan2f(ly, lx);
+    float ratio = 0.2917f / dist;
+    ratio = ratio < 1.0f ? ratio : 1.0f;
+    const float alpha = (ratio + 0.5708f * (ratio * ratio * ratio)) + 2.0f * step + 3e-3f;
+    const float phi = atan2_approx(ly, lx);
     const float inv_step = (float)(beams - 1) / kPi;
     const float flo = (phi - alpha + 0.5f * kPi) * inv_step;
     const float fhi = (phi + alpha + 0.5f * kPi) * inv_step;

@@ -574,9 +574,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     float4* nb = reinterpret_cast<float4*>(lds);
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
-    float* rbuf = reinterpret_cast<float*>(nb_count + 4);             // [B] ranges for the wide epilogue
-    float* obuf = rbuf + e.B;                                         // [B] normalised ranges
-    unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(obuf + e.B);   // [B] neighbours per beam
+    unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(nb_count + 4);   // [B] neighbours per beam
     int* nb_more = nb_count + 1;                                      // big worlds: another chunk of neighbours follows
 
     const int T = e.B / K;                    // marching threads
@@ -609,9 +607,6 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         bc[k] = e.beam_cos[b];
         bs[k] = e.beam_sin[b];
     }
-    const bool wide = tid < (e.B >> 2);
-    const int fstride = e.B >> 2;
-    float4* ob4 = reinterpret_cast<float4*>(e.obs + (size_t)n * e.F * e.B);
     // (The frame-stack shift -- ppo_stage1.py:87-89: popleft / append -- does not depend on this tick's ranges: it ran
     // before this kernel, next to the move kernel, see shift_frames.  Here only the newest frame is appended.)
     // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
@@ -752,25 +747,24 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         __syncthreads();          // ... and the next one is ready
     }
     if (!marches) return;
+    // --- scan, normalised observation (stage_world1.py:140), newest frame of the stack (ppo_stage1.py:59-60,87-89):
+    //     every thread stores its own beams -- lane l of a wave holds beam base + l, so each store instruction of a
+    //     wave covers 256 contiguous bytes.  (Round 1 went through LDS so that a quarter of the threads could move 16
+    //     bytes each: one more barrier and an LDS round trip for the same two cache lines per wave.)
+    {
+        float* scan_row = e.scan + (size_t)n * e.B;
+        float* obs_row = e.obs + (size_t)n * e.F * e.B;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int b = tid + k * T;
-        const float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
-        rbuf[b] = r;
-        obuf[b] = norm_obs(r);     // stage_world1.py:140, once per value, spread over all marching threads
-    }
-
-    // --- scan, normalised observation, frame stack (ppo_stage1.py:59-60,87-89): ranges went through LDS so
-    //     that a quarter of the threads can move 16 bytes each
-    __syncthreads();
-    if (wide) {
-        const float4 r4 = reinterpret_cast<const float4*>(rbuf)[tid];
-        const float4 o4 = reinterpret_cast<const float4*>(obuf)[tid];
-        reinterpret_cast<float4*>(e.scan + (size_t)n * e.B)[tid] = r4;
-        if (fresh) {
-            for (int f = 0; f < e.F; ++f) ob4[f * fstride + tid] = o4;
-        } else {
-            ob4[(e.F - 1) * fstride + tid] = o4;      // the older frames were shifted down by shift_frames
+        for (int k = 0; k < K; ++k) {
+            const int b = tid + k * T;
+            const float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
+            const float o = norm_obs(r);
+            scan_row[b] = r;
+            if (fresh) {
+                for (int f = 0; f < e.F; ++f) obs_row[f * e.B + b] = o;
+            } else {
+                obs_row[(e.F - 1) * e.B + b] = o;      // the older frames were shifted down by shift_frames
+            }
         }
     }
     if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
@@ -1071,7 +1065,7 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 }  // namespace
 
 size_t ray_lds_bytes(const EnvView& e) {
-    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 16;
+    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 8;
 }
 
 size_t move_lds_bytes(const EnvView& e) {

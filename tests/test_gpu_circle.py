@@ -1,9 +1,11 @@
-"""GPU: circle-test success-rate parity -- HIP env vs the oracle env driven by the SAME policy
-(BASELINE north-star: "success-rate parity on circle_test.py").  ``policy/stage2.pth`` is missing
-from the reference checkout (.MISSING_LARGE_BLOBS), so two stand-ins are used: a seeded
-random-init CNNPolicy (the reference architecture) and a hand-written go-to-goal controller that
-produces non-trivial outcomes.  The policy runs on the GPU for both environments so both see
-bit-identical actions; the environments are bit-exact, hence SR must be EQUAL, not just within 2 pp."""
+"""GPU: the circle test (circle_test.py:36-83) -- success rate of the SELF-TRAINED checkpoint committed under
+``mrca/data/`` (``policy/stage2.pth`` is missing from the reference checkout, .MISSING_LARGE_BLOBS), and success-rate
+parity HIP env vs oracle env driven by the SAME policy (BASELINE north-star: "success-rate parity on circle_test.py").
+Parity is also checked with two stand-ins that need no training: a seeded random-init CNNPolicy (the reference
+architecture) and a hand-written controller with a non-trivial outcome mix.  The policy runs on the GPU for both
+environments so both see bit-identical actions; the environments are bit-exact, hence SR must be EQUAL, not just
+within 2 pp."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -35,7 +37,47 @@ class OracleAsVec:
         self._sync()
 
 
-@pytest.mark.parametrize("which", ["controller", "cnn"])
+CHECKPOINT = os.path.join(U.ROOT, "rl-collision-avoidance_amd", "mrca", "data", "policy_r02_stage2_circles.pth")
+
+
+def _trained_policy():
+    from mrca.net import CNNPolicy
+    pol = CNNPolicy(3, 2).cuda()
+    pol.load_state_dict(torch.load(CHECKPOINT, map_location="cuda"))
+    return pol
+
+
+def test_trained_checkpoint_solves_the_circle_test():
+    """The committed checkpoint (Stage-1 -> Stage-2 worlds mixed with circles of 10-50 robots, profiles/r02_d_*;
+    sha256 87d8d5d6...) on the reference's 50-robot circle: every robot must reach its antipodal goal.  Deterministic
+    mean action, first terminal event latched; also at 1000 robots (20 circles) and through the fused
+    fp32 rollout path of the policy."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    from mrca import evaluate, ppo
+    from mrca.vec_env import VecStageWorld
+    pol = _trained_policy()
+    for circles in (1, 20):
+        env = VecStageWorld(S.circle(num_worlds=circles, seed=0))
+        m = evaluate.circle_test(env, evaluate.cnn_policy_fn(pol), max_ticks=1500)
+        print(f"trained checkpoint, {circles} circle(s):", m)
+        assert m["success_rate"] >= 0.9 and m["crash_rate"] <= 0.1
+        assert m["average_speed_mps"] > 0.5 and m["extra_time_s"] < 60
+        env.close()
+    env = VecStageWorld(S.circle(num_worlds=1, seed=0))
+    pol.refresh_rollout_cache()
+
+    def fused(obs, goal, speed):
+        return ppo.generate_action_no_sampling(pol, obs, goal, speed, evaluate.ACTION_BOUND, fused=True)[1]
+    m = evaluate.circle_test(env, fused, max_ticks=1500)
+    print("trained checkpoint, fused fp32 rollout path:", m)
+    assert m["success_rate"] >= 0.9
+    env.close()
+
+
+@pytest.mark.parametrize("which", ["controller", "cnn", "trained"])
 def test_circle_success_rate_parity(which):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -50,6 +92,9 @@ def test_circle_success_rate_parity(which):
         pol = CNNPolicy(3, 2).cuda()
         fn = evaluate.cnn_policy_fn(pol)
         ticks = 120
+    elif which == "trained":
+        fn = evaluate.cnn_policy_fn(_trained_policy())
+        ticks = 1500
     else:
         fn = evaluate.staggered_roundabout_policy(sc.num_robots)
         ticks = 1100
@@ -61,6 +106,8 @@ def test_circle_success_rate_parity(which):
     assert m_hip["success_rate"] == m_ora["success_rate"]
     if which == "controller":
         assert 0.3 < m_hip["success_rate"] < 1.0 and m_hip["crash_rate"] > 0.02   # a non-trivial outcome mix
+    if which == "trained":
+        assert m_hip["success_rate"] >= 0.9
     assert m_hip["crash_rate"] == m_ora["crash_rate"]
     assert m_hip["ticks_run"] == m_ora["ticks_run"]
     assert np.array_equal(env.first_result.cpu().numpy(), ora.o.first_result)
