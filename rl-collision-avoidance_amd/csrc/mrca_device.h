@@ -54,6 +54,25 @@ MRCA_HD void sincos_det(float th, float* sn, float* cs) {
     *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
 
+// 1 / d, correctly rounded.  On the device: v_rcp_f32 (1 ulp) + ONE Newton step in FMA arithmetic -- bit-identical to the
+// IEEE quotient for every float with 2^-100 <= |d| <= 2^100 (exhaustive sweep over all 2^32 bit patterns on the MI355X,
+// tools/check_rcp.hip, profiles/r02_e_check_rcp.txt: 0 mismatches; the mismatches outside are results that underflow) --
+// in 3 instructions instead of the ~11 of the compiler's division expansion; anything outside that range takes the IEEE
+// division.  The host build (test harness) is the plain quotient, which is the specification.
+MRCA_HD float rcp_exact(float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float a = fabsf(d);
+    if (a >= 7.8886090522101181e-31f && a <= 1.2676506002282294e30f) {
+        const float r = __builtin_amdgcn_rcpf(d);
+        const float e = __builtin_fmaf(-d, r, 1.0f);
+        return __builtin_fmaf(e, r, r);
+    }
+    return 1.0f / d;
+#else
+    return 1.0f / d;
+#endif
+}
+
 // A non-finite command (a diverged policy) is treated as 0: the robot idles instead of poisoning the state.
 MRCA_HD float sane_cmd(float a) { return (a - a == 0.0f) ? a : 0.0f; }
 
@@ -124,8 +143,8 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
     if (occ(ix, iy)) return 0.0f;
     if (!(tmax_c > 0.0f)) return tmax;
     const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
-    const float inv_dx = xnz ? 1.0f / dx : kInf;
-    const float inv_dy = ynz ? 1.0f / dy : kInf;
+    const float inv_dx = xnz ? rcp_exact(dx) : kInf;
+    const float inv_dy = ynz ? rcp_exact(dy) : kInf;
     const int sx = dx > 0.0f ? 1 : -1;
     const int sy = dy > 0.0f ? 1 : -1;
     int bx = dx > 0.0f ? ix + 1 : ix;
@@ -256,8 +275,8 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
     if (v == kCellOccupied) return 0.0f;
     if (!(tmax_c > 0.0f)) return tmax;
     const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
-    const float inv_dx = xnz ? 1.0f / dx : kInf;
-    const float inv_dy = ynz ? 1.0f / dy : kInf;
+    const float inv_dx = xnz ? rcp_exact(dx) : kInf;
+    const float inv_dy = ynz ? rcp_exact(dy) : kInf;
     const bool xpos = dx > 0.0f, ypos = dy > 0.0f;
     const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
     const int ux = xpos ? 1 : 0, uy = ypos ? 1 : 0;      // current cell = pending boundary - u, on each axis
@@ -357,8 +376,8 @@ MRCA_HD void grid_march_skip_n(const Field& field, const GridGeom& g, const Marc
     bool act[K], hit[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        inv_dx[k] = dx[k] != 0.0f ? 1.0f / dx[k] : kInf;
-        inv_dy[k] = dy[k] != 0.0f ? 1.0f / dy[k] : kInf;
+        inv_dx[k] = dx[k] != 0.0f ? rcp_exact(dx[k]) : kInf;
+        inv_dy[k] = dy[k] != 0.0f ? rcp_exact(dy[k]) : kInf;
         bx[k] = org.ix0 + (dx[k] > 0.0f ? 1 : 0);
         by[k] = org.iy0 + (dy[k] > 0.0f ? 1 : 0);
         v[k] = org.v0;
@@ -493,8 +512,8 @@ MRCA_HD void walk_cells(float inv_res, float ox, float oy, float dx, float dy, f
     emit(ix, iy);
     if (!(tmax_c > 0.0f)) return;
     const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
-    const float inv_dx = xnz ? 1.0f / dx : kInf;
-    const float inv_dy = ynz ? 1.0f / dy : kInf;
+    const float inv_dx = xnz ? rcp_exact(dx) : kInf;
+    const float inv_dy = ynz ? rcp_exact(dy) : kInf;
     const int sx = dx > 0.0f ? 1 : -1;
     const int sy = dy > 0.0f ? 1 : -1;
     int bx = dx > 0.0f ? ix + 1 : ix;
@@ -559,7 +578,7 @@ MRCA_HD bool obb_overlap(float xi, float yi, float si, float ci, float xj, float
 
 MRCA_HD void slab(float lo, float ld, float h, float* t0, float* t1) {
     const bool par = fabsf(ld) < 1e-12f;
-    const float inv = 1.0f / (par ? 1.0f : ld);
+    const float inv = rcp_exact(par ? 1.0f : ld);
     const float ta = (-h - lo) * inv;
     const float tb = (h - lo) * inv;
     const bool out = fabsf(lo) > h;
