@@ -416,13 +416,11 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
     v.ray_prep_wave = 0;
     v.ray_sequential = 1;
-    v.ray_rpw = 1;
-    v.ray_lds_bytes = 0;
     env->lds_bytes = mrca::ray_lds_bytes(v);
     if (!v.big && mrca::move_lds_bytes(v) > 64 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "map_cell %.4f m is too fine for the LDS patches: use >= 0.01 m",
                          (double)cfg->map_cell));
-    if (env->lds_bytes * 4 > 160 * 1024)
+    if (env->lds_bytes > 160 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "the ray cast needs %zu B of LDS per robot (> 160 KiB): too many beams",
                          env->lds_bytes));
     mrca::launch_head_init(v, nullptr);   // head records of the construction-time poses (all at the origin)
@@ -538,8 +536,6 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     }
     env->view.ray_prep_wave = (flags & 0x800) ? 1 : 0;
     env->view.ray_sequential = (flags & 0x1000) ? 0 : 1;
-    env->view.ray_rpw = 1 << ((flags >> 13) & 3);      // bits 13-14: 1 / 2 / 4 robots per ray-cast workgroup
-    if (env->view.ray_rpw > 4) env->view.ray_rpw = 4;
     return MRCA_OK;
 }
 #endif

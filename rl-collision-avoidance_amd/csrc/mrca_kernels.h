@@ -74,8 +74,6 @@ struct EnvView {
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel marches 1 << ray_shift beams per thread in lock step
     int32_t ray_sequential; // 1 (with ray_shift 1): the two beams of a thread are marched one after the other
-    int32_t ray_rpw;        // robots per workgroup of the ray cast (1, 2 or 4)
-    int32_t ray_lds_bytes;  // LDS bytes per robot of a ray-cast workgroup (set by launch_raycast)
     int32_t ray_prep_wave;  // 1: a dedicated wave prepares the neighbour list (blockDim = beams >> ray_shift + 64)
     int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
 };

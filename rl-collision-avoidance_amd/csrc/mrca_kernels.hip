@@ -561,24 +561,10 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // K beams in lock step (grid_march_skip_n), so one wait covers K lookups.
 template <int K, bool BIG, bool SEQ>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
-    // A workgroup serves ray_rpw robots (1, 2 or 4; big worlds: 1), threads [sub * TW, (sub + 1) * TW) belong to robot
-    // `sub`: robots are too short-lived (about 2 us of wave time) for one workgroup launch each -- the SQ counters of
-    // the one-robot-per-workgroup kernel show 1.2 resident waves per SIMD on average (profiles/r02_f_pmc_sq_summary.txt):
-    // the dispatcher, not the CUs, set its pace.  The robots of a workgroup share nothing but the barrier.
-    const int TW = (int)blockDim.x / e.ray_rpw;
-    const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x / TW);     // wave-uniform: TW is a multiple of 64
-    const int tid = (int)threadIdx.x - sub * TW;
-    uint32_t* lds = lds_all + sub * (e.ray_lds_bytes >> 2);
-    int n;
-    if (e.ray_count % (8 * e.ray_rpw) == 0) {   // consecutive robots (one world) stay together and on one XCD's L2
-        n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count / e.ray_rpw) * e.ray_rpw + sub;
-    } else {
-        const int slot = (int)blockIdx.x * e.ray_rpw + sub;
-        if (slot >= e.ray_count) return;        // whole waves
-        n = e.ray_first + slot;
-    }
-    // the fresh flag comes through the scalar cache (n is wave-uniform; the aligned word holding the byte),
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
+    const int tid = threadIdx.x;
+    // the fresh flag comes through the scalar cache (n is block-uniform; the aligned word holding the byte),
     // so nothing below queues behind it in the vector-memory counter
     const uint32_t fresh_word = reinterpret_cast<const uint32_t*>(e.fresh)[n >> 2];
 
@@ -591,8 +577,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(nb_count + 4);   // [B] neighbours per beam
     int* nb_more = nb_count + 1;                                      // big worlds: another chunk of neighbours follows
 
-    const int T = e.B / K;                    // marching threads per robot
-    const bool extra = TW > T;                // a dedicated preparation wave sits behind the marching ones
+    const int T = e.B / K;                    // marching threads
+    const bool extra = (int)blockDim.x > T;   // a dedicated preparation wave sits behind the marching ones
     const int prep_base = extra ? T : 0;
     const bool is_prep = tid >= prep_base && tid < prep_base + kWave;   // wave-uniform
     const bool marches = tid < T;                                       // wave-uniform
@@ -1135,17 +1121,12 @@ void launch_head_init(const EnvView& e, hipStream_t s) {
 }
 
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
+    const int threads = (e.B >> e.ray_shift) + (e.ray_prep_wave ? kWave : 0);
+    const size_t lds = ray_lds_bytes(e);
+    const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
-    EnvView v = e;
-    if (v.big || v.ray_rpw < 1) v.ray_rpw = 1;
-    const int per_robot = (v.B >> v.ray_shift) + (v.ray_prep_wave ? kWave : 0);
-    while (per_robot * v.ray_rpw > 1024) v.ray_rpw >>= 1;
-    v.ray_lds_bytes = (int32_t)((ray_lds_bytes(v) + 15) / 16 * 16);
-    const int threads = per_robot * v.ray_rpw;
-    const size_t lds = (size_t)v.ray_lds_bytes * v.ray_rpw;
-    const dim3 grid((v.ray_count + v.ray_rpw - 1) / v.ray_rpw);
     const bool seq = e.ray_sequential != 0;
-#define MRCA_RAY(K, BIG, SEQ) hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, v, only_fresh)
+#define MRCA_RAY(K, BIG, SEQ) hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, e, only_fresh)
     if (e.big) {
         switch (e.ray_shift) {
             case 0: MRCA_RAY(1, true, false); break;

@@ -35,9 +35,7 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
                          (512 + 4096, "2 beams lock-step, wave 0 prepares"), (768, "4 beams lock-step, wave 0 prepares"),
                          (256 + 2048, "1 beam/thread + dedicated prep wave"), (512 + 2048, "2 beams sequential + prep wave"),
                          (512 + 4096 + 2048, "2 beams lock-step + prep wave"),
-                         (768 + 2048, "4 beams lock-step + prep wave"),
-                         (1 << 13, "2 robots per workgroup"), (2 << 13, "4 robots per workgroup"),
-                         (256 + (1 << 13), "1 beam/thread, 2 robots per workgroup"), (0, "full again")):
+                         (768 + 2048, "4 beams lock-step + prep wave"), (0, "full again")):
         try:
             env.set_debug_flags(flags)
         except Exception as exc:  # a variant this build / map does not support
