@@ -85,7 +85,9 @@ def main(argv=None):
                                                          "(scenario.circle_n, e.g. 10:8:40,20:12:30)")
     ap.add_argument("--stock-policy-path", action="store_true", help="rollout inference through the stock PyTorch layers "
                                                                        "instead of the fused fp32 HIP front end")
-    ap.add_argument("--no-graph", action="store_true", help="launch the rollout tick kernel by kernel, not as a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the rollout tick as one hipGraph (measured: no gain at "
+                                                          "4096 robots, the tick is GPU-bound; profiles/r02_e_bench_rollout*.json)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) launch the rollout tick kernel by kernel")
     ap.add_argument("--log-every", type=int, default=1)
     a = ap.parse_args(argv)
 
@@ -117,7 +119,7 @@ def main(argv=None):
     if a.logstd_min is not None:
         hp.logstd_min = a.logstd_min
     hp.rollout_fused = not a.stock_policy_path and not a.bf16_inference
-    hp.graph_tick = not a.no_graph
+    hp.graph_tick = bool(a.graph) and not a.no_graph
     if a.bf16_update:
         hp.update_dtype = torch.bfloat16
     if a.bf16_inference:
