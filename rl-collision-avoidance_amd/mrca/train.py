@@ -73,6 +73,8 @@ def main(argv=None):
     ap.add_argument("--bf16-inference", action="store_true", help="bf16 autocast in the rollout policy (opt-in)")
     ap.add_argument("--init", default=None, help="state_dict to start from (overrides the resume file)")
     ap.add_argument("--circle-every", type=int, default=0, help="run the circle test every K updates (rank 0)")
+    ap.add_argument("--circle-sizes", default="50:25", help="validation circles as 'robots:radius,...' (50:25 = the reference's "
+                                                             "circle test); the score of a checkpoint is the MINIMUM success rate")
     ap.add_argument("--circle-worlds", type=int, default=20)
     ap.add_argument("--circle-ticks", type=int, default=1500)
     ap.add_argument("--max-seconds", type=float, default=0.0, help="stop after this much wall time (0 = no limit)")
@@ -237,13 +239,22 @@ def main(argv=None):
         if a.circle_every and rank == 0 and tr.global_update % a.circle_every == 0:
             from . import evaluate
             if circle_env is None:
-                circle_env = VecStageWorld(scenario.circle(num_worlds=a.circle_worlds, seed=a.seed))
-            m = evaluate.circle_test(circle_env, evaluate.cnn_policy_fn(tr.policy), a.circle_ticks)
-            out.info("circle %05d  success %.3f  crash %.3f  unfinished %.3f  ticks %d", tr.global_update,
-                     m["success_rate"], m["crash_rate"], m["unfinished_rate"], m["ticks_run"])
-            if m["success_rate"] > best_circle:
-                best_circle = m["success_rate"]
+                circle_env = []
+                for spec in a.circle_sizes.split(","):
+                    r, rad = spec.split(":")
+                    sc_c = scenario.circle(num_worlds=a.circle_worlds, seed=a.seed) if (int(r), float(rad)) == (50, 25.0) \
+                        else scenario.circle_n(int(r), float(rad), num_worlds=a.circle_worlds, seed=a.seed)
+                    circle_env.append((spec, VecStageWorld(sc_c)))
+            scores = []
+            for spec, ce in circle_env:
+                m = evaluate.circle_test(ce, evaluate.cnn_policy_fn(tr.policy), a.circle_ticks)
+                scores.append(m["success_rate"])
+                out.info("circle %05d  [%s]  success %.3f  crash %.3f  unfinished %.3f  ticks %d", tr.global_update, spec,
+                         m["success_rate"], m["crash_rate"], m["unfinished_rate"], m["ticks_run"])
+            if min(scores) > best_circle:
+                best_circle = min(scores)
                 torch.save(tr.policy.state_dict(), os.path.join(a.policy_dir, "best_circle.pth"))
+                out.info("circle %05d  new best checkpoint: min success %.3f", tr.global_update, best_circle)
     if tr.global_update % a.save_every != 0:      # the last state of a run that stopped between save points
         gens = gather_generators()
         if rank == 0:
