@@ -46,3 +46,23 @@ def test_trained_checkpoint_solves_the_circle_test_on_the_oracle_env():
     print(m)
     assert m["success_rate"] >= 0.9 and m["crash_rate"] <= 0.1      # measured: 50 of 50 robots, 600 ticks
     assert m["mean_path_ratio"] < 1.2 and m["average_speed_mps"] > 0.5
+
+
+CHECKPOINT_ALL_SIZES = os.path.join(U.ROOT, "rl-collision-avoidance_amd", "mrca", "data", "policy_r02_all_circle_sizes.pth")
+
+
+def test_second_checkpoint_solves_circles_of_every_size_on_the_oracle_env():
+    """The continuation of the same run with circles of 10-50 robots in the mix and validation on 20 / 30 / 40 / 50
+    robots at once (profiles/r02_h_*; sha256 385f493a...): circles the paper evaluates (Long et al. 2018, Sec. V: 4-20
+    robots) and beyond.  Measured on this env: 1.00 / 1.00 / 1.00 / 0.98 for 20 / 30 / 40 / 50 robots."""
+    from mrca import evaluate
+    from mrca.net import CNNPolicy
+    assert hashlib.sha256(open(CHECKPOINT_ALL_SIZES, "rb").read()).hexdigest().startswith("385f493a3fd65f38")
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    pol = CNNPolicy(3, 2)
+    pol.load_state_dict(torch.load(CHECKPOINT_ALL_SIZES, map_location="cpu"))
+    for robots, radius in ((20, 12.0), (30, 16.0), (40, 20.0), (50, 25.0)):
+        sc = S.circle(num_worlds=1) if robots == 50 else S.circle_n(robots, radius)
+        m = evaluate.circle_test(_OracleVec(sc), evaluate.cnn_policy_fn(pol), max_ticks=1200)
+        print(robots, m)
+        assert m["success_rate"] >= 0.9, (robots, m)

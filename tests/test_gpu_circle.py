@@ -77,6 +77,25 @@ def test_trained_checkpoint_solves_the_circle_test():
     env.close()
 
 
+def test_second_checkpoint_on_circles_of_every_size():
+    """mrca/data/policy_r02_all_circle_sizes.pth (profiles/r02_h_*): circles of 10 ... 50 robots, 20 circles each."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mrca import evaluate
+    from mrca.net import CNNPolicy
+    from mrca.vec_env import VecStageWorld
+    pol = CNNPolicy(3, 2).cuda()
+    pol.load_state_dict(torch.load(os.path.join(os.path.dirname(CHECKPOINT), "policy_r02_all_circle_sizes.pth"),
+                                   map_location="cuda"))
+    for robots, radius in ((10, 8.0), (20, 12.0), (30, 16.0), (40, 20.0), (50, 25.0)):
+        sc = S.circle(num_worlds=20) if robots == 50 else S.circle_n(robots, radius, num_worlds=20)
+        env = VecStageWorld(sc)
+        m = evaluate.circle_test(env, evaluate.cnn_policy_fn(pol), max_ticks=1500)
+        print(f"{robots}-robot circles:", m)
+        assert m["success_rate"] >= 0.9, (robots, m)
+        env.close()
+
+
 @pytest.mark.parametrize("which", ["controller", "cnn", "trained"])
 def test_circle_success_rate_parity(which):
     if not torch.cuda.is_available():
