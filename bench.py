@@ -326,9 +326,10 @@ def main():
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
-                         "note": "HBM is the nominal roof (SURVEY 8d); the ray cast is bound by VALU issue in the march and by its "
-                                 "per-robot latency chain, not by traffic -- it no longer moves the frame stack (that is the "
-                                 "move launch's 8.2 kB per agent-step); see DESIGN.md 5"},
+                         "note": "HBM is the nominal roof (SURVEY 8d); the ray cast is bound by its per-robot latency chain and the "
+                                 "march, not by traffic or VALU issue (608 VALU instructions per wave, 63 % of the launch's "
+                                 "issue cycles) -- it no longer moves the frame stack (that is the move launch's 8.2 kB per "
+                                 "agent-step); see DESIGN.md 5"},
         }
         if args.mode == "rollout":
             # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Research tool (NOT product, never shipped): drive mrca.trainer.Stage1Trainer on the CPU against the C
-restatement of the oracle, to study learning behaviour of the PPO recipe without spending MI355X minutes.
+"""Test-side research harness (NOT product, never shipped; lives under tests/ because it drives the oracle): run
+mrca.trainer.Stage1Trainer on the CPU against the C restatement of the oracle, to study the learning behaviour of the
+PPO recipe without spending MI355X minutes.
 
 The env is oracle/libmrca_oracle_c.so behind a tiny object with the VecStageWorld surface (numpy state viewed as
 torch CPU tensors); the GAE kernel is replaced by the torch loop of tests/test_golden_learner.  Nothing under
 rl-collision-avoidance_amd/ imports this file.
 
-    python tools/cpu_train.py --stage 1 --worlds 1 --robots 24 --updates 300 --lr 5e-5
+    python tests/cpu_train.py --stage 1 --worlds 1 --robots 24 --updates 300 --lr 5e-5
 """
 import argparse
 import os
