@@ -66,6 +66,12 @@ class CNNPolicy(nn.Module):
         v = self.critic(self._tower("crt", x, goal, speed))
         return mean, v
 
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        if getattr(self, "_rc", None) is not None:      # the fused rollout path reads derived copies: keep them in step
+            self.refresh_rollout_cache()
+        return out
+
     # ------------------------------------------------------------------ rollout fast path (inference only)
     def refresh_rollout_cache(self):
         """Tower-major copies of the parameters the fused rollout path reads (call after every optimiser step
