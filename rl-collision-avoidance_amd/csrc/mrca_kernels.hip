@@ -249,13 +249,22 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     //     everybody else commits straight away -- their outcome does not depend on the order.
     bool involved = false;
     if (!MRCA_DBG(e, 16)) {
+        // every robot's old and provisional centre goes through LDS once (the patch area is free until the outline test
+        // below) and is read back as ONE broadcast 16-byte load per candidate: four v_readlane + their VALU hazards per
+        // candidate before
+        float4* centres = reinterpret_cast<float4*>(mini);
+        centres[lane] = make_float4(x, y, nx, ny);
+        __syncthreads();
+#pragma unroll 4
         for (int j = 0; j < e.R; ++j) {
-            const float ax = nx - fbcast(x, j), ay = ny - fbcast(y, j);
-            const float bx2 = nx - fbcast(nx, j), by2 = ny - fbcast(ny, j);
+            const float4 q = centres[j];
+            const float ax = nx - q.x, ay = ny - q.y;
+            const float bx2 = nx - q.z, by2 = ny - q.w;
             const float d_old = ax * ax + ay * ay, d_new = bx2 * bx2 + by2 * by2;
             if (j != lane && (d_old <= e.collide_reach2 || d_new <= e.collide_reach2)) involved = true;  // (2*0.2907 + 0.001)^2
         }
         involved = involved && valid;
+        __syncthreads();   // the patches below reuse this LDS
     }
     const bool need = check_map && !(inside && clearance > hc);
     {
