@@ -39,12 +39,18 @@ MOVE_BYTES_PER_AGENT_STEP = 2 * 4096 + 108     # two frames read + written one s
 
 
 def kernel_source_hash():
-    """sha256 (16 hex digits) of the device sources the ray-cast kernel is compiled from: PMC counters measured on
-    one version of the kernel say nothing about another."""
+    """sha256 (16 hex digits) of the CODE of the device sources the env kernels are compiled from (comments and blank
+    lines stripped: counters measured on one version of the kernels say nothing about another, but a reworded comment
+    changes nothing the counters saw)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in ("mrca_kernels.hip", "mrca_device.h", "mrca_kernels.h"):
-        h.update(open(os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc", f), "rb").read())
+        src = open(os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc", f)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        code = "\n".join(ln.rstrip() for ln in src.splitlines() if ln.strip())
+        h.update(code.encode())
     return h.hexdigest()[:16]
 
 

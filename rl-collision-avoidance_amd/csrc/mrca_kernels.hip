@@ -9,19 +9,24 @@
 //                  lane runs the rectangle SAT against the pose it has at that point of the
 //                  order, a wavefront ballot decides revert+stall.  Reward / terminal / episode
 //                  bookkeeping (wave-parallel Philox resets, group ballots) follow.
-//   raycast_kernel one workgroup per robot: beams/K marching threads, each marching K beams in LOCK STEP
-//                  (K independent field lookups in flight per thread: the march is a chain of dependent
-//                  L2 lookups, ~2 per ray), plus one preparation wave that compacts the other robots of
-//                  the world within lidar reach into LDS (ballot + popcount) together with a per-beam
-//                  bitmask of who can touch which beam.  The robot's own sin/cos and the field entry of
-//                  its cell come from the 16-byte `head` record the move kernel published (scalar
-//                  loads), so no wave recomputes them.  Each thread then slab-tests its own beams against
-//                  the flagged neighbours; scan, normalised observation and the frame-stack shift leave
-//                  through LDS as 16-byte stores.
+//                  The copy blocks of the tick's frame-stack shift ride behind the per-world blocks in the
+//                  same launch (shift_frames).
+//   raycast_kernel one workgroup per robot, beams/K threads, K beams per thread (product: K = 2, marched one
+//                  after the other; the lock-step form and a dedicated preparation wave are measured variants).
+//                  The first wave compacts the other robots of the world within lidar reach into LDS (ballot +
+//                  popcount) together with a per-beam bitmask of who can touch which beam, then marches like
+//                  the others: the exact skipping march over the per-cell free-rectangle field (~2 dependent
+//                  L2 lookups per ray).  The robot's own sin/cos and the field entry of its cell come from the
+//                  16-byte `head` record the move kernel published (scalar loads), so no wave recomputes them.
+//                  Each thread slab-tests its own beams against the flagged neighbours and stores their scan
+//                  value and newest observation frame itself.
+//   bw_*           the move kernel's tick for worlds with more than 64 robots (per-robot threads, spatial
+//                  hashes, ordered collision pass as dependency rounds); raycast_kernel<K, true> is its ray cast.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
 //   gae_kernel     reverse GAE scan, thread per robot, coalesced over N.
 //
-// No dense contraction anywhere: MFMA is deliberately unused (BASELINE.json north_star).
+// No dense contraction anywhere in the environment: MFMA is deliberately unused here (BASELINE.json north_star); the
+// policy's conv front end (mrca_policy.hip) is where it is used.
 #include "mrca_kernels.h"
 
 namespace mrca {
@@ -566,8 +571,8 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // lookups per ray.  (Staging a tile of it in LDS per robot was measured slower at every granularity tried,
 // the tile costs more to fill than the few lookups it serves.  So were persistent workgroups
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
-// no difference.)  What a chain of dependent lookups wants is more of them in flight: each thread marches its
-// K beams in lock step (grid_march_skip_n), so one wait covers K lookups.
+// no difference.)  Marching the K beams of a thread in LOCK STEP (grid_march_skip_n: K lookups in flight per wait) is
+// implemented and measured too: slower than one after the other (34.7 vs 28.1 us, profiles/r02_c_*), see mrca_abi.hip.
 template <int K, bool BIG, bool SEQ>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];

@@ -91,3 +91,25 @@ def test_product_has_no_cpu_fallback():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "mrca_oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_committed_pmc_traffic_matches_the_kernel_sources():
+    """profiles/pmc_traffic.json feeds roofline.traffic of bench.py and is refused when it was measured on other kernel
+    code: the committed file must belong to the committed sources (re-run the PMC passes after touching a kernel), and
+    the stamp must ignore comments but not code."""
+    import importlib
+    import sys
+    sys.path.insert(0, U.ROOT)
+    bench = importlib.import_module("bench")
+    traffic, note = bench.pmc_traffic(4096, "stage1")
+    assert traffic is not None and 15e6 < traffic < 40e6, note
+    h0 = bench.kernel_source_hash()
+    f = os.path.join(U.ROOT, "rl-collision-avoidance_amd", "csrc", "mrca_kernels.h")
+    src = open(f).read()
+    try:
+        open(f, "w").write(src + "\n// a comment\n/* another\n one */\n")
+        assert bench.kernel_source_hash() == h0
+        open(f, "w").write(src + "\nstatic const int kNotThere = 1;\n")
+        assert bench.kernel_source_hash() != h0
+    finally:
+        open(f, "w").write(src)
