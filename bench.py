@@ -38,19 +38,22 @@ RAY_BYTES_PER_AGENT_STEP = 2 * 4 * 512 + 48    # scan + newest obs frame written
 MOVE_BYTES_PER_AGENT_STEP = 2 * 4096 + 108     # two frames read + written one slot down, ~0.1 kB of robot state
 
 
+def code_only(src):
+    """C++ source without comments and blank lines (what the kernel-source stamp hashes)."""
+    import re
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    return "\n".join(ln.rstrip() for ln in src.splitlines() if ln.strip())
+
+
 def kernel_source_hash():
     """sha256 (16 hex digits) of the CODE of the device sources the env kernels are compiled from (comments and blank
     lines stripped: counters measured on one version of the kernels say nothing about another, but a reworded comment
     changes nothing the counters saw)."""
     import hashlib
-    import re
     h = hashlib.sha256()
     for f in ("mrca_kernels.hip", "mrca_device.h", "mrca_kernels.h"):
-        src = open(os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc", f)).read()
-        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        src = re.sub(r"//[^\n]*", "", src)
-        code = "\n".join(ln.rstrip() for ln in src.splitlines() if ln.strip())
-        h.update(code.encode())
+        h.update(code_only(open(os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc", f)).read()).encode())
     return h.hexdigest()[:16]
 
 
