@@ -146,3 +146,32 @@ def test_unchanged_circle_test_with_our_checkpoint(monkeypatch):
     finally:
         stage_world.set_backend_factory(None)
     assert not errs, errs
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "circle_test.py")), reason="reference checkout absent")
+def test_unchanged_circle_test_with_the_trained_checkpoint_reaches_every_goal(monkeypatch):
+    """The reference's deliverable end to end: its UNCHANGED circle_test.py (50 ranks, its own CNNPolicy and
+    generate_action_no_sampling, model/ppo.py:84-107) loads the checkpoint this repo trained
+    (mrca/data/policy_r02_stage2_circles.pth as policy/stage2.pth) and drives the 50 robots of the drop-in circle world:
+    every robot's first terminal event must be "Reach Goal"."""
+    import shutil
+    from mrca import spmd, stage_world
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "policy"))
+    shutil.copy(os.path.join(U.ROOT, "rl-collision-avoidance_amd", "mrca", "data", "policy_r02_stage2_circles.pth"),
+                os.path.join(tmp, "policy", "stage2.pth"))
+    made = []
+
+    def factory(sc):
+        made.append(U.COracleBackend(sc))
+        return made[-1]
+    stage_world.set_backend_factory(factory)
+    try:
+        errs = spmd.run_script(os.path.join(REF, "circle_test.py"), 50, max_ticks=700, chdir=tmp)
+    finally:
+        stage_world.set_backend_factory(None)
+    assert not errs, errs
+    first = np.asarray(made[-1].env.first_result)
+    assert (first == 1).mean() >= 0.9, np.bincount(first, minlength=4)       # measured: 50 of 50 reach their goals

@@ -49,7 +49,7 @@ def _trained_policy():
 
 def test_trained_checkpoint_solves_the_circle_test():
     """The committed checkpoint (Stage-1 -> Stage-2 worlds mixed with circles of 10-50 robots, profiles/r02_d_*;
-    sha256 87d8d5d6...) on the reference's 50-robot circle: every robot must reach its antipodal goal.  Deterministic
+    sha256 23b64ea9...) on the reference's 50-robot circle: every robot must reach its antipodal goal.  Deterministic
     mean action, first terminal event latched; also at 1000 robots (20 circles) and through the fused
     fp32 rollout path of the policy."""
     if not torch.cuda.is_available():

@@ -240,3 +240,20 @@ class COracleEnv(EmulEnv):
     def step(self, actions):
         a = np.ascontiguousarray(actions, np.float32)
         self.lib.oc_step(C.byref(self._st), C.c_void_p(a.ctypes.data))
+
+
+class COracleBackend:
+    """The C oracle behind the SharedWorld backend protocol of mrca/stage_world.py (tests only; much faster than the
+    NumPy OracleBackend for the 50-robot circle)."""
+
+    def __init__(self, sc):
+        self.env = COracleEnv(sc)
+
+    def reset(self, mask, poses, goals):
+        self.env.reset(mask, poses, goals)
+
+    def step(self, actions):
+        self.env.step(actions)
+
+    def field(self, name):
+        return np.asarray(getattr(self.env, name))
