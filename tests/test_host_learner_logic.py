@@ -1,0 +1,95 @@
+"""Host-side learner logic that needs no GPU: the trainer on the C oracle env (tests/cpu_train.CpuEnv) --
+one-frame-per-tick rollout buffer == full-stack buffer, mixed-scenario env concatenation, KL-adaptive learning rate,
+floor on the policy's log std."""
+import numpy as np
+import torch
+
+import cpu_train as ct          # tests/cpu_train.py: CpuEnv + the torch GAE stand-in for the HIP kernel
+import util as U  # noqa: F401
+from util import S
+
+
+def _trainers(sc, horizon, **kw):
+    from mrca.trainer import HParams, Stage1Trainer
+    out = []
+    for single in (False, True):
+        env = ct.CpuEnv(sc)
+        tr = Stage1Trainer(env, hp=HParams(horizon=horizon, batch_size=256, epoch=1, single_frame_buffer=single, **kw),
+                           seed=4)
+        tr.start()
+        out.append(tr)
+    return out
+
+
+def test_single_frame_buffer_equals_the_stack_buffer_on_the_oracle_env():
+    torch.set_num_threads(2)
+    sc = S.stage1(num_worlds=2, robots_per_world=12, seed=8)
+    a, b = _trainers(sc, horizon=60)
+    for _ in range(59):
+        a.tick()
+        b.tick()
+    A, B = a.buffer, b.buffer
+    assert int(A.done[:59].sum()) > 0                      # robots restarted inside the horizon
+    assert torch.equal(A.action[:59], B.action[:59])
+    assert torch.equal(B.obs_rows().materialise()[:59], A.obs[:59])
+    idx = torch.randperm(59 * sc.num_robots)[:300]
+    assert torch.equal(B.obs_rows()[idx], A.obs_rows()[idx])
+    keep = torch.rand(60 * sc.num_robots) < 0.7            # the Stage-2 filter path: boolean mask, then indices
+    keep[59 * sc.num_robots:] = False
+    sub = torch.arange(int(keep.sum()))[::5]
+    assert torch.equal(B.obs_rows()[keep][sub], A.obs_rows()[keep][sub])
+    assert B.frames.numel() * 3 < A.obs.numel() * 1.2      # a third of the memory (plus two rows)
+    a.tick()                                               # the update runs; the next horizon starts from row 0 again
+    b.tick()
+    a.tick()
+    b.tick()
+    assert a.global_update == b.global_update == 1
+
+
+def test_concat_env_steps_every_part_and_keeps_the_order():
+    from mrca.multi_env import ConcatEnv
+    parts = [ct.CpuEnv(S.stage2(num_worlds=1, seed=1)), ct.CpuEnv(S.circle_n(10, 8.0, train=True))]
+    ref = [ct.CpuEnv(S.stage2(num_worlds=1, seed=1)), ct.CpuEnv(S.circle_n(10, 8.0, train=True))]
+    env = ConcatEnv(parts)
+    env.reset()
+    for e in ref:
+        e.reset()
+    assert env.N == 54 and env.bounds == [(0, 44), (44, 54)]
+    g = torch.Generator().manual_seed(0)
+    for _ in range(5):
+        act = torch.stack([torch.rand(54, generator=g), torch.rand(54, generator=g) * 2 - 1], 1)
+        env.step(act)
+        ref[0].step(act[:44].contiguous())
+        ref[1].step(act[44:].contiguous())
+    for k in ("obs", "local_goal", "reward", "done", "live", "fresh"):
+        assert torch.equal(getattr(env, k)[:44], getattr(ref[0], k)), k
+        assert torch.equal(getattr(env, k)[44:], getattr(ref[1], k)), k
+
+
+def test_kl_adaptive_lr_and_logstd_floor():
+    from mrca import ppo
+    from mrca.net import CNNPolicy
+    torch.manual_seed(0)
+    pol = CNNPolicy(3, 2)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+    ctl = ppo.KLAdaptiveLR(target=0.01, lr_min=1e-6, lr_max=3e-4, stop_factor=2.0)
+    ctl.step(opt, torch.tensor(0.001), 1, None)            # KL well below target: lr up, capped
+    assert abs(opt.param_groups[0]["lr"] - 1.5e-4) < 1e-12
+    ctl.step(opt, torch.tensor(0.001), 1, None)
+    ctl.step(opt, torch.tensor(0.001), 1, None)
+    assert opt.param_groups[0]["lr"] == 3e-4
+    ctl.step(opt, torch.tensor(0.05), 1, None)             # above 2 x target: lr down
+    assert abs(opt.param_groups[0]["lr"] - 2e-4) < 1e-12
+    assert ctl.should_stop(torch.tensor(0.03), None) and not ctl.should_stop(torch.tensor(0.015), None)
+    # the floor: an update that would push logstd down leaves it at the floor
+    T, N = 4, 8
+    g = torch.Generator().manual_seed(1)
+    mem = (torch.rand(T, N, 3, 512, generator=g) - 0.5, torch.rand(T, N, 2, generator=g), torch.rand(T, N, 2, generator=g),
+           torch.rand(T, N, 2, generator=g), torch.full((T, N, 1), -2.0), torch.randn(T, N, generator=g), None, None,
+           torch.randn(T, N, generator=g))
+    with torch.no_grad():
+        pol.logstd.fill_(-1.2)
+    big = torch.optim.SGD(pol.parameters(), lr=1.0)
+    ppo.ppo_update_stage1(policy=pol, optimizer=big, batch_size=16, memory=mem, epoch=2, coeff_entropy=5e-4,
+                          clip_value=0.1, num_step=T, num_env=N, frames=3, obs_size=512, act_size=2, logstd_min=-1.2)
+    assert float(pol.logstd.detach().min()) >= -1.2
