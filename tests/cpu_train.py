@@ -58,7 +58,10 @@ def _gae_cpu(rewards, values, last_value, dones, gamma, lam):
     return targets, targets - values
 
 
-vec_env.gae = _gae_cpu
+def install_cpu_gae():
+    """Replace the HIP GAE kernel's binding by the torch loop above (this process only; tests use monkeypatch instead so
+    that nothing leaks into GPU tests collected in the same session)."""
+    vec_env.gae = _gae_cpu
 
 
 def circle_eval(policy, circles=1, max_ticks=1500):
@@ -88,6 +91,7 @@ def main():
     ap.add_argument("--lr-max", type=float, default=1e-3)
     ap.add_argument("--max-grad-norm", type=float, default=0.0)
     a = ap.parse_args()
+    install_cpu_gae()
     torch.set_num_threads(a.threads)
     os.environ.setdefault("OMP_NUM_THREADS", str(a.threads))
     if a.stage == 1:

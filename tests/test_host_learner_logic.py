@@ -2,11 +2,19 @@
 one-frame-per-tick rollout buffer == full-stack buffer, mixed-scenario env concatenation, KL-adaptive learning rate,
 floor on the policy's log std."""
 import numpy as np
+import pytest
 import torch
 
 import cpu_train as ct          # tests/cpu_train.py: CpuEnv + the torch GAE stand-in for the HIP kernel
 import util as U  # noqa: F401
 from util import S
+
+
+@pytest.fixture(autouse=True)
+def _cpu_gae(monkeypatch):
+    """The HIP GAE kernel's binding -> the torch loop, for the duration of one test only."""
+    from mrca import vec_env
+    monkeypatch.setattr(vec_env, "gae", ct._gae_cpu)
 
 
 def _trainers(sc, horizon, **kw):
