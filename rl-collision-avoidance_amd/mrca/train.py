@@ -96,12 +96,17 @@ def main(argv=None):
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MRCA_TRAIN_BACKEND", "nccl")      # "gloo": the CPU tests of the multi-rank path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     out, cal, ppo_log = _loggers(rank)
 
     from .vec_env import VecStageWorld
@@ -206,7 +211,8 @@ def main(argv=None):
             ep_reward = torch.where(d, torch.zeros_like(ep_reward), ep_reward)
             r = env.result
             ep_done += torch.stack([(d & (r == 1)).sum(), (d & (r == 2)).sum(), (d & (r == 3)).sum()]).float()
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
             dist.all_reduce(ep_done)

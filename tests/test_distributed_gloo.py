@@ -199,3 +199,31 @@ def test_kl_adaptive_lr_takes_the_same_decision_on_every_rank():
     out = os.path.join(tempfile.mkdtemp(), "ok.pt")
     mp.spawn(_worker_kl, args=(2, _free_port(), out), nprocs=2, join=True)
     assert os.path.exists(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# The multi-rank TRAIN CLI end to end on two gloo ranks (the C oracle standing in for the device env): sharded worlds,
+# flat-bucket gradient all-reduce, KL decisions, the collective stop, per-rank generator states in the checkpoint.
+def _worker_train_cli(rank, world, port, workdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), MRCA_TRAIN_BACKEND="gloo")
+    import cpu_train as ct
+    from mrca import train, vec_env
+    vec_env.VecStageWorld = ct.CpuEnv            # this worker process only
+    vec_env.gae = ct._gae_cpu
+    torch.set_num_threads(2)
+    os.chdir(workdir)
+    train.main(["--stage", "2", "--worlds", "1", "--updates", "3", "--save-every", "2", "--batch-size", "64", "--horizon", "8",
+                "--epoch", "2", "--kl-target", "0.01", "--kl-stop", "2.0", "--max-grad-norm", "1.0", "--logstd-min", "-1.2",
+                "--stock-policy-path", "--policy-dir", "policy", "--seed", "3"])
+
+
+def test_train_cli_two_ranks_stage2_end_to_end():
+    work = tempfile.mkdtemp()
+    mp.spawn(_worker_train_cli, args=(2, _free_port(), work), nprocs=2, join=True)
+    st = torch.load(os.path.join(work, "policy", "stage2_2.pth.state"), weights_only=False)
+    assert st["global_update"] == 2 and len(st["generators"]) == 2                  # one noise generator state per rank
+    assert not torch.equal(st["generators"][0], st["generators"][1])
+    sd = torch.load(os.path.join(work, "policy", "last.pth"))
+    assert float(sd["logstd"].min()) >= -1.2 and all(torch.isfinite(v).all() for v in sd.values())
+    assert os.path.exists(os.path.join(work, "policy", "stage2_3.pth"))            # the run's last state is saved too
