@@ -96,3 +96,50 @@ def test_lidar_features_rejects_other_geometries(pol):
     rc = pol.refresh_rollout_cache()
     with pytest.raises(ValueError):
         policy_ops.lidar_features(torch.zeros(4, 3, 256, device="cuda"), rc["w1"], rc["b1"], rc["w2"], rc["b2"])
+
+
+def test_bf16_inference_is_bounded_against_fp32():
+    """bf16 autocast inference is an opt-in of the rollout (`--bf16-inference`, bench `--policy-dtype bf16`; fp32 is the
+    default and what every other test uses).  With the trained checkpoint on real circle-test observations: the action
+    mean and the value must stay within bf16's three significant digits of the fp32 forward, and the circle test under
+    bf16 inference is run and reported (the scenario is chaotic in the last bits, so its success rate is printed, not
+    asserted beyond "most robots do not crash")."""
+    import os
+    from mrca import evaluate, ppo
+    from mrca import scenario as S
+    from mrca.net import CNNPolicy
+    from mrca.vec_env import VecStageWorld
+    ck = os.path.join(U.ROOT, "rl-collision-avoidance_amd", "mrca", "data", "policy_r02_stage2_circles.pth")
+    pol = CNNPolicy(3, 2).cuda()
+    pol.load_state_dict(torch.load(ck, map_location="cuda"))
+    env = VecStageWorld(S.circle(num_worlds=20, seed=0))
+    env.reset()
+    worst_m, worst_v, sum_m, cnt = 0.0, 0.0, 0.0, 0
+    for k in range(240):
+        with torch.no_grad():
+            m32, v32 = pol.mean_value(env.obs, env.local_goal, env.speed)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                m16, v16 = pol.mean_value(env.obs, env.local_goal, env.speed)
+        worst_m = max(worst_m, float((m32 - m16.float()).abs().max()))
+        sum_m += float((m32 - m16.float()).abs().mean())
+        cnt += 1
+        worst_v = max(worst_v, float(((v32 - v16.float()).abs() / (1.0 + v32.abs())).max()))
+        lo, hi = ppo._bounds(evaluate.ACTION_BOUND, m32.device, m32.dtype)
+        env.step(torch.minimum(torch.maximum(m32, lo), hi).contiguous())
+    print(f"bf16 vs fp32 inference over 240 circle ticks x 1000 robots: max |d mean| {worst_m:.4f}, "
+          f"(mean {sum_m / cnt:.5f}), max |d value| / (1 + |value|) {worst_v:.4f}")
+    # measured: max 0.104, mean 0.0066, value 0.14 over 240 000 evaluations; circle SR under bf16 inference 1.00 -- a saturating sigmoid / tanh head amplifies bf16's 3 digits where
+    # its input is large; the typical deviation is two orders of magnitude smaller
+    assert worst_m < 0.25 and sum_m / cnt < 0.02 and worst_v < 0.3
+
+    def bf16_policy(obs, goal, speed):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            mean, _v = pol.mean_value(obs, goal, speed)
+        lo, hi = ppo._bounds(evaluate.ACTION_BOUND, obs.device, torch.float32)
+        return torch.minimum(torch.maximum(mean.float(), lo), hi)
+    env1 = VecStageWorld(S.circle(num_worlds=1, seed=0))
+    m = evaluate.circle_test(env1, bf16_policy, max_ticks=1500)
+    print("circle test under bf16 inference:", m)
+    assert m["crash_rate"] < 0.5
+    env.close()
+    env1.close()
