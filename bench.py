@@ -147,7 +147,10 @@ def main():
                     help="train: autocast dtype of the PPO update (master weights stay fp32); f32 = the reference's")
     ap.add_argument("--policy-path", default="fused", choices=["fused", "stock"],
                     help="rollout/train: policy INFERENCE through the fp32 HIP conv front end + batched GEMMs (fused, "
-                         "default) or through the stock PyTorch layers (stock); the PPO update always uses the latter")
+                         "default) or through the stock PyTorch layers (stock)")
+    ap.add_argument("--update-path", default="fused", choices=["fused", "stock"],
+                    help="train: the PPO update differentiates the conv front end through the HIP forward / backward "
+                         "kernels (fused, default) or through the stock PyTorch layers / MIOpen (stock)")
     ap.add_argument("--no-graph", action="store_true", help="rollout/train: launch the tick kernel by kernel instead of "
                                                              "replaying it as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -215,7 +218,8 @@ def main():
                                   inference_dtype=torch.bfloat16 if args.policy_dtype == "bf16" else None,
                                   update_dtype=torch.bfloat16 if args.update_dtype == "bf16" else None,
                                   fused=(args.policy_path == "fused" and args.policy_dtype == "f32"),
-                                  graph=not args.no_graph)
+                                  graph=not args.no_graph,
+                                  update_fused=(args.update_path == "fused" and args.update_dtype == "f32"))
 
     if args.mode == "train":
         # warm-up must cover whole horizons so that MIOpen tuning / allocator growth of the FIRST update
@@ -227,7 +231,10 @@ def main():
     for k in range(args.warmup):
         step_fn(k)
     barrier()
-    env.enable_timing(8)   # HIP events around the kernels of every 8th step of the timed region
+    # HIP events around the kernels of every 8th step of the timed region -- of EVERY step when the region is short
+    # (the driver's 20-step run used to average 3 launches)
+    every = 8 if args.steps >= 64 else 1
+    env.enable_timing(every)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step_fn(k)
@@ -235,7 +242,8 @@ def main():
     elapsed = time.perf_counter() - t0
     mv_ms, ray_ms, launches = env.read_timing()
     env.enable_timing(False)
-    kernel_timing_note = "HIP events around the kernels of every 8th step of the timed region"
+    kernel_timing_note = ("HIP events around the kernels of every 8th step of the timed region" if every == 8 else
+                          "HIP events around the kernels of every step of the timed region")
     if launches == 0:
         # the tick was replayed as a hipGraph (the library's event records are not part of a captured tick): time the
         # two env kernels in a short eager pass AFTER the timed region instead
@@ -290,7 +298,17 @@ def main():
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     per_rank = None
+    ranks_seen, devices = None, None
     if dist is not None:
+        # evidence that the collective really spans the ranks: an all-reduce of ones, and every rank's device
+        ones = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        props = torch.cuda.get_device_properties(dev)
+        mine_dev = f"rank {rank}: cuda:{dev.index} {props.name} ({getattr(props, 'gcnArchName', '?')}, " \
+                   f"{props.multi_processor_count} CUs)"
+        devices = [None] * world_size
+        dist.all_gather_object(devices, mine_dev)
         mine = torch.tensor([N * args.steps / elapsed], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world_size)]
         dist.all_gather(gathered, mine)
@@ -321,7 +339,9 @@ def main():
                        "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
                        if args.mode != "env" else None,
                        "tick_as_hipgraph": (not args.no_graph) if args.mode != "env" else None,
-                       "ppo_update_dtype": args.update_dtype if args.mode == "train" else None},
+                       "ppo_update_dtype": args.update_dtype if args.mode == "train" else None,
+                       "ppo_update_path": (args.update_path if args.update_dtype == "f32" else "stock")
+                       if args.mode == "train" else None},
             "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_note": traffic_note,
@@ -356,6 +376,8 @@ def main():
         if per_rank is not None:
             out["per_rank_agent_steps_per_s"] = per_rank      # each rank's own rate on the same per-GPU workload
             out["collective_backend"] = dist.get_backend()
+            out["rccl_ranks_seen"] = ranks_seen               # sum over ranks of 1.0 through the same process group
+            out["devices"] = devices
         out.update(extra)
         print(json.dumps(out))
     if dist is not None:

@@ -166,7 +166,7 @@ int mrca_enable_timing(mrca_env* env, int32_t on); /* on = n > 0: time every n-t
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
 /* Rollout-path front end of the lidar actor-critic (model/net.py:19-25,37-49,57-69: Conv1d(3,32,k5,s2,p1) -> ReLU ->
  * Conv1d(32,32,k3,s2,p1) -> ReLU for the actor and the critic tower), fused into one kernel: fp32 in, fp32 MFMA
- * accumulate, the 32 x 255 intermediate never leaves the CU.  Inference only -- training keeps the PyTorch layers.
+ * accumulate, the 32 x 255 intermediate never leaves the CU.
  *   obs_dev  f32[N,3,512]   the env's observation stack (field MRCA_F_OBS)
  *   w1_dev   f32[2,32,3,5]  b1_dev f32[2,32]    act_fea_cv1 / crt_fea_cv1 weight and bias, tower-major
  *   w2_dev   f32[2,32,32,3] b2_dev f32[2,32]    act_fea_cv2 / crt_fea_cv2
@@ -174,6 +174,23 @@ int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, i
  * frames must be 3 and beams 512 (MRCA_ERR_UNSUPPORTED otherwise). */
 int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams, const float* w1_dev,
                         const float* b1_dev, const float* w2_dev, const float* b2_dev, float* feat_dev, void* stream);
+
+/* Backward pass of the same front end for the PPO update (model/ppo.py:158-192 back-propagates the loss through
+ * act_fea_cv1/2 and crt_fea_cv1/2 of model/net.py:19-25 for every minibatch): given the gradient with respect to the
+ * forward kernel's output it returns the gradients of both towers' convolution weights and biases; h1 is recomputed,
+ * g1 never leaves the registers, per-wave partial sums are added in a fixed order (deterministic).
+ *   obs_dev   f32[N,3,512]   the minibatch's observation stacks (no gradient: data)
+ *   w1_dev f32[2,32,3,5]  b1_dev f32[2,32]  w2_dev f32[2,32,32,3]      the weights the forward ran with
+ *   feat_dev  f32[2,N,4096]  the forward's output (its sign pattern is the second ReLU's mask)
+ *   gfeat_dev f32[2,N,4096]  dLoss / dfeat
+ *   dw1_dev f32[2,32,3,5]  db1_dev f32[2,32]  dw2_dev f32[2,32,32,3]  db2_dev f32[2,32]   out (overwritten)
+ *   scratch_dev              caller-owned device scratch of at least mrca_lidar_features_backward_scratch() bytes
+ *                            on the CURRENT device */
+int mrca_lidar_features_backward_scratch(size_t* bytes_out);
+int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams,
+                                 const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* feat_dev,
+                                 const float* gfeat_dev, float* dw1_dev, float* db1_dev, float* dw2_dev, float* db2_dev,
+                                 void* scratch_dev, size_t scratch_bytes, void* stream);
 
 #ifdef MRCA_PROFILING
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product

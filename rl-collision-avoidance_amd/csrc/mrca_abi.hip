@@ -13,19 +13,27 @@
 
 #include "../../include/mrca_env.h"
 #include "mrca_host.h"
+#include "mrca_hostutil.h"
 #include "mrca_kernels.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char* fmt, ...) {
+namespace mrca {
+int set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
+}  // namespace mrca
+
+namespace {
+
+using mrca::DeviceGuard;
+#define fail(...) mrca::set_error(__VA_ARGS__)
 
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
@@ -188,19 +196,6 @@ std::shared_ptr<const HostField> host_field(const mrca_config* c) {
     cache.push_back(f);
     return f;
 }
-
-// Launches must target the env's device whatever the caller's current device is (two envs on two GPUs in one
-// process; a torch caller whose current device differs): switch for the duration of the call, then restore.
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(int want) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (switched) (void)hipSetDevice(prev);
-    }
-};
 
 }  // namespace
 
@@ -498,6 +493,7 @@ int mrca_gae(const float* rewards_dev, const float* values_dev, const float* las
     if (!rewards_dev || !values_dev || !last_value_dev || !dones_dev || !targets_dev || !advs_dev)
         return fail(MRCA_ERR_INVALID, "mrca_gae: NULL pointer");
     if (T < 1 || N < 1) return fail(MRCA_ERR_INVALID, "mrca_gae: T=%d N=%d", T, N);
+    DeviceGuard guard(mrca::device_of(rewards_dev));      // launch where the buffers live
     mrca::launch_gae(rewards_dev, values_dev, last_value_dev, dones_dev, gamma, lam, T, N, targets_dev, advs_dev,
                      static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());

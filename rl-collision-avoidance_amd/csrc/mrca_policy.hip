@@ -1,5 +1,6 @@
 // mrca_policy.hip -- the lidar front end of the actor-critic (model/net.py:19-25,37-49: two Conv1d + ReLU per tower)
-// as ONE fused gfx950 kernel for the ROLLOUT path (inference only; training keeps the stock PyTorch layers).
+// as ONE fused gfx950 kernel: the rollout's inference and the forward half of the PPO update (its backward pass is
+// mrca_policy_bwd.hip).
 //
 //   feat[t][n][c*128 + l] = relu(b2[t][c] + sum_{ci<32,k<3} w2[t][c][ci][k] * h1[t][ci][2l+k-1])          l < 128
 //   h1[t][c][l]           = relu(b1[t][c] + sum_{ci<3, k<5} w1[t][c][ci][k] * obs[n][ci][2l+k-1])         l < 255
@@ -20,6 +21,7 @@
 #include <stdint.h>
 
 #include "../../include/mrca_env.h"
+#include "mrca_hostutil.h"
 
 namespace mrca_policy {
 
@@ -174,29 +176,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
 
 }  // namespace mrca_policy
 
+namespace mrca_policy {
+struct DeviceInfo {
+    int cus = 0;
+    bool attr_set = false;
+};
+static DeviceInfo g_dev[64];     // per DEVICE: CU count and the dynamic-LDS attribute (a second GPU needs its own)
+}  // namespace mrca_policy
+
 extern "C" int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams,
                                    const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
                                    float* feat_dev, void* stream) {
     using namespace mrca_policy;
-    if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !feat_dev) return MRCA_ERR_INVALID;
-    if (frames != kFrames || beams != kBeams || n_robots < 1) return MRCA_ERR_UNSUPPORTED;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !feat_dev)
+        return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features: NULL pointer");
+    if (frames != kFrames || beams != kBeams || n_robots < 1)
+        return mrca::set_error(MRCA_ERR_UNSUPPORTED, "mrca_lidar_features: frames %d beams %d robots %d (needs 3 x 512, >= 1)",
+                               frames, beams, n_robots);
+    mrca::DeviceGuard guard(mrca::device_of(obs_dev));     // launch where the buffers live
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features: hipGetDevice failed");
+    DeviceInfo& d = g_dev[dev];
+    const size_t lds = (size_t)kWavesPerBlock * kWaveFloats * sizeof(float);
+    if (d.cus == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        d.cus = cus;
+    }
+    if (!d.attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_features_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features: %zu B of dynamic LDS refused: %s", lds,
+                                   hipGetErrorString(e));
+        d.attr_set = true;
     }
     // persistent waves: one workgroup of 4 waves per CU (159 kB of LDS), each wave pair walks every (#pairs)-th robot
-    int blocks = cus;
+    int blocks = d.cus;
     const int pairs_needed = (n_robots + 1) / 2;          // a block holds two (actor, critic) pairs
     if (blocks > pairs_needed) blocks = pairs_needed;
-    const size_t lds = (size_t)kWavesPerBlock * kWaveFloats * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_features_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(lidar_features_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), lds,
                        static_cast<hipStream_t>(stream), obs_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
-    return hipGetLastError() == hipSuccess ? MRCA_OK : MRCA_ERR_HIP;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features launch: %s", hipGetErrorString(e));
+    return MRCA_OK;
 }

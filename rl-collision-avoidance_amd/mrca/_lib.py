@@ -20,7 +20,7 @@ FIELDS = [  # order = enum mrca_field
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
            "mrca_step", "mrca_step_slice", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
-           "mrca_lidar_features"]
+           "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward"]
 
 
 class MrcaConfig(C.Structure):
@@ -67,6 +67,9 @@ def load(path=None):
                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_lidar_features.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_lidar_features_backward_scratch.argtypes = [C.POINTER(C.c_size_t)]
+    lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + \
+        [C.c_size_t, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only
         lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]

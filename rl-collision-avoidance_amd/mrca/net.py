@@ -1,5 +1,6 @@
-"""The lidar actor-critic, kept in stock PyTorch (BASELINE.json north_star: "the 1-D-conv policy in
-model/net.py kept in PyTorch").
+"""The lidar actor-critic, kept in PyTorch (BASELINE.json north_star: "the 1-D-conv policy in
+model/net.py kept in PyTorch"): an ``nn.Module`` with the reference's parameters whose two Conv1d + ReLU pairs may run
+-- forward and backward -- through the hand-written HIP front end (``fused_train``, mrca/policy_ops.py) instead of MIOpen.
 
 Architecture and parameter names follow the reference's ``CNNPolicy`` (model/net.py:16-80) so that
 ``policy/stage2.pth`` style checkpoints load unchanged (state_dict keys: ``logstd``,
@@ -48,6 +49,17 @@ class CNNPolicy(nn.Module):
                 self.actor2 = nn.Linear(128, 1)
         self.critic = nn.Linear(128, 1)
 
+    # True: mean_value (and so forward / evaluate_actions, i.e. the PPO update) evaluates the conv front end of BOTH
+    # towers through policy_ops.lidar_features_fn -- fp32 MFMA forward and backward kernels, gradients to the same
+    # nn.Conv1d parameters.  Needs a GPU and frames = 3, beams = 512; results differ from the stock layers by
+    # summation order only (tests/test_gpu_policy_bwd.py).
+    fused_train = False
+
+    def _tail(self, tw, h, goal, speed):
+        h = torch.relu(getattr(self, f"{tw}_fc1")(h))
+        h = torch.cat((h, goal, speed), dim=-1)
+        return torch.relu(getattr(self, f"{tw}_fc2")(h))
+
     def _tower(self, tw, x, goal, speed):
         # the two Conv1d layers evaluated as H=1 conv2d on a channels-last tensor: same parameters, bitwise
         # the same result on gfx950, ~15 % faster because MIOpen skips its NCHW<->NHWC transposes
@@ -56,15 +68,22 @@ class CNNPolicy(nn.Module):
         h = x.unsqueeze(2).contiguous(memory_format=torch.channels_last)
         h = torch.relu(F.conv2d(h, c1.weight.unsqueeze(2), c1.bias, stride=(1, 2), padding=(0, 1)))
         h = torch.relu(F.conv2d(h, c2.weight.unsqueeze(2), c2.bias, stride=(1, 2), padding=(0, 1)))
-        h = torch.relu(getattr(self, f"{tw}_fc1")(h.contiguous().flatten(1)))
-        h = torch.cat((h, goal, speed), dim=-1)
-        return torch.relu(getattr(self, f"{tw}_fc2")(h))
+        return self._tail(tw, h.contiguous().flatten(1), goal, speed)
 
     def mean_value(self, x, goal, speed):
-        a = self._tower("act", x, goal, speed)
+        if self.fused_train and x.is_cuda:
+            from . import policy_ops
+            st = lambda a, c: torch.stack((a, c))      # noqa: E731  (its backward hands each tower its slice)
+            feat = policy_ops.lidar_features_fn(
+                x.float(), st(self.act_fea_cv1.weight, self.crt_fea_cv1.weight), st(self.act_fea_cv1.bias, self.crt_fea_cv1.bias),
+                st(self.act_fea_cv2.weight, self.crt_fea_cv2.weight), st(self.act_fea_cv2.bias, self.crt_fea_cv2.bias))
+            a = self._tail("act", feat[0], goal, speed)
+            c = self._tail("crt", feat[1], goal, speed)
+        else:
+            a = self._tower("act", x, goal, speed)
+            c = self._tower("crt", x, goal, speed)
         mean = torch.cat((torch.sigmoid(self.actor1(a)), torch.tanh(self.actor2(a))), dim=-1)
-        v = self.critic(self._tower("crt", x, goal, speed))
-        return mean, v
+        return mean, self.critic(c)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)

@@ -1,5 +1,7 @@
-"""HIP ops of the rollout path of the policy (csrc/mrca_policy.hip through the C ABI).  Inference only: the
-training path keeps the stock PyTorch layers (BASELINE.json north_star: "the 1-D-conv policy kept in PyTorch").
+"""HIP ops of the policy's lidar front end (csrc/mrca_policy.hip, csrc/mrca_policy_bwd.hip through the C ABI): the
+fused forward of both towers' Conv1d + ReLU pairs (rollout AND update) and its backward pass, tied together as a
+``torch.autograd.Function`` (``lidar_features_fn``) so that the PPO update (model/ppo.py:158-192) differentiates through
+hand-written fp32 MFMA kernels instead of MIOpen.  The rest of the policy stays stock PyTorch.
 There is no fallback: without the HIP library these raise."""
 import ctypes as C
 
@@ -25,3 +27,62 @@ def lidar_features(obs, w1, b1, w2, b2, out=None):
         _lib.check(lib.mrca_lidar_features(obs.data_ptr(), N, F, B, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                            b2.data_ptr(), out.data_ptr(), stream), "mrca_lidar_features")
     return out
+
+
+_scratch = {}
+
+
+def _backward_scratch(device):
+    """Per-device scratch of the backward kernel's per-wave partial sums (allocated once, reused by every call on the
+    device's current stream order)."""
+    key = (device.type, device.index)
+    if key not in _scratch:
+        lib = _lib.load()
+        n = C.c_size_t()
+        with torch.cuda.device(device):
+            _lib.check(lib.mrca_lidar_features_backward_scratch(C.byref(n)), "mrca_lidar_features_backward_scratch")
+        _scratch[key] = torch.empty(n.value, dtype=torch.uint8, device=device)
+    return _scratch[key]
+
+
+def lidar_features_backward(obs, w1, b1, w2, feat, gfeat):
+    """Gradients of lidar_features with respect to (w1, b1, w2, b2) given dLoss/dfeat; see include/mrca_env.h.
+    -> dw1 f32[2,32,3,5], db1 f32[2,32], dw2 f32[2,32,32,3], db2 f32[2,32]"""
+    lib = _lib.load()
+    N = obs.shape[0]
+    for t, shape in ((obs, (N, 3, 512)), (w1, (2, 32, 3, 5)), (b1, (2, 32)), (w2, (2, 32, 32, 3)), (feat, (2, N, 4096)),
+                     (gfeat, (2, N, 4096))):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
+            raise ValueError(f"lidar_features_backward: expected a contiguous cuda float32 tensor of shape {shape}, got "
+                             f"{tuple(t.shape)} {t.dtype} {t.device}")
+    dev = obs.device
+    dw1, db1 = torch.empty_like(w1), torch.empty_like(b1)
+    dw2, db2 = torch.empty_like(w2), torch.empty(2, 32, dtype=torch.float32, device=dev)
+    scratch = _backward_scratch(dev)
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mrca_lidar_features_backward(obs.data_ptr(), N, 3, 512, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                                    feat.data_ptr(), gfeat.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+                                                    dw2.data_ptr(), db2.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                                                    stream), "mrca_lidar_features_backward")
+    return dw1, db1, dw2, db2
+
+
+class _LidarFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obs, w1, b1, w2, b2):
+        obs, w1, b1, w2, b2 = (t.detach().contiguous() for t in (obs, w1, b1, w2, b2))
+        feat = lidar_features(obs, w1, b1, w2, b2)
+        ctx.save_for_backward(obs, w1, b1, w2, feat)
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        obs, w1, b1, w2, feat = ctx.saved_tensors
+        dw1, db1, dw2, db2 = lidar_features_backward(obs, w1, b1, w2, feat, gfeat.contiguous())
+        return None, dw1, db1, dw2, db2
+
+
+def lidar_features_fn(obs, w1, b1, w2, b2):
+    """Differentiable lidar_features: same arguments, gradients flow to w1 / b1 / w2 / b2 (the scan is data)."""
+    return _LidarFeatures.apply(obs, w1, b1, w2, b2)

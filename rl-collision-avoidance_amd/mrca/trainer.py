@@ -35,6 +35,8 @@ class HParams:
     single_frame_buffer: bool = True  # rollout buffer keeps one lidar frame per tick, not the 3-frame stack (ppo.RolloutBuffer)
     graph_tick: bool = False          # capture the rollout tick (policy + sampling + env tick + buffer stores) in a hipGraph
     rollout_fused: bool = False       # rollout inference through the HIP conv front end (net.mean_value_fused, fp32)
+    # the PPO update differentiates the conv front end through the HIP forward / backward kernels (net.CNNPolicy.fused_train)
+    update_fused: bool = False
     kl_target: float = 0.0            # > 0: KL-adaptive learning rate (ppo.KLAdaptiveLR; opt-in, large-batch regime)
     lr_max: float = 1e-3
     kl_stop: float = 0.0              # > 0: abandon the rest of an update when a minibatch reports KL > kl_stop x kl_target
@@ -60,6 +62,8 @@ class Stage1Trainer:
         self.policy = policy or CNNPolicy(frames=self.hp.laser_hist, action_space=self.hp.act_size,
                                           beams=self.hp.obs_size)
         self.policy.to(dev)
+        if self.hp.update_fused:
+            self.policy.fused_train = True
         broadcast_parameters(self.policy, dist)
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate)
         self.flat_grads = ppo.FlatGrads(self.policy.parameters())
@@ -103,7 +107,11 @@ class Stage1Trainer:
         side = torch.cuda.Stream(device=self.env.device)
         side.wait_stream(torch.cuda.current_stream(self.env.device))
         with torch.cuda.stream(side):
-            for _ in range(3):                          # warm-up on the capture stream (lazy inits, workspace allocs)
+            # warm-up on the capture stream (lazy inits, workspace allocs).  The three ticks really advance the env (their
+            # transitions are not logged: the first update's episode statistics miss them) but all write the buffer row
+            # the horizon is at, which the first real tick overwrites -- never a row past a short horizon
+            for _ in range(3):
+                self._t_idx.fill_(self.t)
                 self._tick_body()
         torch.cuda.current_stream(self.env.device).wait_stream(side)
         self._t_idx.fill_(self.t)
@@ -167,10 +175,10 @@ class Stage1Trainer:
 
 
 def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, update_dtype=None, fused=False,
-                    graph=False):
+                    graph=False, update_fused=False):
     """bench.py --mode rollout|train: returns step_fn(k) doing one tick for all robots."""
     hp = HParams(batch_size=batch_size, inference_dtype=inference_dtype, update_dtype=update_dtype, rollout_fused=fused,
-                 graph_tick=graph)
+                 graph_tick=graph, update_fused=update_fused)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0)
     tr.started = True  # bench.py resets the env itself
     if mode == "rollout" and graph:

@@ -15,6 +15,7 @@
 
 #include "../../rl-collision-avoidance_amd/csrc/mrca_device.h"
 #include "../../rl-collision-avoidance_amd/csrc/mrca_host.h"
+#include "../../rl-collision-avoidance_amd/csrc/mrca_policy_layout.h"
 
 using namespace mrca;
 
@@ -349,6 +350,19 @@ void emul_sincos(const float* th, int n, float* s, float* c) {
 void emul_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
     const U4 r = philox4x32_10(c0, c1, c2, c3, k0, k1);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+// --- the LDS image / operand address formulas of the policy's backward kernel (mrca_policy_layout.h), for
+//     tests/test_policy_bwd_layout.py
+int pl_rowmap(int reg, int hl) { return mrca_pbwd::rowmap(reg, hl); }
+int pl_x_operand_base(int kk) { return mrca_pbwd::x_operand_base(kk); }
+int pl_conv1_pstart(int h) { return mrca_pbwd::conv1_pstart(h); }
+int pl_h1_store_off(int p, int h) { return mrca_pbwd::h1_store_off(p, h); }
+void pl_constants(int* out) {
+    using namespace mrca_pbwd;
+    const int v[] = {kXPitch, kGPitch, kHPitch, kXE, kXO, kG2, kH1E, kH1O, kWaveFloats, kWavesPerBlock,
+                     kPartDw2, kPartDw1, kPartDb1, kPartDb2, kPartFloats, kHalf};
+    for (unsigned i = 0; i < sizeof(v) / sizeof(v[0]); ++i) out[i] = v[i];
 }
 
 }  // extern "C"

@@ -14,11 +14,25 @@ import pytest
 import torch
 
 DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+# "cuda-fused": the same goldens with the conv front end evaluated AND differentiated by the hand-written HIP kernels
+# (net.CNNPolicy.fused_train: csrc/mrca_policy.hip forward, csrc/mrca_policy_bwd.hip backward) instead of MIOpen
+POLICY_DEVICES = DEVICES + [pytest.param("cuda-fused", marks=pytest.mark.gpu)]
 
 
 def _need(device):
-    if device == "cuda" and not torch.cuda.is_available():
+    if device.startswith("cuda") and not torch.cuda.is_available():
         pytest.skip("no GPU")
+
+
+def _place(pol, device):
+    """-> the torch device; switches the policy's HIP front end on for the 'cuda-fused' leg."""
+    if device == "cuda-fused":
+        import __graft_entry__ as g
+        g.build()
+        pol.fused_train = True
+        device = "cuda"
+    pol.to(device)
+    return device
 
 import util as U
 from util import O
@@ -86,11 +100,11 @@ def test_filter_index_matches_reference_quirk_included(device):
     assert sorted(got.tolist()) == sorted(g["index"].tolist())
 
 
-@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("device", POLICY_DEVICES)
 def test_policy_forward_and_evaluate_match_reference(device):
     _need(device)
     pol, g, *_ = _policy()
-    pol.to(device)
+    device = _place(pol, device)
     x, goal, speed, action = (torch.from_numpy(g[k]).to(device) for k in ("x", "goal", "speed", "action"))
     with torch.no_grad():
         v, logprob, entropy = pol.evaluate_actions(x, goal, speed, action)
@@ -116,7 +130,7 @@ def _check_update(prefix, stage2, device="cpu"):
     from mrca import ppo
     tol = 1e-6 if device == "cpu" else 1e-5
     pol, _g, keys, shapes, sd0 = _policy()
-    pol.to(device)
+    device = _place(pol, device)
     g = np.load(os.path.join(GOLD, "ppo_update.npz"), allow_pickle=True)
     P = lambda k: g[f"{prefix}_{k}"]  # noqa: E731
     opt = torch.optim.Adam(pol.parameters(), lr=5e-5)
@@ -148,13 +162,13 @@ def _check_update(prefix, stage2, device="cpu"):
             assert abs(delta - want) <= 0.02 * want + 1e-7, (k, delta, want)
 
 
-@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("device", POLICY_DEVICES)
 def test_ppo_update_stage1_matches_reference(device):
     _need(device)
     _check_update("s1", False, device)
 
 
-@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("device", POLICY_DEVICES)
 def test_ppo_update_stage2_matches_reference(device):
     _need(device)
     _check_update("s2", True, device)

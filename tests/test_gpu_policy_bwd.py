@@ -1,0 +1,136 @@
+"""GPU: the backward kernel of the policy's conv front end (csrc/mrca_policy_bwd.hip) against torch.autograd through
+the stock Conv1d -> ReLU -> Conv1d -> ReLU layers of the same CNNPolicy (model/net.py:19-25,37-49).
+
+Tolerance: a weight gradient is a sum of N x 128 (conv2) / N x 255 (conv1) fp32 products; the kernel and MIOpen add them
+in different orders.  Small batches are compared with a float64 evaluation on the CPU to 2e-5 of the gradient's largest
+entry; the 4096- and 16 384-sample batches with the fp32 device result to 2e-4 of it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import util as U  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+
+
+def _weights(seed):
+    g = torch.Generator().manual_seed(seed)
+    w1 = torch.randn(2, 32, 3, 5, generator=g) * 0.3
+    b1 = torch.randn(2, 32, generator=g) * 0.1
+    w2 = torch.randn(2, 32, 32, 3, generator=g) * 0.1
+    b2 = torch.randn(2, 32, generator=g) * 0.1
+    return w1, b1, w2, b2
+
+
+def _autograd(x, w1, b1, w2, b2, gfeat, dtype, device):
+    x, gfeat = x.to(device, dtype), gfeat.to(device, dtype)
+    ps = [p.to(device, dtype).requires_grad_(True) for p in (w1, b1, w2, b2)]
+    feats = []
+    for t in range(2):
+        h = torch.relu(F.conv1d(x, ps[0][t], ps[1][t], stride=2, padding=1))
+        feats.append(torch.relu(F.conv1d(h, ps[2][t], ps[3][t], stride=2, padding=1)).flatten(1))
+    feat = torch.stack(feats)
+    feat.backward(gfeat)
+    return feat.detach(), [p.grad for p in ps]
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 513])
+def test_backward_equals_float64_autograd(n):
+    from mrca import policy_ops
+    w1, b1, w2, b2 = _weights(n)
+    g = torch.Generator().manual_seed(100 + n)
+    x = torch.rand(n, 3, 512, generator=g) - 0.5
+    gfeat = torch.randn(2, n, 4096, generator=g)
+    _, want = _autograd(x, w1, b1, w2, b2, gfeat, torch.float64, "cpu")
+    c = lambda t: t.cuda().contiguous()          # noqa: E731
+    feat = policy_ops.lidar_features(c(x), c(w1), c(b1), c(w2), c(b2))
+    got = policy_ops.lidar_features_backward(c(x), c(w1), c(b1), c(w2), feat, c(gfeat))
+    for name, a, b in zip(("dw1", "db1", "dw2", "db2"), got, want):
+        scale = float(b.abs().max())
+        err = float((a.cpu().double() - b).abs().max())
+        assert scale > 0.1 and err < 2e-5 * scale, (name, n, err, scale)
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_backward_equals_the_device_autograd_at_minibatch_size(n):
+    from mrca import policy_ops
+    w1, b1, w2, b2 = _weights(7)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.rand(n, 3, 512, generator=g, device="cuda") - 0.5
+    gfeat = torch.randn(2, n, 4096, generator=g, device="cuda") / n
+    feat_ref, want = _autograd(x, w1, b1, w2, b2, gfeat, torch.float32, "cuda")
+    c = lambda t: t.cuda().contiguous()          # noqa: E731
+    feat = policy_ops.lidar_features(x, c(w1), c(b1), c(w2), c(b2))
+    assert float((feat - feat_ref).abs().max()) < 1e-5
+    got = policy_ops.lidar_features_backward(x, c(w1), c(b1), c(w2), feat, gfeat)
+    again = policy_ops.lidar_features_backward(x, c(w1), c(b1), c(w2), feat, gfeat)
+    for name, a, a2, b in zip(("dw1", "db1", "dw2", "db2"), got, again, want):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) < 2e-4 * scale, (name, n, float((a - b).abs().max()), scale)
+        assert torch.equal(a, a2), name          # fixed-order reduction: bit-identical from run to run
+
+
+def test_backward_one_hot_probes():
+    """A single non-zero upstream gradient, scan sample and weight per tower must land in exactly the weight-gradient
+    entries the convolution arithmetic says."""
+    from mrca import policy_ops
+    w1 = torch.zeros(2, 32, 3, 5)
+    b1 = torch.zeros(2, 32)
+    w2 = torch.zeros(2, 32, 32, 3)
+    b2 = torch.zeros(2, 32)
+    w1[0, 5, 1, 3], w2[0, 9, 5, 0] = 2.0, 3.0        # actor: ch 5 <- frame 1 tap 3 ; ch 9 <- ch 5 tap 0
+    w1[1, 7, 2, 0], w2[1, 30, 7, 2] = 1.0, 1.0       # critic
+    b2[:] = 0.5                                      # keep the second ReLU open everywhere
+    b1[:] = 0.25
+    x = torch.zeros(3, 3, 512)
+    x[0, 1, 100], x[1, 2, 301], x[2, 0, 7] = 1.0, 1.0, -2.0
+    gfeat = torch.zeros(2, 3, 4096)
+    gfeat[0, 0, 9 * 128 + 26], gfeat[1, 1, 30 * 128 + 75], gfeat[0, 2, 3 * 128 + 127] = 1.0, -1.5, 2.0
+    _, want = _autograd(x, w1, b1, w2, b2, gfeat, torch.float64, "cpu")
+    c = lambda t: t.cuda().contiguous()          # noqa: E731
+    feat = policy_ops.lidar_features(c(x), c(w1), c(b1), c(w2), c(b2))
+    got = policy_ops.lidar_features_backward(c(x), c(w1), c(b1), c(w2), feat, c(gfeat))
+    for name, a, b in zip(("dw1", "db1", "dw2", "db2"), got, want):
+        assert float((a.cpu().double() - b).abs().max()) < 1e-6, name
+        assert int((b != 0).sum()) > 0, name
+
+
+def test_policy_gradients_with_the_hip_front_end_equal_the_stock_gradients():
+    """evaluate_actions -> PPO-like loss -> backward, once through the stock layers and once through
+    lidar_features_fn: every parameter's gradient agrees."""
+    from mrca.net import CNNPolicy
+    torch.manual_seed(5)
+    pol = CNNPolicy(3, 2).cuda()
+    with torch.no_grad():
+        for q in pol.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    n = 2048
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(n, 3, 512, device="cuda", generator=g) - 0.5
+    goal = torch.rand(n, 2, device="cuda", generator=g) * 10 - 5
+    speed = torch.rand(n, 2, device="cuda", generator=g)
+    act = torch.rand(n, 2, device="cuda", generator=g)
+    adv = torch.randn(n, 1, device="cuda", generator=g)
+    tgt = torch.randn(n, 1, device="cuda", generator=g)
+    grads = []
+    for fused in (False, True):
+        pol.fused_train = fused
+        pol.zero_grad()
+        v, lp, ent = pol.evaluate_actions(x, goal, speed, act)
+        loss = -(torch.exp(lp) * adv).mean() + 20.0 * F.mse_loss(v, tgt) - 5e-4 * ent
+        loss.backward()
+        grads.append({k: p.grad.clone() for k, p in pol.named_parameters()})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-9, (k, float((a - b).abs().max()), scale)
+    assert float(grads[1]["act_fea_cv1.weight"].abs().max()) > 0 and float(grads[1]["crt_fea_cv2.bias"].abs().max()) > 0

@@ -77,9 +77,10 @@ def emul_lib():
     if _emul_lib is not None:
         return _emul_lib
     src = os.path.join(ROOT, "tests", "host_emul", "emul.cpp")
-    hdr = os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc", "mrca_device.h")
+    hdrs = [os.path.join(ROOT, "rl-collision-avoidance_amd", "csrc", h)
+            for h in ("mrca_device.h", "mrca_host.h", "mrca_policy_layout.h")]
     out = os.path.join(ROOT, "tests", "host_emul", "libmrca_emul.so")
-    if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-shared", "-fPIC",
                                "-Wno-unknown-pragmas", src, "-o", out])
     _emul_lib = C.CDLL(out)

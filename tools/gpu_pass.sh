@@ -1,0 +1,87 @@
+#!/usr/bin/env bash
+# One parameterised GPU-box pass (replaces the per-pass one-shot scripts of rounds 1-2).
+#   TAG=r03a bash tools/gpu_pass.sh smoke tests bench update_bench prof ...
+# Stages (run in the order given; each bounded by its own timeout, logs under gpurun_out/$TAG/):
+#   smoke            __graft_entry__.smoke()
+#   tests            pytest -m gpu            (TESTS="tests/test_x.py ..." narrows it; PYTEST_ARGS adds flags)
+#   bench            bench.py default line (env-only, configs[1], cpu_baseline, roofline)
+#   bench_modes      bench.py rollout / train (fused and stock update) / stage2
+#   update_bench     tools/update_bench.py: forward + backward kernels of the conv front end, fwd+bwd+adam per minibatch
+#   ablate           tools/ablate.py (profiling build)
+#   prof             rocprofv3 --kernel-trace --stats of the default bench + FETCH_SIZE / WRITE_SIZE passes -> pmc_traffic.json
+#   prof_train       rocprofv3 --kernel-trace --stats of bench.py --mode train (one update)
+#   prof_rollout     rocprofv3 --kernel-trace --stats of bench.py --mode rollout --no-graph
+#   sq               tools/pmc_profile.sh (SQ counter sets of the env kernels)
+#   bigworld         tools/bigworld_bench.py
+#   circle           mrca.evaluate of the committed checkpoints (POLICY=... overrides)
+#   train            tools/train_recipe.sh (TRAIN_ARGS / S1_SECONDS / S2_SECONDS)
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd "$R"
+TAG="${TAG:-pass}"
+O="$R/gpurun_out/$TAG"
+mkdir -p "$O"
+export TMPDIR=/tmp
+export PYTHONPATH="$R/rl-collision-avoidance_amd"
+flt() { grep -v amdgpu.ids; }
+nproc > "$O/host.txt"; rocm-smi --showproductname 2>/dev/null | head -12 >> "$O/host.txt"
+for STAGE in "$@"; do
+  echo "==== $STAGE"
+  case "$STAGE" in
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke.log" 2>&1; echo "rc=$?"; tail -1 "$O/smoke.log" ;;
+    tests)
+      timeout "${TESTS_TIMEOUT:-1800}" python -m pytest ${TESTS:-tests} -m gpu -q ${PYTEST_ARGS:-} > "$O/pytest_gpu.log" 2>&1; echo "rc=$?"
+      flt < "$O/pytest_gpu.log" | tail -${TESTS_TAIL:-25} | cut -c1-400 ;;
+    bench)
+      timeout 600 python bench.py ${BENCH_ARGS:---steps 1000 --warmup 100} > "$O/bench_env.json" 2> "$O/bench.err"; echo "rc=$?"
+      cut -c1-2200 "$O/bench_env.json"; flt < "$O/bench.err" | tail -3 ;;
+    bench_modes)
+      timeout 600 python bench.py --mode rollout --steps 400 --warmup 40 --no-cpu-baseline --no-graph > "$O/bench_rollout.json" 2>> "$O/bench.err"; echo "rollout rc=$?"; cut -c1-260 "$O/bench_rollout.json"
+      timeout 900 python bench.py --mode train --steps 256 --warmup 0 --no-cpu-baseline --no-graph > "$O/bench_train.json" 2>> "$O/bench.err"; echo "train rc=$?"; cut -c1-260 "$O/bench_train.json"
+      timeout 900 python bench.py --mode train --steps 256 --warmup 0 --no-cpu-baseline --no-graph --update-path stock > "$O/bench_train_stock.json" 2>> "$O/bench.err"; echo "train stock rc=$?"; cut -c1-260 "$O/bench_train_stock.json"
+      timeout 600 python bench.py --scenario stage2 --worlds 187 --steps 500 --warmup 50 --no-cpu-baseline --no-extra > "$O/bench_stage2.json" 2>> "$O/bench.err"; echo "stage2 rc=$?"; cut -c1-260 "$O/bench_stage2.json"
+      flt < "$O/bench.err" | tail -4 ;;
+    update_bench)
+      timeout 900 python tools/update_bench.py ${UPDATE_BENCH_ARGS:-} 2>&1 | flt > "$O/update_bench.txt"; echo "rc=$?"; cut -c1-220 "$O/update_bench.txt" | head -80 ;;
+    ablate)
+      timeout 600 python tools/ablate.py 2>&1 | flt > "$O/ablate.txt"; echo "rc=$?"; cat "$O/ablate.txt" ;;
+    prof)
+      cd /tmp
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o trace -- python "$R/bench.py" --steps 300 --warmup 30 --no-cpu-baseline --no-extra > "$O/prof_trace.log" 2>&1; echo "trace rc=$?"
+      for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/prof" -o pmc_$C -- python "$R/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extra > "$O/prof_pmc_$C.log" 2>&1; echo "pmc $C rc=$?"
+      done
+      cd "$R"
+      f=$(find "$O/prof" -name "trace_kernel_stats.csv" | head -1); [ -n "$f" ] && head -5 "$f" | cut -c1-200 && cp "$f" "$O/env_kernel_stats.csv"
+      python tools/pmc_summary.py "$O/prof" > "$O/pmc_summary.txt" 2>&1; grep mrca "$O/pmc_summary.txt" | cut -c1-200
+      python tools/pmc_summary.py "$O/prof" --traffic-json "$O/pmc_traffic.json" 4096 stage1 | cut -c1-400
+      rm -rf "$O/prof" ;;
+    prof_train)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_train" -o trace -- python "$R/bench.py" --mode train --steps 128 --warmup 0 --no-cpu-baseline --no-graph > "$O/prof_train.log" 2>&1; echo "rc=$?"
+      cd "$R"
+      f=$(find "$O/prof_train" -name "trace_kernel_stats.csv" | head -1); [ -n "$f" ] && head -24 "$f" | cut -c1-230 && cp "$f" "$O/train_kernel_stats.csv"
+      rm -rf "$O/prof_train" ;;
+    prof_rollout)
+      cd /tmp
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_rollout" -o trace -- python "$R/bench.py" --mode rollout --steps 100 --warmup 20 --no-cpu-baseline --no-graph > "$O/prof_rollout.log" 2>&1; echo "rc=$?"
+      cd "$R"
+      f=$(find "$O/prof_rollout" -name "trace_kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-230 && cp "$f" "$O/rollout_kernel_stats.csv"
+      rm -rf "$O/prof_rollout" ;;
+    sq)
+      TAG="${TAG}_sq" timeout 900 bash tools/pmc_profile.sh > "$O/pmc_sq.log" 2>&1; cp "gpurun_out/pmc_${TAG}_sq/summary.txt" "$O/pmc_sq_summary.txt" 2>/dev/null
+      grep -E "raycast|move_kernel" "$O/pmc_sq_summary.txt" | head -60 | cut -c1-200 ;;
+    bigworld)
+      timeout 900 python tools/bigworld_bench.py ${BIGWORLD_ARGS:-} 2>&1 | flt | tee "$O/bigworld.jsonl" | cut -c1-300 ;;
+    circle)
+      for P in ${POLICY:-$R/rl-collision-avoidance_amd/mrca/data/policy_r02_stage2_circles.pth $R/rl-collision-avoidance_amd/mrca/data/policy_r02_all_circle_sizes.pth}; do
+        for SPEC in "10 8" "20 12" "30 16" "40 20" "50 25"; do set -- $SPEC
+          timeout 300 python -m mrca.evaluate --circles ${CIRCLES:-100} --robots $1 --radius $2 --policy "$P" --max-ticks 2000 ${EVAL_ARGS:-} 2>/dev/null | tail -1 | tee -a "$O/circle_eval.jsonl" | cut -c1-330
+        done
+      done ;;
+    train)
+      bash tools/train_recipe.sh "$O" ;;
+    *) echo "unknown stage $STAGE" ;;
+  esac
+done
+du -sh "$O"
