@@ -182,15 +182,16 @@ int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32_t frames, 
  *   obs_dev   f32[N,3,512]   the minibatch's observation stacks (no gradient: data)
  *   w1_dev f32[2,32,3,5]  b1_dev f32[2,32]  w2_dev f32[2,32,32,3]      the weights the forward ran with
  *   feat_dev  f32[2,N,4096]  the forward's output (its sign pattern is the second ReLU's mask)
- *   gfeat_dev f32[2,N,4096]  dLoss / dfeat
+ *   gfeat_act_dev, gfeat_crt_dev  f32[N,4096] each: dLoss / dfeat of the actor and of the critic tower (two buffers:
+ *                            they are the outputs of two independent fc1 backward GEMMs)
  *   dw1_dev f32[2,32,3,5]  db1_dev f32[2,32]  dw2_dev f32[2,32,32,3]  db2_dev f32[2,32]   out (overwritten)
  *   scratch_dev              caller-owned device scratch of at least mrca_lidar_features_backward_scratch() bytes
  *                            on the CURRENT device */
 int mrca_lidar_features_backward_scratch(size_t* bytes_out);
 int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams,
                                  const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* feat_dev,
-                                 const float* gfeat_dev, float* dw1_dev, float* db1_dev, float* dw2_dev, float* db2_dev,
-                                 void* scratch_dev, size_t scratch_bytes, void* stream);
+                                 const float* gfeat_act_dev, const float* gfeat_crt_dev, float* dw1_dev, float* db1_dev,
+                                 float* dw2_dev, float* db2_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 #ifdef MRCA_PROFILING
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product

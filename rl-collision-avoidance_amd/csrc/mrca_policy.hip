@@ -12,9 +12,18 @@
 // convolutions become unit-stride reads), both convolutions are fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32: exact f32,
 // a k-ordered fmaf chain) on implicit im2col operands read straight from LDS, the intermediate never leaves the CU,
 // and the weights of the tower live in registers for the wave's whole life (persistent waves walk the robots).
-//   conv1:  C[32 ch][256 pos] = W1[32][16] x X1[16][256]     (K = 3*5 = 15, padded to 16)   64 MFMAs
-//   conv2:  C[32 ch][128 pos] = W2[32][96] x X2[96][128]     (K = 32*3)                     192 MFMAs
+//   conv1:  C[32 ch][256 pos] = W1[32][16] x X1[16][256]     (K = 3*5 = 15 + the bias as a 16th k)   64 MFMAs
+//   conv2:  C[32 ch][128 pos] = W2[32][96] x X2[96][128]     (K = 32*3)                              192 MFMAs
 // 256 MFMAs x 64 cycles per (robot, tower): 55 us at 4096 robots if every SIMD issued back to back.
+//
+// What keeps the matrix pipe fed (round 3; the round-2 kernel reached 50 % of the fp32 MFMA peak -- its ISA waited on
+// every LDS read right before the MFMA that used it and staged the scan with six serialised HBM round trips):
+//   * the next robot's scan is requested from HBM as soon as the current one is staged;
+//   * every LDS operand is requested a chunk (8 MFMAs) ahead of its use, the order pinned with sched_barrier;
+//   * the K index is enumerated so that the two k of an MFMA step differ by a constant address offset
+//     (mrca_policy_layout.h): all operand addresses are "one of five lane-constant bases + immediate";
+//   * conv2 runs as two tile pairs; the first pair's output leaves through LDS as 16-byte rows (one float4 store per lane
+//     covers 4 rows x 256 contiguous bytes instead of a dword store per register) while the second pair's MFMAs run.
 //
 // fp32 in, fp32 accumulate: the result differs from the PyTorch layers only by summation order (tested to 1e-5).
 #include <hip/hip_runtime.h>
@@ -22,43 +31,29 @@
 
 #include "../../include/mrca_env.h"
 #include "mrca_hostutil.h"
+#include "mrca_policy_layout.h"
 
 namespace mrca_policy {
 
+using namespace mrca_pfwd;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kBeams = 512, kFrames = 3, kCh = 32;
-constexpr int kL1 = 255;            // conv1 output length: (512 + 2 - 5) / 2 + 1
-constexpr int kL2 = 128;            // conv2 output length: (255 + 2 - 3) / 2 + 1
-constexpr int kXPitch = 260;        // floats per de-interleaved scan row (259 used)
-constexpr int kHPitch = 130;        // floats per de-interleaved h1 row (129 used)
-// LDS per wave (floats): XE[3][kXPitch] XO[3][kXPitch] | H1E[32][kHPitch] H1O[32][kHPitch] | 256 zeros (the K-padding
-// operand of conv1, one per position of the 8 tiles)
-constexpr int kXE = 0, kXO = 3 * kXPitch, kH1E = 6 * kXPitch, kH1O = kH1E + kCh * kHPitch;
-constexpr int kZero = kH1O + kCh * kHPitch;
-constexpr int kWaveFloats = kZero + 256;
-constexpr int kWavesPerBlock = 4;
+#define MRCA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MRCA_PIN() __builtin_amdgcn_sched_barrier(0)
 
-// x[ci][2l + tap - 1] for conv1 position l, from the de-interleaved rows:
-//   XE[ci][j] = x[ci][2j],  XO[ci][j + 1] = x[ci][2j + 1],  XO[ci][0] = x[ci][-1] = 0 (left padding)
-//   tap 0 -> XO[ci][l]   tap 1 -> XE[ci][l]   tap 2 -> XO[ci][l+1]   tap 3 -> XE[ci][l+1]   tap 4 -> XO[ci][l+2]
-__device__ __host__ inline int conv1_operand_base(int kk) {
-    if (kk >= 15) return kZero;   // K padding: reads zeros (the matching weight is zero as well)
-    const int ci = kk / 5, tap = kk % 5;
-    const int row = ((tap & 1) ? kXE : kXO) + ci * kXPitch;
-    return row + (tap + 1) / 2 - ((tap & 1) ? 1 : 0);     // tap 0,1 -> +0 ; tap 2,3 -> +1 ; tap 4 -> +2
+__device__ inline f32x16 splat16(const float (&v)[16]) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = v[r];
+    return z;
 }
 
-// h1[ci][2l + tap - 1] for conv2 position l:
-//   H1E[ci][j] = h1[ci][2j],  H1O[ci][j + 1] = h1[ci][2j + 1],  H1O[ci][0] = h1[ci][-1] = 0,  h1[ci][255] = 0
-//   tap 0 -> H1O[ci][l]   tap 1 -> H1E[ci][l]   tap 2 -> H1O[ci][l+1]
-__device__ __host__ inline int conv2_operand_base(int kk) {
-    const int ci = kk / 3, tap = kk % 3;
-    return (tap == 1 ? kH1E : kH1O) + ci * kHPitch + (tap == 2 ? 1 : 0);
+__device__ inline f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
 }
-
-// C/D layout of v_mfma_f32_32x32x2_f32: lane holds column (lane & 31), rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-__device__ __host__ inline int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     const float* __restrict__ obs, int n_robots, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -70,45 +65,61 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     const int gwave = blockIdx.x * kWavesPerBlock + wave;
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int tower = gwave & 1;                 // waves come in (actor, critic) pairs on the same robots
-    const int col = lane & 31, half = lane >> 5;
+    const int col = lane & 31, hl = lane >> 5;
 
-    // --- the tower's weights as MFMA A fragments, for the wave's whole life: A[i = lane & 31][k = lane >> 5]
+    // --- the tower's weights as MFMA A fragments A[i = out channel = col][k], in the K orders of mrca_policy_layout.h
     float a1[8], a2[48];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const int kk = 2 * s + half;
-        a1[s] = kk < 15 ? w1[tower * 480 + col * 15 + kk] : 0.0f;
+        const int kk = conv1_kk(s, hl);
+        a1[s] = kk < 15 ? w1[tower * 480 + col * 15 + kk] : b1[tower * 32 + col];
     }
 #pragma unroll
-    for (int s = 0; s < 48; ++s) a2[s] = w2[tower * 3072 + col * 96 + 2 * s + half];
-    float bias1[16], bias2[16];
+    for (int s = 0; s < 48; ++s) a2[s] = w2[tower * 3072 + col * 96 + conv2_ci(s, hl) * 3 + conv2_tap(s, hl)];
+    float bias2[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        bias1[r] = b1[tower * 32 + mfma_row(r, lane)];
-        bias2[r] = b2[tower * 32 + mfma_row(r, lane)];
+    for (int r = 0; r < 16; ++r) bias2[r] = b2[tower * 32 + rowmap(r, hl)];
+
+    // constant parts of this wave's LDS image: the paddings x[ci][-1], h1[c][-1], h1[c][255] and the row tails the
+    // last conv1 tile reads for the non-existent position 255
+    if (lane < 3) {
+        lds[kXO + lane * kXPitch] = 0.0f;
+#pragma unroll
+        for (int k = 256; k < kXPitch; ++k) lds[kXE + lane * kXPitch + k] = 0.0f;
+#pragma unroll
+        for (int k = 257; k < kXPitch; ++k) lds[kXO + lane * kXPitch + k] = 0.0f;
     }
-    // constant parts of this wave's LDS image: left paddings, the right padding of h1, the zero block
-    for (int ci = lane; ci < 3; ci += 64) lds[kXO + ci * kXPitch] = 0.0f;
-    for (int ci = lane; ci < kCh; ci += 64) {
-        lds[kH1O + ci * kHPitch] = 0.0f;              // h1[ci][-1]
-        lds[kH1O + ci * kHPitch + 128] = 0.0f;        // h1[ci][255]
-    }
-    for (int k = lane; k < 256; k += 64) lds[kZero + k] = 0.0f;
-    // also clear the tails the padded conv1 tile may read (x[ci][512 .. 515])
-    for (int ci = lane; ci < 3; ci += 64) {
-        lds[kXE + ci * kXPitch + 256] = 0.0f;
-        lds[kXE + ci * kXPitch + 257] = 0.0f;
-        lds[kXO + ci * kXPitch + 257] = 0.0f;
-        lds[kXO + ci * kXPitch + 258] = 0.0f;
+    if (lane < kCh) {
+        lds[kH1O + lane * kHPitch] = 0.0f;
+        lds[kH1O + lane * kHPitch + 128] = 0.0f;
     }
 
-    for (int n = gwave >> 1; n < n_robots; n += nwaves >> 1) {
-        // --- stage the scan de-interleaved: 3 x 512 floats = 384 float4, 6 per lane
+    // lane-constant bases; every access below is <base>[<compile-time offset>]
+    const float* x1 = lds + col + hl;                    // conv1 operand families (mrca_policy_layout.h)
+    const float* x2 = lds + col + hl * kXPitch;
+    const float* x3 = lds + col;
+    float* hst = lds + ((col & 1) ? kH1O + (col + 1) / 2 : kH1E + col / 2) + 4 * hl * kHPitch;   // h1_store_off + row
+    const float* ha = lds + col + hl;                    // conv2 operand families
+    const float* hb = lds + col + hl * kHPitch;
+    float* oe = lds + kH1E + 4 * hl * kHPitch + col;     // epilogue: accumulators in, [channel][position]
+    const float* orow = lds + kH1E + (lane >> 4) * kHPitch + 4 * (lane & 15);   // ... rows out: float4 q -> channel 4q + lane/16
+    const size_t gofs = (size_t)(lane >> 4) * kL2 + 4 * (lane & 15);
+
+    const int stride = nwaves >> 1;
+    int n = gwave >> 1;
+    float4 sx[6];
+    if (n < n_robots) {
         const float4* src = reinterpret_cast<const float4*>(obs + (size_t)n * kFrames * kBeams);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sx[q] = src[q * 64 + lane];
+    }
+
+    for (; n < n_robots; n += stride) {
+        // --- stage the scan de-interleaved: 3 x 512 floats = 384 float4, 6 per lane; then request the next robot's
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int idx = q * 64 + lane;            // float4 index: ci = idx / 128, m = idx % 128 -> x[ci][4m .. 4m+3]
-            const float4 v = src[idx];
+            const float4 v = sx[q];
             const int ci = idx >> 7, m = idx & 127;
             float* xe = lds + kXE + ci * kXPitch + 2 * m;
             float* xo = lds + kXO + ci * kXPitch + 2 * m + 1;
@@ -117,60 +128,124 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
             xe[1] = v.z;
             xo[1] = v.w;
         }
-        // --- conv1: 8 position tiles of 32, four at a time (independent accumulators keep the MFMA pipe full)
+        MRCA_PIN();
+        if (n + stride < n_robots) {
+            const float4* src = reinterpret_cast<const float4*>(obs + (size_t)(n + stride) * kFrames * kBeams);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            f32x16 acc[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = bias1[r];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int base = half ? conv1_operand_base(2 * s + 1) : conv1_operand_base(2 * s);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float b = lds[base + (g * 4 + t) * 32 + col];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b, acc[t], 0, 0, 0);
-                }
-            }
-            // ReLU, then to LDS de-interleaved (position 255 does not exist: it is conv2's right padding)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int l = (g * 4 + t) * 32 + col;
-                const int dst = (l & 1) ? (kH1O + (l >> 1) + 1) : (kH1E + (l >> 1));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[t][r] > 0.0f ? acc[t][r] : 0.0f;
-                    if (l < kL1) lds[dst + mfma_row(r, lane) * kHPitch] = v;
-                }
-            }
+            for (int q = 0; q < 6; ++q) sx[q] = src[q * 64 + lane];
         }
-        // --- conv2: 4 position tiles of 32, all at once
+        MRCA_PIN();
+        float* out = feat + ((size_t)tower * n_robots + n) * (kCh * kL2) + gofs;
+
+        // --- conv1: 8 position tiles of 32 in pairs; the operands of the next pair are requested before this pair's MFMAs
         {
-            f32x16 acc[4];
+            float ba[2][8], bb[2][8];
+#define MRCA_CONV1_LOAD(buf, T)                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                      \
+        const float* base = conv1_family(s) == 1 ? x1 : (conv1_family(s) == 2 ? x2 : x3);                \
+        ba[buf][s] = base[conv1_step_off(s) + 32 * (T)];                                                 \
+        bb[buf][s] = base[conv1_step_off(s) + 32 * (T) + 32];                                            \
+    }                                                                                                    \
+    ba[buf][7] = hl ? 1.0f : ba[buf][7];                                                                 \
+    bb[buf][7] = hl ? 1.0f : bb[buf][7];
+            MRCA_CONV1_LOAD(0, 0)
+            MRCA_PIN();
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = bias2[r];
-#pragma unroll
-            for (int s = 0; s < 48; ++s) {
-                const int base = half ? conv2_operand_base(2 * s + 1) : conv2_operand_base(2 * s);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float b = lds[base + t * 32 + col];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], b, acc[t], 0, 0, 0);
+            for (int tp = 0; tp < 4; ++tp) {
+                const int cur = tp & 1, nxt = cur ^ 1, T = 2 * tp;
+                if (tp < 3) {
+                    MRCA_CONV1_LOAD(nxt, T + 2)
                 }
+                MRCA_PIN();
+                f32x16 acca = zero16(), accb = zero16();
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    acca = MRCA_MFMA(a1[s], ba[cur][s], acca);
+                    accb = MRCA_MFMA(a1[s], bb[cur][s], accb);
+                }
+                MRCA_PIN();
+                // ReLU, then to LDS de-interleaved (position 255 does not exist: H1O[c][128] stays conv2's right padding)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hst[16 * T + rowmap(r, 0) * kHPitch] = acca[r] > 0.0f ? acca[r] : 0.0f;
+                if (tp < 3 || col != 31) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        hst[16 * T + 16 + rowmap(r, 0) * kHPitch] = accb[r] > 0.0f ? accb[r] : 0.0f;
+                }
+                MRCA_PIN();
             }
-            float* out = feat + ((size_t)tower * n_robots + n) * (kCh * kL2);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[t][r] > 0.0f ? acc[t][r] : 0.0f;
-                    out[mfma_row(r, lane) * kL2 + t * 32 + col] = v;     // flatten order of [32, 128]: c * 128 + l
-                }
+#undef MRCA_CONV1_LOAD
         }
+
+        // --- conv2: two pairs of position tiles (positions 64 P .. 64 P + 63), 48 steps each, operands of four steps
+        //     requested ahead; pair 0's output leaves through H1E[c][0..63] while pair 1 computes
+        f32x16 acc0, acc1, done0, done1;
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+            acc0 = splat16(bias2);
+            acc1 = splat16(bias2);
+            float b0[2][4], b1v[2][4];
+#define MRCA_CONV2_LOAD(buf, ch)                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                      \
+        const int s = 4 * (ch) + k;                                                                      \
+        const float* base = s < 32 ? ha : hb;                                                            \
+        b0[buf][k] = base[conv2_step_off(s) + 64 * P];                                                   \
+        b1v[buf][k] = base[conv2_step_off(s) + 64 * P + 32];                                             \
+    }
+            MRCA_CONV2_LOAD(0, 0)
+            MRCA_PIN();
+#pragma unroll
+            for (int ch = 0; ch < 12; ++ch) {
+                const int cur = ch & 1, nxt = cur ^ 1;
+                if (ch < 11) {
+                    MRCA_CONV2_LOAD(nxt, ch + 1)
+                }
+                if (P == 1) {
+                    // pair 0's epilogue rides along: accumulators -> LDS (after this pair's first MFMAs are queued),
+                    // rows back as float4, out to HBM
+                    if (ch == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            oe[rowmap(r, 0) * kHPitch] = done0[r] > 0.0f ? done0[r] : 0.0f;
+                            oe[rowmap(r, 0) * kHPitch + 32] = done1[r] > 0.0f ? done1[r] : 0.0f;
+                        }
+                    }
+                    if (ch == 3 || ch == 5) {
+#pragma unroll
+                        for (int q = 4 * (ch == 5); q < 4 * (ch == 5) + 4; ++q) {
+                            const float4 v = *reinterpret_cast<const float4*>(orow + 4 * q * kHPitch);
+                            *reinterpret_cast<float4*>(out + 4 * q * kL2) = v;
+                        }
+                    }
+                }
+                MRCA_PIN();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int s = 4 * ch + k;
+                    acc0 = MRCA_MFMA(a2[s], b0[cur][k], acc0);
+                    acc1 = MRCA_MFMA(a2[s], b1v[cur][k], acc1);
+                }
+                MRCA_PIN();
+            }
+#undef MRCA_CONV2_LOAD
+            if (P == 0) {
+                done0 = acc0;
+                done1 = acc1;
+            }
+        }
+        // --- pair 1's epilogue through H1E[c][64..127] (its MFMAs have read it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oe[rowmap(r, 0) * kHPitch + 64] = acc0[r] > 0.0f ? acc0[r] : 0.0f;
+            oe[rowmap(r, 0) * kHPitch + 96] = acc1[r] > 0.0f ? acc1[r] : 0.0f;
+        }
+        MRCA_PIN();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(orow + 4 * q * kHPitch + 64);
+            *reinterpret_cast<float4*>(out + 4 * q * kL2 + 64) = v;
+        }
+        MRCA_PIN();
     }
 }
 
@@ -198,7 +273,7 @@ extern "C" int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features: hipGetDevice failed");
     DeviceInfo& d = g_dev[dev];
-    const size_t lds = (size_t)kWavesPerBlock * kWaveFloats * sizeof(float);
+    const size_t lds = (size_t)kWavesPerBlock * kWaveFloats * sizeof(float);   // 160 128 B
     if (d.cus == 0) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -212,7 +287,7 @@ extern "C" int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32
                                    hipGetErrorString(e));
         d.attr_set = true;
     }
-    // persistent waves: one workgroup of 4 waves per CU (159 kB of LDS), each wave pair walks every (#pairs)-th robot
+    // persistent waves: one workgroup of 4 waves per CU (156 kB of LDS), each wave pair walks every (#pairs)-th robot
     int blocks = d.cus;
     const int pairs_needed = (n_robots + 1) / 2;          // a block holds two (actor, critic) pairs
     if (blocks > pairs_needed) blocks = pairs_needed;

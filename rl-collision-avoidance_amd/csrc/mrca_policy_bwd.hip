@@ -2,7 +2,7 @@
 // Conv1d + ReLU per tower) as ONE fused gfx950 kernel for the PPO update (model/ppo.py:158-192 differentiates through
 // these layers for every minibatch; through MIOpen that is 85 % of an update: profiles/r01_f_ppo_update_profile.txt).
 //
-//   given  gfeat[t][n][c*128 + l] = dLoss / dfeat   (feat = the forward kernel's output, mrca_policy.hip)
+//   given  gfeat_t[n][c*128 + l] = dLoss / dfeat of tower t  (feat = the forward kernel's output, mrca_policy.hip)
 //   g2[c][l]   = gfeat * (feat > 0)                                                       l < 128
 //   dw2[c][ci][k] = sum_{n,l} g2[c][l] * h1[ci][2l + k - 1]          db2[c] = sum_{n,l} g2[c][l]
 //   dh1[ci][p] = sum_{c,k : 2l + k - 1 = p} w2[c][ci][k] * g2[c][l]  g1 = dh1 * (h1 > 0)  p < 255
@@ -19,10 +19,11 @@
 //   conv1 wgrad      DW1'[16 (ci,k)][32 c] += X1[16][pos] x D'[pos][32 c]   ... which IS the B operand layout of the
 //                                          contraction over positions: dgrad's accumulators feed conv1's wgrad in place,
 //                                          g1 never leaves the registers.  Row 15 of X1 is ones: that row of DW1' is db1.
-// An item is processed in two halves of 64 conv2 positions so that the h1 image of a wave is 16.6 kB and four waves fit
-// the CU's 160 kB of LDS (39.4 kB each).  The tower's weights live in registers for the wave's life; the next item's
-// scan / gfeat / feat are requested from HBM before the second half of the current item.  Per-wave partial sums go to a
-// scratch buffer; a second kernel adds them in a fixed order (deterministic, no float atomics).
+// An item is processed in two halves of 64 conv2 positions so that the h1 and g2 images of a wave are 8.3 kB each and four
+// waves fit the CU's 160 kB of LDS (31.2 kB each).  The tower's weights live in registers for the wave's life; the next
+// half's gfeat / feat rows (and the next item's scan) are requested from HBM while the current half computes, and every
+// LDS operand is requested a few MFMAs ahead of its use.  Per-wave partial sums go to a scratch buffer; a second kernel
+// adds them in a fixed order (deterministic, no float atomics).
 // MFMAs per (sample, tower): 64 + 192 + 192 + 128 = 576 (2.4 MFLOP); 16 384 x 2 items: 0.49 ms at the fp32 MFMA peak.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,29 +43,79 @@ __device__ inline f32x16 zero16() {
     return z;
 }
 
-struct ItemLoads {           // one item's HBM inputs in flight: the scan (6 float4 per lane), gfeat and feat (16 each)
-    float4 x[6], g[16], f[16];
+// HBM inputs in flight.  The scan of an item: 6 float4 per lane.  One HALF of an item's gfeat / feat rows (32 rows x 64
+// columns each): 8 + 8 float4 per lane, plus -- for half 0 -- column 64, which conv2's dgrad reads as "l + 1".
+struct ScanLoads {
+    float4 x[6];
+};
+struct GradLoads {
+    float4 g[8], f[8];
+    float ge, fe;
 };
 
-__device__ inline void request_item(ItemLoads& ld, const float* __restrict__ obs, const float* __restrict__ feat,
-                                    const float* __restrict__ gfeat, int n_items, int tower, int n, int lane) {
+__device__ inline void request_scan(ScanLoads& ld, const float* __restrict__ obs, int n, int lane) {
     const float4* xs = reinterpret_cast<const float4*>(obs + (size_t)n * kFrames * kBeams);
-    const size_t row = ((size_t)tower * n_items + n) * (kCh * kL2);
-    const float4* gs = reinterpret_cast<const float4*>(gfeat + row);
-    const float4* fs = reinterpret_cast<const float4*>(feat + row);
 #pragma unroll
     for (int q = 0; q < 6; ++q) ld.x[q] = xs[q * 64 + lane];
+}
+
+__device__ inline void request_grad(GradLoads& ld, const float* __restrict__ feat_t, const float* __restrict__ gfeat_t,
+                                    int n, int h, int lane) {
+    const size_t row = (size_t)n * (kCh * kL2) + kHalf * h;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        ld.g[q] = gs[q * 64 + lane];
-        ld.f[q] = fs[q * 64 + lane];
+    for (int q = 0; q < 8; ++q) {
+        const int idx = q * 64 + lane;           // float4 index: c = idx / 16, m = idx % 16 -> [c][64h + 4m .. 4m+3]
+        const size_t off = row + (size_t)(idx >> 4) * kL2 + 4 * (idx & 15);
+        ld.g[q] = *reinterpret_cast<const float4*>(gfeat_t + off);
+        ld.f[q] = *reinterpret_cast<const float4*>(feat_t + off);
+    }
+    ld.ge = 0.0f;
+    ld.fe = 0.0f;
+    if (h == 0 && lane < kCh) {
+        ld.ge = gfeat_t[row + (size_t)lane * kL2 + kHalf];
+        ld.fe = feat_t[row + (size_t)lane * kL2 + kHalf];
     }
 }
 
+__device__ inline void stage_scan(float* lds, const ScanLoads& ld, int lane) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int idx = q * 64 + lane;           // float4 index: ci = idx / 128, m = idx % 128 -> x[ci][4m .. 4m+3]
+        const float4 v = ld.x[q];
+        const int ci = idx >> 7, m = idx & 127;
+        float* xe = lds + kXE + ci * kXPitch + 2 * m;
+        float* xo = lds + kXO + ci * kXPitch + 2 * m + 1;
+        xe[0] = v.x;
+        xo[0] = v.y;
+        xe[1] = v.z;
+        xo[1] = v.w;
+    }
+}
+
+__device__ inline void stage_grad(float* lds, const GradLoads& ld, int lane) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int idx = q * 64 + lane;
+        const float4 g = ld.g[q], f = ld.f[q];
+        float* dst = lds + kG2 + (idx >> 4) * kGPitch + 4 * (idx & 15);
+        dst[0] = f.x > 0.0f ? g.x : 0.0f;
+        dst[1] = f.y > 0.0f ? g.y : 0.0f;
+        dst[2] = f.z > 0.0f ? g.z : 0.0f;
+        dst[3] = f.w > 0.0f ? g.w : 0.0f;
+    }
+    if (lane < kCh) lds[kG2 + lane * kGPitch + kHalf] = ld.fe > 0.0f ? ld.ge : 0.0f;
+}
+
+#define MRCA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// Pins the order "operands of the NEXT chunk requested, then the MFMAs of THIS chunk": left to itself hipcc (ROCm 7.2)
+// sinks the LDS reads next to their uses in half of this kernel's blocks ("ds_read, s_waitcnt lgkmcnt(0), v_mfma" --
+// every MFMA group then waits a full LDS round trip; measured 41 % of the MFMA peak)
+#define MRCA_PIN() __builtin_amdgcn_sched_barrier(0)
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel(
     const float* __restrict__ obs, int n_items, const float* __restrict__ w1, const float* __restrict__ b1,
-    const float* __restrict__ w2, const float* __restrict__ feat, const float* __restrict__ gfeat,
-    float* __restrict__ partial) {
+    const float* __restrict__ w2, const float* __restrict__ feat, const float* __restrict__ gfeat_act,
+    const float* __restrict__ gfeat_crt, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -73,6 +124,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
     const int nwaves = gridDim.x * kWavesPerBlock;
     const int tower = gwave & 1;                 // waves come in (actor, critic) pairs on the same samples
     const int col = lane & 31, hl = lane >> 5;
+    const float* __restrict__ feat_t = feat + (size_t)tower * n_items * (kCh * kL2);
+    const float* __restrict__ gfeat_t = tower ? gfeat_crt : gfeat_act;
 
     // --- the tower's weights in MFMA fragment form, for the wave's whole life
     // conv1 (A operand, A[i = out channel][k]): kk = 2s + hl; kk = 15 is the bias (its B operand is 1)
@@ -82,15 +135,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
         const int kk = 2 * s + hl;
         a1[s] = kk < 15 ? w1[tower * 480 + col * 15 + kk] : b1[tower * 32 + col];
     }
-    // conv2 dgrad (B operand, B[k = c][j = ci]): w2f[tap][s] = w2[c = 2s + hl][ci = col][tap]
-    float w2f[3][16];
-#pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-        for (int s = 0; s < 16; ++s) w2f[tap][s] = w2[tower * 3072 + ((2 * s + hl) * 32 + col) * 3 + tap];
+    // conv2 dgrad's B operand B[k = c][j = ci] = w2[c][ci][tap]: both towers' weights tap-major in LDS behind the four
+    // waves' images, W2L[tower][tap][c][ci] (24 kB per workgroup; 48 registers per lane if kept in fragments instead --
+    // with them the kernel spilled)
+    float* w2l_all = lds_all + kWavesPerBlock * kWaveFloats;
+    for (int k = threadIdx.x; k < 2 * 3072; k += 64 * kWavesPerBlock) {
+        const int t = k / 3072, rem = k % 3072, c = rem / 96, ci = (rem % 96) / 3, tap = rem % 3;
+        w2l_all[t * 3072 + (tap * 32 + c) * 32 + ci] = w2[k];
+    }
+    __syncthreads();
+    const float* w2l = w2l_all + tower * 3072 + hl * 32 + col;      // + (tap * 32 + 2s) * 32
 
-    // constant parts of the LDS image: x[ci][-1] = 0, the row tails conv1's wgrad reads for the non-existent h1
-    // position 255 (its g1 is 0, but 0 x garbage could be NaN), g2[c][128] = 0
+    // constant parts of the LDS image: x[ci][-1] = 0 and the row tails conv1's wgrad reads for the non-existent h1
+    // position 255 (its g1 is 0, but 0 x garbage could be NaN)
     if (lane < 3) {
         lds[kXO + lane * kXPitch] = 0.0f;
 #pragma unroll
@@ -98,108 +155,199 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
 #pragma unroll
         for (int k = 257; k < kXPitch; ++k) lds[kXO + lane * kXPitch + k] = 0.0f;
     }
-    if (lane < kCh) lds[kG2 + lane * kGPitch + kL2] = 0.0f;
 
     f32x16 acc2[3] = {zero16(), zero16(), zero16()};     // dw2[c = rowmap][ci = col][tap]
-    f32x16 acc1 = zero16();                              // rows (ci, tap) = rowmap < 15 and db1 (row 15), column c = col
+    f32x16 acc1e = zero16(), acc1o = zero16();           // rows (ci, tap) = rowmap < 15 and db1 (row 15), column c = col;
+                                                         // even / odd h1 positions in chains of their own
     float db2p = 0.0f;                                   // sum of this lane's g2[c = col][l] over its l
 
-    // lane-constant operand bases
-    int xb1[8];                                          // conv1 B operand base of step s for this lane's hl
+    // lane-constant operand addresses
+    // Every LDS access below is written as  <lane-constant base pointer>[<compile-time offset>]  with the lane's hl
+    // folded into the base: the offset then rides in the instruction's immediate field.  (Written as lds[f(hl) + ...]
+    // hipcc materialised -- and hoisted out of the item loop -- one address REGISTER per access: 64 of them for conv1's
+    // h1 stores alone, and spilled.)
+    const float* xrow[8];                                // conv1 B operand of step s: x[ci][2p + tap - 1], kk = 2s + hl
 #pragma unroll
-    for (int s = 0; s < 8; ++s) xb1[s] = x_operand_base((2 * s + hl) < 15 ? (2 * s + hl) : 14);
-    const int xbw = x_operand_base(col < 15 ? col : 0);  // conv1 wgrad A operand base: row (ci, tap) = col
+    for (int s = 0; s < 8; ++s) xrow[s] = lds + x_operand_base((2 * s + hl) < 15 ? (2 * s + hl) : 14) + col;
+    // conv1's h1 stores of position p = pstart(h) + 32 T + col, channel rowmap(r, hl): hst[h][16 T + rowmap(r, 0) * kHPitch]
+    float* hst[2];
+    hst[0] = lds + ((col & 1) ? kH1O + (col + 1) / 2 : kH1E + col / 2) + 4 * hl * kHPitch;
+    hst[1] = lds + ((col & 1) ? kH1E + (col - 1) / 2 : kH1O + col / 2) + 4 * hl * kHPitch;
+    const float* xw = lds + x_operand_base(col < 15 ? col : 0) + 8 * hl;   // conv1 wgrad A operand: row (ci, tap) = col
     const bool ones_row = col >= 15;                     // row 15 = ones (db1); rows 16..31 are not stored
+    const float* g2row = lds + kG2 + col * kGPitch + hl; // lanes over channels c, position 2s + hl
+    const float* g2col = lds + kG2 + hl * kGPitch + col; // lanes over positions, rows c = 2s + hl
+    const float* h1e = lds + kH1E + col * kHPitch + hl;  // lanes over channels ci, position 2s + hl
+    const float* h1o = lds + kH1O + col * kHPitch + hl;
+    const float* m1e = lds + kH1E + col * kHPitch + 4 * hl;   // the same rows at position rowmap(r, hl)
+    const float* m1o = lds + kH1O + col * kHPitch + 4 * hl;
 
     const int stride = nwaves >> 1;
     int n = gwave >> 1;
-    ItemLoads ld;
-    if (n < n_items) request_item(ld, obs, feat, gfeat, n_items, tower, n, lane);
+    ScanLoads sx;
+    GradLoads sg;
+    if (n < n_items) {
+        request_scan(sx, obs, n, lane);
+        request_grad(sg, feat_t, gfeat_t, n, 0, lane);
+    }
 
     for (; n < n_items; n += stride) {
-        // --- stage the scan de-interleaved and g2 = gfeat * (feat > 0)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int idx = q * 64 + lane;           // float4 index: ci = idx / 128, m = idx % 128 -> x[ci][4m .. 4m+3]
-            const float4 v = ld.x[q];
-            const int ci = idx >> 7, m = idx & 127;
-            float* xe = lds + kXE + ci * kXPitch + 2 * m;
-            float* xo = lds + kXO + ci * kXPitch + 2 * m + 1;
-            xe[0] = v.x;
-            xo[0] = v.y;
-            xe[1] = v.z;
-            xo[1] = v.w;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int idx = q * 64 + lane;           // float4 index: c = idx / 32, m = idx % 32 -> [c][4m .. 4m+3]
-            const float4 g = ld.g[q], f = ld.f[q];
-            float* dst = lds + kG2 + (idx >> 5) * kGPitch + 4 * (idx & 31);
-            dst[0] = f.x > 0.0f ? g.x : 0.0f;
-            dst[1] = f.y > 0.0f ? g.y : 0.0f;
-            dst[2] = f.z > 0.0f ? g.z : 0.0f;
-            dst[3] = f.w > 0.0f ? g.w : 0.0f;
-        }
-
+        stage_scan(lds, sx, lane);
+        MRCA_PIN();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (h == 1 && n + stride < n_items)      // the next item's inputs travel while this half computes
-                request_item(ld, obs, feat, gfeat, n_items, tower, n + stride, lane);
+            stage_grad(lds, sg, lane);
+            MRCA_PIN();
+            // the inputs of the next half travel while this one computes
+            if (h == 0) {
+                request_grad(sg, feat_t, gfeat_t, n, 1, lane);
+            } else if (n + stride < n_items) {
+                request_scan(sx, obs, n + stride, lane);
+                request_grad(sg, feat_t, gfeat_t, n + stride, 0, lane);
+            }
             // --- h1 paddings of this half: h = 0: h1[-1] (H1O[c][0]); h = 1: h1[255] (H1O[c][64])
             if (lane < kCh) lds[kH1O + lane * kHPitch + (h ? kHalf : 0)] = 0.0f;
-            // --- conv1 recompute: 128 positions p = pstart + 32 T + col, bias through the K padding
+            MRCA_PIN();
+            // --- conv1 recompute: 128 positions p = pstart + 32 T + col, two tiles at a time, bias through the K padding
             const int pstart = conv1_pstart(h);
 #pragma unroll
-            for (int T = 0; T < 4; ++T) {
-                f32x16 acc = zero16();
+            for (int T = 0; T < 4; T += 2) {
+                float ba[8], bb[8];
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    float b = lds[xb1[s] + pstart + 32 * T + col];
-                    if (s == 7) b = hl ? 1.0f : b;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b, acc, 0, 0, 0);
+                    ba[s] = xrow[s][pstart + 32 * T];
+                    bb[s] = xrow[s][pstart + 32 * T + 32];
                 }
-                const int dst = h1_store_off(pstart + 32 * T + col, h);
+                ba[7] = hl ? 1.0f : ba[7];
+                bb[7] = hl ? 1.0f : bb[7];
+                MRCA_PIN();
+                f32x16 acca = zero16(), accb = zero16();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) lds[dst + rowmap(r, hl) * kHPitch] = acc[r] > 0.0f ? acc[r] : 0.0f;
+                for (int s = 0; s < 8; ++s) {
+                    acca = MRCA_MFMA(a1[s], ba[s], acca);
+                    accb = MRCA_MFMA(a1[s], bb[s], accb);
+                }
+                MRCA_PIN();
+                // h1_store_off(pstart + 32 T + col, h) + rowmap(r, hl) * kHPitch, see hst above
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    hst[h][16 * T + rowmap(r, 0) * kHPitch] = acca[r] > 0.0f ? acca[r] : 0.0f;
+                    hst[h][16 * T + 16 + rowmap(r, 0) * kHPitch] = accb[r] > 0.0f ? accb[r] : 0.0f;
+                }
             }
-            // --- conv2 wgrad: contraction over this half's 64 positions, two per MFMA (l = 64h + 2s + hl)
+            // --- conv2 wgrad: contraction over this half's 64 positions, two per MFMA (i = 2s + hl), operands of four
+            //     steps requested ahead of the MFMAs that use them
+            {
+                float a[2][4], b0[2][4], b1v[2][4], b2[2][4];
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const int i = 2 * s + hl;
-                const float a = lds[kG2 + col * kGPitch + kHalf * h + i];
-                const float b0 = lds[kH1O + col * kHPitch + i];
-                const float b1v = lds[kH1E + col * kHPitch + i];
-                const float b2 = lds[kH1O + col * kHPitch + i + 1];
-                db2p += a;
-                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc2[0], 0, 0, 0);
-                acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1v, acc2[1], 0, 0, 0);
-                acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc2[2], 0, 0, 0);
+                for (int k = 0; k < 4; ++k) {
+                    const int i = 2 * k;
+                    a[0][k] = g2row[i];
+                    b0[0][k] = h1o[i];
+                    b1v[0][k] = h1e[i];
+                    b2[0][k] = h1o[i + 1];
+                }
+                MRCA_PIN();
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const int cur = ch & 1, nxt = cur ^ 1;
+                    if (ch < 7) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int i = 2 * (4 * (ch + 1) + k);
+                            a[nxt][k] = g2row[i];
+                            b0[nxt][k] = h1o[i];
+                            b1v[nxt][k] = h1e[i];
+                            b2[nxt][k] = h1o[i + 1];
+                        }
+                    }
+                    MRCA_PIN();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        db2p += a[cur][k];
+                        acc2[0] = MRCA_MFMA(a[cur][k], b0[cur][k], acc2[0]);
+                        acc2[1] = MRCA_MFMA(a[cur][k], b1v[cur][k], acc2[1]);
+                        acc2[2] = MRCA_MFMA(a[cur][k], b2[cur][k], acc2[2]);
+                    }
+                    MRCA_PIN();
+                }
             }
             // --- conv2 dgrad -> ReLU mask -> conv1 wgrad, 32 conv2 positions (64 h1 positions) at a time
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int L0 = kHalf * h + 32 * u;
-                f32x16 accE = zero16(), accO = zero16();     // dh1 at p = 2 (L0 + row) and 2 (L0 + row) + 1
+                const int I0 = 32 * u;                        // position inside the half; l = 64h + I0 + row
+                f32x16 accE = zero16(), accO = zero16();     // dh1 at p = 2l and 2l + 1
+                float ge[2][4], gs[2][4], wa[2][4], wb[2][4], wc[2][4];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float* g = lds + kG2 + (2 * s + hl) * kGPitch + L0 + col;
-                    const float ae = g[0], as = g[1];
-                    accE = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, w2f[1][s], accE, 0, 0, 0);
-                    accO = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, w2f[2][s], accO, 0, 0, 0);
-                    accO = __builtin_amdgcn_mfma_f32_32x32x2f32(as, w2f[0][s], accO, 0, 0, 0);
+                for (int k = 0; k < 4; ++k) {
+                    ge[0][k] = g2col[2 * k * kGPitch + I0];
+                    gs[0][k] = g2col[2 * k * kGPitch + I0 + 1];
+                    wa[0][k] = w2l[(0 * 32 + 2 * k) * 32];
+                    wb[0][k] = w2l[(1 * 32 + 2 * k) * 32];
+                    wc[0][k] = w2l[(2 * 32 + 2 * k) * 32];
+                }
+                MRCA_PIN();
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int cur = ch & 1, nxt = cur ^ 1;
+                    if (ch < 3) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int s = 4 * (ch + 1) + k;
+                            ge[nxt][k] = g2col[2 * s * kGPitch + I0];
+                            gs[nxt][k] = g2col[2 * s * kGPitch + I0 + 1];
+                            wa[nxt][k] = w2l[(0 * 32 + 2 * s) * 32];
+                            wb[nxt][k] = w2l[(1 * 32 + 2 * s) * 32];
+                            wc[nxt][k] = w2l[(2 * 32 + 2 * s) * 32];
+                        }
+                    }
+                    MRCA_PIN();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        accO = MRCA_MFMA(ge[cur][k], wc[cur][k], accO);
+                        accE = MRCA_MFMA(ge[cur][k], wb[cur][k], accE);
+                        accO = MRCA_MFMA(gs[cur][k], wa[cur][k], accO);
+                    }
+                    MRCA_PIN();
+                }
+                // the mask source and conv1 wgrad's first scan operands: requested while the last MFMAs drain
+                float me[16], mo[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    me[r] = m1e[I0 + rowmap(r, 0)];
+                    mo[r] = m1o[I0 + rowmap(r, 0) + 1];
+                }
+                float xe[2][4], xo[2][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = 2 * (kHalf * h + I0 + rowmap(k, 0));
+                    xe[0][k] = xw[p];
+                    xo[0][k] = xw[p + 1];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = 32 * u + rowmap(r, hl);
-                    accE[r] = lds[kH1E + col * kHPitch + i] > 0.0f ? accE[r] : 0.0f;
-                    accO[r] = lds[kH1O + col * kHPitch + i + 1] > 0.0f ? accO[r] : 0.0f;
+                    accE[r] = me[r] > 0.0f ? accE[r] : 0.0f;
+                    accO[r] = mo[r] > 0.0f ? accO[r] : 0.0f;
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = 2 * (L0 + rowmap(r, hl));
-                    const float xe = lds[xbw + p], xo = lds[xbw + p + 1];
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ones_row ? 1.0f : xe, accE[r], acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ones_row ? 1.0f : xo, accO[r], acc1, 0, 0, 0);
+                for (int ch = 0; ch < 4; ++ch) {
+                    const int cur = ch & 1, nxt = cur ^ 1;
+                    if (ch < 3) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int p = 2 * (kHalf * h + I0 + rowmap(4 * (ch + 1) + k, 0));
+                            xe[nxt][k] = xw[p];
+                            xo[nxt][k] = xw[p + 1];
+                        }
+                    }
+                    MRCA_PIN();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = 4 * ch + k;
+                        acc1e = MRCA_MFMA(ones_row ? 1.0f : xe[cur][k], accE[r], acc1e);
+                        acc1o = MRCA_MFMA(ones_row ? 1.0f : xo[cur][k], accO[r], acc1o);
+                    }
+                    MRCA_PIN();
                 }
             }
         }
@@ -214,25 +362,38 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = rowmap(r, hl);
-        if (i < 15) P[kPartDw1 + col * 15 + i] = acc1[r];
-        if (i == 15) P[kPartDb1 + col] = acc1[r];
+        const float v = acc1e[r] + acc1o[r];
+        if (i < 15) P[kPartDw1 + col * 15 + i] = v;
+        if (i == 15) P[kPartDb1 + col] = v;
     }
     const float other = __shfl_xor(db2p, 32);
     if (hl == 0) P[kPartDb2 + col] = db2p + other;
 }
 
-// out[t][k] = sum over the waves of tower t (gwave & 1 == t), in wave order
-__global__ void lidar_features_bwd_finalize(const float* __restrict__ partial, int nwaves, float* __restrict__ dw1,
-                                            float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= 2 * kPartFloats) return;
-    const int t = o / kPartFloats, k = o % kPartFloats;
+// out[t][k] = sum over the waves of tower t (gwave & 1 == t) in a FIXED order: a block owns 64 consecutive outputs of one
+// tower; its 16 wavefronts each add every 16th wave's partial (coalesced 256-byte rows), then the 16 sums are added in
+// index order.
+constexpr int kFinGroups = 16;
+__global__ __launch_bounds__(64 * kFinGroups) void lidar_features_bwd_finalize(
+    const float* __restrict__ partial, int nwaves, float* __restrict__ dw1, float* __restrict__ db1,
+    float* __restrict__ dw2, float* __restrict__ db2) {
+    __shared__ float part[kFinGroups][64];
+    const int j = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int chunks = (kPartFloats + 63) / 64;
+    const int t = blockIdx.x / chunks, k = (blockIdx.x % chunks) * 64 + j;
     float s = 0.0f;
-    for (int w = t; w < nwaves; w += 2) s += partial[(size_t)w * kPartFloats + k];
-    if (k < kPartDw1) dw2[t * 3072 + k] = s;
-    else if (k < kPartDb1) dw1[t * 480 + (k - kPartDw1)] = s;
-    else if (k < kPartDb2) db1[t * 32 + (k - kPartDb1)] = s;
-    else db2[t * 32 + (k - kPartDb2)] = s;
+    if (k < kPartFloats)
+        for (int w = t + 2 * grp; w < nwaves; w += 2 * kFinGroups) s += partial[(size_t)w * kPartFloats + k];
+    part[grp][j] = s;
+    __syncthreads();
+    if (grp != 0 || k >= kPartFloats) return;
+    float tot = 0.0f;
+#pragma unroll
+    for (int gidx = 0; gidx < kFinGroups; ++gidx) tot += part[gidx][j];
+    if (k < kPartDw1) dw2[t * 3072 + k] = tot;
+    else if (k < kPartDb1) dw1[t * 480 + (k - kPartDw1)] = tot;
+    else if (k < kPartDb2) db1[t * 32 + (k - kPartDb1)] = tot;
+    else db2[t * 32 + (k - kPartDb2)] = tot;
 }
 
 struct DeviceInfo {
@@ -253,7 +414,7 @@ static int prepare_device(int* cus_out) {
         d.cus = cus;
     }
     if (!d.attr_set) {
-        const size_t lds = (size_t)kWavesPerBlock * kWaveFloats * sizeof(float);
+        const size_t lds = (size_t)kBlockFloats * sizeof(float);
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_features_bwd_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
@@ -279,11 +440,11 @@ extern "C" int mrca_lidar_features_backward_scratch(size_t* bytes_out) {
 
 extern "C" int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams,
                                             const float* w1_dev, const float* b1_dev, const float* w2_dev,
-                                            const float* feat_dev, const float* gfeat_dev, float* dw1_dev,
-                                            float* db1_dev, float* dw2_dev, float* db2_dev, void* scratch_dev,
-                                            size_t scratch_bytes, void* stream) {
+                                            const float* feat_dev, const float* gfeat_act_dev,
+                                            const float* gfeat_crt_dev, float* dw1_dev, float* db1_dev, float* dw2_dev,
+                                            float* db2_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
     using namespace mrca_pbwd;
-    if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !feat_dev || !gfeat_dev || !dw1_dev || !db1_dev || !dw2_dev ||
+    if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !feat_dev || !gfeat_act_dev || !gfeat_crt_dev || !dw1_dev || !db1_dev || !dw2_dev ||
         !db2_dev || !scratch_dev)
         return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features_backward: NULL pointer");
     if (frames != kFrames || beams != kBeams || n_robots < 1)
@@ -298,11 +459,11 @@ extern "C" int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robo
     if (scratch_bytes < (size_t)nwaves * kPartFloats * sizeof(float))
         return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features_backward: scratch of %zu B < %zu B", scratch_bytes,
                                (size_t)nwaves * kPartFloats * sizeof(float));
-    const size_t lds = (size_t)kWavesPerBlock * kWaveFloats * sizeof(float);
+    const size_t lds = (size_t)kBlockFloats * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(lidar_features_bwd_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), lds, st, obs_dev, n_robots,
-                       w1_dev, b1_dev, w2_dev, feat_dev, gfeat_dev, static_cast<float*>(scratch_dev));
-    hipLaunchKernelGGL(lidar_features_bwd_finalize, dim3((2 * kPartFloats + 255) / 256), dim3(256), 0, st,
+                       w1_dev, b1_dev, w2_dev, feat_dev, gfeat_act_dev, gfeat_crt_dev, static_cast<float*>(scratch_dev));
+    hipLaunchKernelGGL(lidar_features_bwd_finalize, dim3(2 * ((kPartFloats + 63) / 64)), dim3(64 * kFinGroups), 0, st,
                        static_cast<const float*>(scratch_dev), nwaves, dw1_dev, db1_dev, dw2_dev, db2_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features_backward launch: %s", hipGetErrorString(e));

@@ -68,7 +68,7 @@ def load(path=None):
     lib.mrca_lidar_features.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_lidar_features_backward_scratch.argtypes = [C.POINTER(C.c_size_t)]
-    lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 10 + \
+    lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + \
         [C.c_size_t, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only

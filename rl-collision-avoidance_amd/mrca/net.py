@@ -74,11 +74,11 @@ class CNNPolicy(nn.Module):
         if self.fused_train and x.is_cuda:
             from . import policy_ops
             st = lambda a, c: torch.stack((a, c))      # noqa: E731  (its backward hands each tower its slice)
-            feat = policy_ops.lidar_features_fn(
+            fa, fc = policy_ops.lidar_features_fn(
                 x.float(), st(self.act_fea_cv1.weight, self.crt_fea_cv1.weight), st(self.act_fea_cv1.bias, self.crt_fea_cv1.bias),
                 st(self.act_fea_cv2.weight, self.crt_fea_cv2.weight), st(self.act_fea_cv2.bias, self.crt_fea_cv2.bias))
-            a = self._tail("act", feat[0], goal, speed)
-            c = self._tail("crt", feat[1], goal, speed)
+            a = self._tail("act", fa, goal, speed)
+            c = self._tail("crt", fc, goal, speed)
         else:
             a = self._tower("act", x, goal, speed)
             c = self._tower("crt", x, goal, speed)

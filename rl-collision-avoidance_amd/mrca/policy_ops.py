@@ -45,13 +45,14 @@ def _backward_scratch(device):
     return _scratch[key]
 
 
-def lidar_features_backward(obs, w1, b1, w2, feat, gfeat):
-    """Gradients of lidar_features with respect to (w1, b1, w2, b2) given dLoss/dfeat; see include/mrca_env.h.
+def lidar_features_backward(obs, w1, b1, w2, feat, gfeat_act, gfeat_crt):
+    """Gradients of lidar_features with respect to (w1, b1, w2, b2) given dLoss/dfeat of the two towers (two [N,4096]
+    buffers: they come out of two independent fc1 backward GEMMs); see include/mrca_env.h.
     -> dw1 f32[2,32,3,5], db1 f32[2,32], dw2 f32[2,32,32,3], db2 f32[2,32]"""
     lib = _lib.load()
     N = obs.shape[0]
     for t, shape in ((obs, (N, 3, 512)), (w1, (2, 32, 3, 5)), (b1, (2, 32)), (w2, (2, 32, 32, 3)), (feat, (2, N, 4096)),
-                     (gfeat, (2, N, 4096))):
+                     (gfeat_act, (N, 4096)), (gfeat_crt, (N, 4096))):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
             raise ValueError(f"lidar_features_backward: expected a contiguous cuda float32 tensor of shape {shape}, got "
                              f"{tuple(t.shape)} {t.dtype} {t.device}")
@@ -62,27 +63,35 @@ def lidar_features_backward(obs, w1, b1, w2, feat, gfeat):
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.mrca_lidar_features_backward(obs.data_ptr(), N, 3, 512, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-                                                    feat.data_ptr(), gfeat.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
-                                                    dw2.data_ptr(), db2.data_ptr(), scratch.data_ptr(), scratch.numel(),
-                                                    stream), "mrca_lidar_features_backward")
+                                                    feat.data_ptr(), gfeat_act.data_ptr(), gfeat_crt.data_ptr(),
+                                                    dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                                                    scratch.data_ptr(), scratch.numel(), stream),
+                   "mrca_lidar_features_backward")
     return dw1, db1, dw2, db2
 
 
 class _LidarFeatures(torch.autograd.Function):
+    """-> (actor features [N,4096], critic features [N,4096]): two outputs, so that autograd hands the backward kernel
+    the two fc1 gradients as they are (one stacked output cost a zero-fill + two copies + an add of [2,N,4096] per
+    minibatch: profiles/r03a_update_bench.txt)."""
+
     @staticmethod
     def forward(ctx, obs, w1, b1, w2, b2):
         obs, w1, b1, w2, b2 = (t.detach().contiguous() for t in (obs, w1, b1, w2, b2))
         feat = lidar_features(obs, w1, b1, w2, b2)
         ctx.save_for_backward(obs, w1, b1, w2, feat)
-        return feat
+        return feat[0], feat[1]
 
     @staticmethod
-    def backward(ctx, gfeat):
+    def backward(ctx, g_act, g_crt):
         obs, w1, b1, w2, feat = ctx.saved_tensors
-        dw1, db1, dw2, db2 = lidar_features_backward(obs, w1, b1, w2, feat, gfeat.contiguous())
+        g_act = torch.zeros_like(feat[0]) if g_act is None else g_act.contiguous()
+        g_crt = torch.zeros_like(feat[1]) if g_crt is None else g_crt.contiguous()
+        dw1, db1, dw2, db2 = lidar_features_backward(obs, w1, b1, w2, feat, g_act, g_crt)
         return None, dw1, db1, dw2, db2
 
 
 def lidar_features_fn(obs, w1, b1, w2, b2):
-    """Differentiable lidar_features: same arguments, gradients flow to w1 / b1 / w2 / b2 (the scan is data)."""
+    """Differentiable lidar_features: same arguments, returns (actor features, critic features), gradients flow to
+    w1 / b1 / w2 / b2 (the scan is data)."""
     return _LidarFeatures.apply(obs, w1, b1, w2, b2)

@@ -361,7 +361,21 @@ int pl_h1_store_off(int p, int h) { return mrca_pbwd::h1_store_off(p, h); }
 void pl_constants(int* out) {
     using namespace mrca_pbwd;
     const int v[] = {kXPitch, kGPitch, kHPitch, kXE, kXO, kG2, kH1E, kH1O, kWaveFloats, kWavesPerBlock,
-                     kPartDw2, kPartDw1, kPartDb1, kPartDb2, kPartFloats, kHalf};
+                     kPartDw2, kPartDw1, kPartDb1, kPartDb2, kPartFloats, kHalf, kBlockFloats};
+    for (unsigned i = 0; i < sizeof(v) / sizeof(v[0]); ++i) out[i] = v[i];
+}
+
+// --- the same for the forward kernel (namespace mrca_pfwd), for tests/test_policy_conv_layout.py
+int pf_conv1_kk(int s, int hl) { return mrca_pfwd::conv1_kk(s, hl); }
+int pf_conv1_family(int s) { return mrca_pfwd::conv1_family(s); }
+int pf_conv1_step_off(int s) { return mrca_pfwd::conv1_step_off(s); }
+int pf_conv2_ci(int s, int hl) { return mrca_pfwd::conv2_ci(s, hl); }
+int pf_conv2_tap(int s, int hl) { return mrca_pfwd::conv2_tap(s, hl); }
+int pf_conv2_step_off(int s) { return mrca_pfwd::conv2_step_off(s); }
+int pf_h1_store_off(int p) { return mrca_pfwd::h1_store_off(p); }
+void pf_constants(int* out) {
+    using namespace mrca_pfwd;
+    const int v[] = {kXPitch, kHPitch, kXE, kXO, kH1E, kH1O, kWaveFloats, kWavesPerBlock};
     for (unsigned i = 0; i < sizeof(v) / sizeof(v[0]); ++i) out[i] = v[i];
 }
 

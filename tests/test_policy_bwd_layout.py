@@ -17,9 +17,10 @@ import util as U
 
 SRC = open(os.path.join(U.ROOT, "rl-collision-avoidance_amd", "csrc", "mrca_policy_bwd.hip")).read()
 L = U.emul_lib()
-_c = (C.c_int * 16)()
+_c = (C.c_int * 17)()
 L.pl_constants(_c)
-(XP, GP, HP, kXE, kXO, kG2, kH1E, kH1O, WAVE_FLOATS, WAVES, P_DW2, P_DW1, P_DB1, P_DB2, P_FLOATS, HALF) = list(_c)
+(XP, GP, HP, kXE, kXO, kG2, kH1E, kH1O, WAVE_FLOATS, WAVES, P_DW2, P_DW1, P_DB1, P_DB2, P_FLOATS, HALF,
+ BLOCK_FLOATS) = list(_c)
 
 LANE = np.arange(64)
 COL, HL = LANE & 31, LANE >> 5
@@ -52,83 +53,97 @@ def mfma(a, b, acc):
 
 
 def test_lds_budget_and_layout_constants():
-    assert WAVES * WAVE_FLOATS * 4 <= 160 * 1024
+    assert BLOCK_FLOATS == WAVES * WAVE_FLOATS + 2 * 3 * 32 * 32 and BLOCK_FLOATS * 4 <= 160 * 1024
     assert GP % 2 == 1 and HP % 2 == 1          # rows read with lanes over channels: odd pitches are conflict-free
     assert kXO == 3 * XP and kG2 == 6 * XP and kH1E == kG2 + 32 * GP and kH1O == kH1E + 32 * HP
     assert WAVE_FLOATS == kH1O + 32 * HP
     # the kernel uses the header's formulas, not private copies
     for name in ("x_operand_base(", "h1_store_off(", "rowmap(", "conv1_pstart("):
         assert name in SRC
-    assert len(re.findall(r"__builtin_amdgcn_mfma_f32_32x32x2f32", SRC)) == 9
+    assert len(re.findall(r"MRCA_MFMA\(", SRC)) == 11          # the macro + 10 uses
 
 
 def reenact(x, w1, b1, w2, feat, gfeat):
     """One wave's work on the items x[n] of ONE tower; returns its partial sums (dw2, dw1, db1, db2)."""
     lds = np.full(WAVE_FLOATS, np.nan)                      # NaN everywhere: a read of an unwritten word shows up
     a1 = [np.where(2 * s + HL < 15, w1.reshape(32, 15)[COL, np.minimum(2 * s + HL, 14)], b1[COL]) for s in range(8)]
-    w2f = [[w2[2 * s + HL, COL, tap] for s in range(16)] for tap in range(3)]
+    # W2L[tap][c][ci]: conv2's weights tap-major in LDS; this lane reads w2l[(tap * 32 + 2s) * 32] from its base
+    w2l_img = np.full(3072, np.nan)
+    for k in range(3072):
+        c, ci, tap = k // 96, (k % 96) // 3, k % 3
+        w2l_img[(tap * 32 + c) * 32 + ci] = w2.reshape(-1)[k]
+    w2l_base = HL * 32 + COL
     for ci in range(3):
         lds[kXO + ci * XP] = 0
         lds[kXE + ci * XP + 256: kXE + (ci + 1) * XP] = 0
         lds[kXO + ci * XP + 257: kXO + (ci + 1) * XP] = 0
-    lds[kG2 + np.arange(32) * GP + 128] = 0
     acc2 = [np.zeros((64, 16)) for _ in range(3)]
-    acc1 = np.zeros((64, 16))
+    acc1e, acc1o = np.zeros((64, 16)), np.zeros((64, 16))
     db2p = np.zeros(64)
-    xb1 = [xbase(np.minimum(2 * s + HL, 14)) for s in range(8)]
-    xbw = xbase(np.where(COL < 15, COL, 0))
+    xrow = [xbase(np.minimum(2 * s + HL, 14)) + COL for s in range(8)]
+    hst = [np.where(COL & 1, kH1O + (COL + 1) // 2, kH1E + COL // 2) + 4 * HL * HP,
+           np.where(COL & 1, kH1E + (COL - 1) // 2, kH1O + COL // 2) + 4 * HL * HP]
+    xw = xbase(np.where(COL < 15, COL, 0)) + 8 * HL
     ones_row = COL >= 15
+    g2row = kG2 + COL * GP + HL
+    g2col = kG2 + HL * GP + COL
+    h1e, h1o = kH1E + COL * HP + HL, kH1O + COL * HP + HL
+    m1e, m1o = kH1E + COL * HP + 4 * HL, kH1O + COL * HP + 4 * HL
+    ROW0 = [L.pl_rowmap(r, 0) for r in range(16)]
     for n in range(x.shape[0]):
-        for idx in range(384):
+        for idx in range(384):                              # stage_scan
             ci, m = idx >> 7, idx & 127
             v = x[n, ci, 4 * m: 4 * m + 4]
             xe, xo = kXE + ci * XP + 2 * m, kXO + ci * XP + 2 * m + 1
             lds[xe], lds[xo], lds[xe + 1], lds[xo + 1] = v
-        for idx in range(1024):
-            c, m = idx >> 5, idx & 31
-            g, f = gfeat[n, c * 128 + 4 * m: c * 128 + 4 * m + 4], feat[n, c * 128 + 4 * m: c * 128 + 4 * m + 4]
-            lds[kG2 + c * GP + 4 * m: kG2 + c * GP + 4 * m + 4] = np.where(f > 0, g, 0)
         for h in range(2):
+            for idx in range(512):                          # stage_grad: rows c, columns [64h, 64h + 64) + column 64
+                c, m = idx >> 4, idx & 15
+                o = c * 128 + HALF * h + 4 * m
+                lds[kG2 + c * GP + 4 * m: kG2 + c * GP + 4 * m + 4] = np.where(feat[n, o: o + 4] > 0, gfeat[n, o: o + 4], 0)
+            for c in range(32):
+                ge, fe = (gfeat[n, c * 128 + HALF], feat[n, c * 128 + HALF]) if h == 0 else (0.0, 0.0)
+                lds[kG2 + c * GP + HALF] = ge if fe > 0 else 0.0
             lds[kH1O + np.arange(32) * HP + (HALF if h else 0)] = 0
             pstart = L.pl_conv1_pstart(h)
-            for T in range(4):
-                acc = np.zeros((64, 16))
+            for T in range(0, 4, 2):
+                acca, accb = np.zeros((64, 16)), np.zeros((64, 16))
                 for s in range(8):
-                    b = lds[xb1[s] + pstart + 32 * T + COL]
+                    ba, bb = lds[xrow[s] + pstart + 32 * T], lds[xrow[s] + pstart + 32 * T + 32]
                     if s == 7:
-                        b = np.where(HL == 1, 1.0, b)
-                    mfma(a1[s], b, acc)
-                dst = h1_store(pstart + 32 * T + COL, h)
+                        ba, bb = np.where(HL == 1, 1.0, ba), np.where(HL == 1, 1.0, bb)
+                    mfma(a1[s], ba, acca)
+                    mfma(a1[s], bb, accb)
+                # the store formula must be the header's h1_store_off + rowmap * pitch
+                assert np.array_equal(hst[h] + 16 * T, h1_store(pstart + 32 * T + COL, h) + 4 * HL * HP)
+                assert np.array_equal(hst[h] + 16 * T + 16, h1_store(pstart + 32 * T + 32 + COL, h) + 4 * HL * HP)
                 for r in range(16):
-                    lds[dst + ROW[:, r] * HP] = np.maximum(acc[:, r], 0)
+                    lds[hst[h] + 16 * T + ROW0[r] * HP] = np.maximum(acca[:, r], 0)
+                    lds[hst[h] + 16 * T + 16 + ROW0[r] * HP] = np.maximum(accb[:, r], 0)
             for s in range(32):
-                i = 2 * s + HL
-                a = lds[kG2 + COL * GP + HALF * h + i]
-                b0 = lds[kH1O + COL * HP + i]
-                b1v = lds[kH1E + COL * HP + i]
-                b2 = lds[kH1O + COL * HP + i + 1]
+                i = 2 * s
+                a = lds[g2row + i]
                 db2p += a
-                mfma(a, b0, acc2[0])
-                mfma(a, b1v, acc2[1])
-                mfma(a, b2, acc2[2])
+                mfma(a, lds[h1o + i], acc2[0])
+                mfma(a, lds[h1e + i], acc2[1])
+                mfma(a, lds[h1o + i + 1], acc2[2])
             for u in range(2):
-                L0 = HALF * h + 32 * u
+                I0 = 32 * u
                 accE, accO = np.zeros((64, 16)), np.zeros((64, 16))
                 for s in range(16):
-                    g = kG2 + (2 * s + HL) * GP + L0 + COL
-                    ae, as_ = lds[g], lds[g + 1]
-                    mfma(ae, w2f[1][s], accE)
-                    mfma(ae, w2f[2][s], accO)
-                    mfma(as_, w2f[0][s], accO)
+                    ge, gs = lds[g2col + 2 * s * GP + I0], lds[g2col + 2 * s * GP + I0 + 1]
+                    wa, wb, wc = (w2l_img[w2l_base + (tap * 32 + 2 * s) * 32] for tap in range(3))
+                    mfma(ge, wc, accO)
+                    mfma(ge, wb, accE)
+                    mfma(gs, wa, accO)
                 for r in range(16):
-                    i = 32 * u + ROW[:, r]
-                    accE[:, r] = np.where(lds[kH1E + COL * HP + i] > 0, accE[:, r], 0)
-                    accO[:, r] = np.where(lds[kH1O + COL * HP + i + 1] > 0, accO[:, r], 0)
+                    accE[:, r] = np.where(lds[m1e + I0 + ROW0[r]] > 0, accE[:, r], 0)
+                    accO[:, r] = np.where(lds[m1o + I0 + ROW0[r] + 1] > 0, accO[:, r], 0)
                 for r in range(16):
-                    p = 2 * (L0 + ROW[:, r])
-                    xe, xo = lds[xbw + p], lds[xbw + p + 1]
-                    mfma(np.where(ones_row, 1.0, xe), accE[:, r], acc1)
-                    mfma(np.where(ones_row, 1.0, xo), accO[:, r], acc1)
+                    p = 2 * (HALF * h + I0 + ROW0[r])
+                    mfma(np.where(ones_row, 1.0, lds[xw + p]), accE[:, r], acc1e)
+                    mfma(np.where(ones_row, 1.0, lds[xw + p + 1]), accO[:, r], acc1o)
+    acc1 = acc1e + acc1o
     P = np.full(P_FLOATS, np.nan)
     for tap in range(3):
         for r in range(16):

@@ -49,7 +49,7 @@ for bs in sizes:
     feat = policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"])
     gfeat = torch.randn_like(feat)
     t_f = timed(lambda: policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"], out=feat))
-    t_b = timed(lambda: policy_ops.lidar_features_backward(x, rc["w1"], rc["b1"], rc["w2"], feat, gfeat))
+    t_b = timed(lambda: policy_ops.lidar_features_backward(x, rc["w1"], rc["b1"], rc["w2"], feat, gfeat[0], gfeat[1]))
     out = {"minibatch": bs,
            "forward_kernel_us": t_f * 1e6, "forward_tflops": 2 * bs * FWD_FLOP / t_f / 1e12,
            "forward_frac_of_fp32_mfma_peak": 2 * bs * FWD_FLOP / t_f / 1e12 / PEAK,
