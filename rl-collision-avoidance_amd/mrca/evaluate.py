@@ -50,18 +50,44 @@ def staggered_roundabout_policy(num_robots, bias=1.4, near=3.5, vgain=0.8, stop=
     return fn
 
 
-def cnn_policy_fn(policy):
+def cnn_policy_fn(policy, fused=False):
     def fn(obs, local_goal, speed):
-        _mean, scaled = ppo.generate_action_no_sampling(policy, obs, local_goal, speed, ACTION_BOUND)
+        _mean, scaled = ppo.generate_action_no_sampling(policy, obs, local_goal, speed, ACTION_BOUND, fused=fused)
         return scaled
     return fn
 
 
-def circle_test(env, policy_fn, max_ticks=1200):
+def perturbed_start(env, jitter_xy, jitter_th, seed):
+    """Start poses of a circle world with every robot moved off its table pose by U(-jitter_xy, jitter_xy) metres in x
+    and y and U(-jitter_th, jitter_th) radians of heading -- drawn from a Philox generator seeded with ``seed``, so that
+    W circles are W DIFFERENT scenarios (the reference's table, model/utils.py:6-38, is one perfectly symmetric
+    scenario: a deterministic policy either solves all of its copies or none).  Goals stay the table's.
+    -> (poses f32[N,3], goals f32[N,2]) on the env's device."""
+    sc = env.scenario
+    dev = env.obs.device
+    W, R = sc.num_worlds, sc.robots_per_world
+    base = torch.as_tensor(sc.init_table, dtype=torch.float32, device=dev).unsqueeze(0).expand(W, R, 3)
+    goal = torch.as_tensor(sc.goal_table, dtype=torch.float32, device=dev).unsqueeze(0).expand(W, R, 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    u = torch.rand(W, R, 3, generator=g, device=dev) * 2.0 - 1.0
+    scale = torch.tensor([jitter_xy, jitter_xy, jitter_th], dtype=torch.float32, device=dev)
+    poses = base + u * scale
+    poses[..., 2] = torch.atan2(torch.sin(poses[..., 2]), torch.cos(poses[..., 2]))
+    return poses.reshape(W * R, 3).contiguous(), goal.reshape(W * R, 2).contiguous()
+
+
+def circle_test(env, policy_fn, max_ticks=1200, perturb=None, seed=0):
     """Runs the circle scenario on ``env`` (any object with the VecStageWorld surface) and returns
     the metrics dict.  Mirrors circle_test.py:52-80: deterministic action, and a robot whose last
-    ``get_reward_and_terminate`` said terminal gets v = 0 (``real_action[0] = 0``, :64-65)."""
-    env.reset()
+    ``get_reward_and_terminate`` said terminal gets v = 0 (``real_action[0] = 0``, :64-65).
+    ``perturb = (jitter_xy, jitter_th)``: every circle starts from its own jittered poses (``perturbed_start``); the
+    metrics then carry the mean success rate over circles with a 95 % interval."""
+    if perturb is None:
+        env.reset()
+    else:
+        poses, goals = perturbed_start(env, perturb[0], perturb[1], seed)
+        env.reset(None, poses, goals)
     N = env.N
     dev = env.obs.device
     ticks_to_goal = torch.zeros(N, device=dev)
@@ -87,7 +113,18 @@ def circle_test(env, policy_fn, max_ticks=1200):
     extra_time = (time_s - straight / 1.0)[reach]
     extra_dist = (path - straight)[reach]
     avg_speed = (path / time_s.clamp(min=0.1))[reach]
+    R = getattr(getattr(env, "scenario", None), "robots_per_world", None)
+    per_circle = {}
+    if R and N % R == 0 and N // R > 1:
+        # the circle is the unit of randomisation: mean of the per-circle success fractions, normal 95 % interval of
+        # that mean (robots of one circle succeed or fail together far too often to count as independent samples)
+        sr = reach.view(N // R, R).float().mean(dim=1)
+        sd = float(sr.std(unbiased=True))
+        half = 1.96 * sd / math.sqrt(N // R)
+        per_circle = {"circles": N // R, "success_rate_ci95": [max(0.0, float(sr.mean()) - half), min(1.0, float(sr.mean()) + half)],
+                      "circles_fully_solved": float((sr == 1.0).float().mean()), "worst_circle": float(sr.min())}
     return {
+        **per_circle,
         "robots": N, "ticks_run": k + 1,
         "success_rate": n_reach / N,
         "crash_rate": float((fr == 2).float().mean()),
@@ -109,20 +146,31 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--robots", type=int, default=50, help="robots per circle (50 = the reference's table; others: scenario.circle_n)")
     ap.add_argument("--radius", type=float, default=25.0)
+    ap.add_argument("--perturb", default=None, help="'dxy,dth': start every robot U(-dxy, dxy) m / U(-dth, dth) rad off its table "
+                                                     "pose (Philox, seeded by --seed) so that the circles are different scenarios, "
+                                                     "e.g. 0.2,0.1; the output carries the mean success rate with a 95 %% interval")
+    ap.add_argument("--stage-resolution", action="store_true", help="fidelity mode: the map at Stage's own cell size "
+                                                                      "(worlds/circle.world:3) -- the clearances a Stage-trained policy lives with")
+    ap.add_argument("--fused", action="store_true", help="policy inference through the fp32 HIP conv front end")
     a = ap.parse_args()
     from .vec_env import VecStageWorld
-    sc = scenario.circle(num_worlds=a.circles, seed=a.seed) if (a.robots == 50 and a.radius == 25.0) else \
-        scenario.circle_n(a.robots, a.radius, num_worlds=a.circles, seed=a.seed)
+    if a.robots == 50 and a.radius == 25.0:
+        sc = scenario.circle(num_worlds=a.circles, seed=a.seed, stage_resolution=a.stage_resolution)
+    else:
+        grid = scenario.load_map("circle_rink_r0010") if a.stage_resolution else None
+        sc = scenario.circle_n(a.robots, a.radius, num_worlds=a.circles, seed=a.seed, grid=grid)
     env = VecStageWorld(sc)
     if a.policy:
         pol = CNNPolicy(3, 2).to(env.device)
         pol.load_state_dict(torch.load(a.policy, map_location=env.device))
-        fn, name = cnn_policy_fn(pol), a.policy
+        fn, name = cnn_policy_fn(pol, fused=a.fused), a.policy
     else:
         fn, name = staggered_roundabout_policy(env.N), "staggered-roundabout stand-in (no checkpoint given)"
-    out = circle_test(env, fn, a.max_ticks)
+    perturb = tuple(float(v) for v in a.perturb.split(",")) if a.perturb else None
+    out = circle_test(env, fn, a.max_ticks, perturb=perturb, seed=a.seed)
     out["policy"] = name
     out["robots_per_circle"], out["radius_m"] = a.robots, a.radius
+    out["perturb_xy_th"], out["seed"], out["stage_resolution"] = perturb, a.seed, bool(a.stage_resolution)
     print(json.dumps(out))
 
 

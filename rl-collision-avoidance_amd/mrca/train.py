@@ -76,6 +76,12 @@ def main(argv=None):
     ap.add_argument("--circle-sizes", default="50:25", help="validation circles as 'robots:radius,...' (50:25 = the reference's "
                                                              "circle test); the score of a checkpoint is the MINIMUM success rate")
     ap.add_argument("--circle-worlds", type=int, default=20)
+    ap.add_argument("--circle-perturb", default="", help="'dxy,dth': validate on PERTURBED circles (evaluate.perturbed_start) -- "
+                                                          "every validation circle a different scenario, drawn with "
+                                                          "--circle-seed (keep it apart from the seeds the final evaluation uses)")
+    ap.add_argument("--circle-seed", type=int, default=900001)
+    ap.add_argument("--update-path", default="fused", choices=["fused", "stock"],
+                    help="PPO update through the HIP forward / backward kernels of the conv front end (fused) or MIOpen (stock)")
     ap.add_argument("--circle-ticks", type=int, default=1500)
     ap.add_argument("--max-seconds", type=float, default=0.0, help="stop after this much wall time (0 = no limit)")
     ap.add_argument("--kl-stop", type=float, default=0.0, help="abandon an update when a minibatch's KL exceeds this x kl-target")
@@ -127,17 +133,11 @@ def main(argv=None):
         hp.logstd_min = a.logstd_min
     hp.rollout_fused = not a.stock_policy_path and not a.bf16_inference
     hp.graph_tick = bool(a.graph) and not a.no_graph
+    hp.update_fused = a.update_path == "fused" and not a.bf16_update and torch.cuda.is_available()
     if a.bf16_update:
         hp.update_dtype = torch.bfloat16
     if a.bf16_inference:
         hp.inference_dtype = torch.bfloat16
-    if a.batch_size:
-        hp.batch_size = a.batch_size
-    elif sc.num_robots > 64:
-        # the reference's 1024 / 512 assume 24 / 44 robots (3 / 6 minibatches per epoch).  Minibatches are drawn
-        # from THIS rank's T*N rows, so the per-rank batch does not depend on the world size: 32 minibatches per
-        # epoch per rank; the global batch of one optimiser step is world_size x this.
-        hp.batch_size = max(hp.batch_size, sc.num_robots * hp.horizon // 32)
     env = VecStageWorld(sc)
     if a.mix_circle > 0 or a.mix_circles:
         from .multi_env import ConcatEnv
@@ -151,6 +151,13 @@ def main(argv=None):
         env = ConcatEnv(parts)
         out.info("training mix: %d robots of %s + %d robots in circle worlds (%s)", sc.num_robots, sc.name,
                  env.N - sc.num_robots, ", ".join("%d x %d robots" % (p.W, p.R) for p in parts[1:]))
+    if a.batch_size:
+        hp.batch_size = a.batch_size
+    elif env.N > 64:
+        # the reference's 1024 / 512 assume 24 / 44 robots (3 / 6 minibatches per epoch).  Minibatches are drawn
+        # from THIS rank's T*N rows (ALL robots of the training mix), so the per-rank batch does not depend on the
+        # world size: 32 minibatches per epoch per rank; the global batch of one optimiser step is world_size x this.
+        hp.batch_size = max(hp.batch_size, env.N * hp.horizon // 32)
     tr = Stage1Trainer(env, hp=hp, dist=dist, seed=a.seed, stage2=(a.stage == 2))
     out.info("per-rank minibatch %d rows, global batch per optimiser step %d, lr %g, epochs %d, horizon %d",
              hp.batch_size, hp.batch_size * world_size, hp.learning_rate, hp.epoch, hp.horizon)
@@ -163,6 +170,11 @@ def main(argv=None):
         if os.path.exists(st) and not a.init:
             extra = torch.load(st, map_location=env.device)
             tr.optimizer.load_state_dict(extra["optimizer"])
+            if a.lr is not None:        # an explicit --lr wins over the (possibly KL-adapted) rate of the saved optimizer
+                for grp in tr.optimizer.param_groups:
+                    grp["lr"] = a.lr
+            else:
+                out.info("resuming with the saved learning rate %g", tr.optimizer.param_groups[0]["lr"])
             tr.global_update = extra["global_update"]
             gens = extra.get("generators") or [extra["generator"]]
             if rank < len(gens):
@@ -253,7 +265,9 @@ def main(argv=None):
                     circle_env.append((spec, VecStageWorld(sc_c)))
             scores = []
             for spec, ce in circle_env:
-                m = evaluate.circle_test(ce, evaluate.cnn_policy_fn(tr.policy), a.circle_ticks)
+                m = evaluate.circle_test(ce, evaluate.cnn_policy_fn(tr.policy), a.circle_ticks,
+                                         perturb=tuple(float(v) for v in a.circle_perturb.split(",")) if a.circle_perturb else None,
+                                         seed=a.circle_seed)
                 scores.append(m["success_rate"])
                 out.info("circle %05d  [%s]  success %.3f  crash %.3f  unfinished %.3f  ticks %d", tr.global_update, spec,
                          m["success_rate"], m["crash_rate"], m["unfinished_rate"], m["ticks_run"])

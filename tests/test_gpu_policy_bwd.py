@@ -106,8 +106,11 @@ def test_backward_one_hot_probes():
 
 
 def test_policy_gradients_with_the_hip_front_end_equal_the_stock_gradients():
-    """evaluate_actions -> PPO-like loss -> backward, once through the stock layers and once through
-    lidar_features_fn: every parameter's gradient agrees."""
+    """evaluate_actions -> PPO-like loss -> backward, through the stock layers (MIOpen), through lidar_features_fn, and
+    in float64 on the CPU: the two fp32 device results differ from each other by summation order only -- each must be
+    as close to the float64 gradient as the other is (5e-4 of the tensor's largest entry at most; the conv1 gradients
+    are sums of 2048 x 255 products of magnitude 1e-7)."""
+    import copy
     from mrca.net import CNNPolicy
     torch.manual_seed(5)
     pol = CNNPolicy(3, 2).cuda()
@@ -122,16 +125,29 @@ def test_policy_gradients_with_the_hip_front_end_equal_the_stock_gradients():
     act = torch.rand(n, 2, device="cuda", generator=g)
     adv = torch.randn(n, 1, device="cuda", generator=g)
     tgt = torch.randn(n, 1, device="cuda", generator=g)
-    grads = []
-    for fused in (False, True):
-        pol.fused_train = fused
-        pol.zero_grad()
-        v, lp, ent = pol.evaluate_actions(x, goal, speed, act)
-        loss = -(torch.exp(lp) * adv).mean() + 20.0 * F.mse_loss(v, tgt) - 5e-4 * ent
+
+    def grads_of(p, args):
+        p.zero_grad()
+        v, lp, ent = p.evaluate_actions(*args[:4])
+        loss = -(torch.exp(lp) * args[4]).mean() + 20.0 * F.mse_loss(v, args[5]) - 5e-4 * ent
         loss.backward()
-        grads.append({k: p.grad.clone() for k, p in pol.named_parameters()})
-    for k in grads[0]:
-        a, b = grads[0][k], grads[1][k]
-        scale = float(a.abs().max())
-        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-9, (k, float((a - b).abs().max()), scale)
-    assert float(grads[1]["act_fea_cv1.weight"].abs().max()) > 0 and float(grads[1]["crt_fea_cv2.bias"].abs().max()) > 0
+        return {k: q.grad.detach().double().cpu() for k, q in p.named_parameters()}
+
+    args = (x, goal, speed, act, adv, tgt)
+    pol.fused_train = False
+    stock = grads_of(pol, args)
+    pol.fused_train = True
+    fused = grads_of(pol, args)
+    ref_pol = copy.deepcopy(pol).cpu().double()
+    ref_pol.fused_train = False
+    ref = grads_of(ref_pol, tuple(a.cpu().double() for a in args))
+    worst = {}
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        e_f, e_s = float((fused[k] - ref[k]).abs().max()) / scale, float((stock[k] - ref[k]).abs().max()) / scale
+        worst[k] = (e_f, e_s)
+        assert e_f <= 5e-4, (k, e_f, e_s)
+        assert e_s <= 5e-4, (k, e_f, e_s)
+    print("relative error vs float64 (fused, stock):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in worst.items()
+                                                         if "fea_cv" in k})
+    assert float(fused["act_fea_cv1.weight"].abs().max()) > 0 and float(fused["crt_fea_cv2.bias"].abs().max()) > 0
