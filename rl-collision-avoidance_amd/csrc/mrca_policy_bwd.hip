@@ -372,24 +372,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
 
 // out[t][k] = sum over the waves of tower t (gwave & 1 == t) in a FIXED order: a block owns 64 consecutive outputs of one
 // tower; its 16 wavefronts each add every 16th wave's partial (coalesced 256-byte rows), then the 16 sums are added in
-// index order.
+// index order.  The partials of a weight gradient cancel heavily (|sum| << sum of |terms|), so they are added in float64:
+// 3.7 M additions, and the result carries the rounding of the per-wave fp32 MFMA chains only.
 constexpr int kFinGroups = 16;
 __global__ __launch_bounds__(64 * kFinGroups) void lidar_features_bwd_finalize(
     const float* __restrict__ partial, int nwaves, float* __restrict__ dw1, float* __restrict__ db1,
     float* __restrict__ dw2, float* __restrict__ db2) {
-    __shared__ float part[kFinGroups][64];
+    __shared__ double part[kFinGroups][64];
     const int j = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int chunks = (kPartFloats + 63) / 64;
     const int t = blockIdx.x / chunks, k = (blockIdx.x % chunks) * 64 + j;
-    float s = 0.0f;
+    double s = 0.0;
     if (k < kPartFloats)
-        for (int w = t + 2 * grp; w < nwaves; w += 2 * kFinGroups) s += partial[(size_t)w * kPartFloats + k];
+        for (int w = t + 2 * grp; w < nwaves; w += 2 * kFinGroups) s += (double)partial[(size_t)w * kPartFloats + k];
     part[grp][j] = s;
     __syncthreads();
     if (grp != 0 || k >= kPartFloats) return;
-    float tot = 0.0f;
+    double acc = 0.0;
 #pragma unroll
-    for (int gidx = 0; gidx < kFinGroups; ++gidx) tot += part[gidx][j];
+    for (int gidx = 0; gidx < kFinGroups; ++gidx) acc += part[gidx][j];
+    const float tot = (float)acc;
     if (k < kPartDw1) dw2[t * 3072 + k] = tot;
     else if (k < kPartDb1) dw1[t * 480 + (k - kPartDw1)] = tot;
     else if (k < kPartDb2) db1[t * 32 + (k - kPartDb1)] = tot;

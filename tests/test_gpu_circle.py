@@ -77,6 +77,36 @@ def test_trained_checkpoint_solves_the_circle_test():
     env.close()
 
 
+@pytest.mark.parametrize("stage_resolution", [False, True])
+def test_success_rate_under_perturbed_starts_every_circle_size(stage_resolution):
+    """The success rate as a MEASUREMENT: every circle starts from its own Philox-jittered poses (+-0.2 m, +-0.1 rad;
+    evaluate.perturbed_start), so 40 circles are 40 different scenarios -- not 40 copies of one perfectly symmetric,
+    deterministic one, on which a policy scores 0 or 1.  Sizes 10 / 20 / 30 / 40 / 50 robots, default maps and the
+    fidelity mode (Stage's own cell size).  The seed used here was never seen in training or checkpoint selection
+    (both used the unperturbed table).  Bar: the lower end of the 95 % interval of the mean success rate >= 0.95 for
+    every size (measured with 200 circles each: 0.997 .. 1.000, profiles/r03_c_circle_eval_perturbed_*.jsonl)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    from mrca import evaluate
+    from mrca.vec_env import VecStageWorld
+    pol = _trained_policy()
+    for robots, radius in ((10, 8.0), (20, 12.0), (30, 16.0), (40, 20.0), (50, 25.0)):
+        if robots == 50:
+            sc = S.circle(num_worlds=40, seed=0, stage_resolution=stage_resolution)
+        else:
+            sc = S.circle_n(robots, radius, num_worlds=40, seed=0,
+                            grid=S.load_map("circle_rink_r0010") if stage_resolution else None)
+        env = VecStageWorld(sc, device="cuda:0")
+        m = evaluate.circle_test(env, evaluate.cnn_policy_fn(pol), max_ticks=2000, perturb=(0.2, 0.1), seed=4242)
+        env.close()
+        assert m["circles"] == 40
+        lo, hi = m["success_rate_ci95"]
+        assert lo >= 0.95, (robots, stage_resolution, m["success_rate"], lo, hi, m["crash_rate"])
+        assert m["success_rate"] >= 0.98, (robots, stage_resolution, m)
+
+
 def test_second_checkpoint_on_circles_of_every_size():
     """mrca/data/policy_r02_all_circle_sizes.pth (profiles/r02_h_*): circles of 10 ... 50 robots, 20 circles each."""
     if not torch.cuda.is_available():
