@@ -13,6 +13,7 @@
 #   prof_rollout     rocprofv3 --kernel-trace --stats of bench.py --mode rollout --no-graph
 #   sq               tools/pmc_profile.sh (SQ counter sets of the env kernels)
 #   bigworld         tools/bigworld_bench.py
+#   prof_bigworld    rocprofv3 --kernel-trace --stats of tools/bigworld_bench.py (BIGWORLD_ARGS: robot counts)
 #   circle           mrca.evaluate of the committed checkpoints (POLICY=... overrides)
 #   train            tools/train_recipe.sh (TRAIN_ARGS / S1_SECONDS / S2_SECONDS)
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -73,6 +74,12 @@ for STAGE in "$@"; do
       grep -E "raycast|move_kernel" "$O/pmc_sq_summary.txt" | head -60 | cut -c1-200 ;;
     bigworld)
       timeout 900 python tools/bigworld_bench.py ${BIGWORLD_ARGS:-} 2>&1 | flt | tee "$O/bigworld.jsonl" | cut -c1-300 ;;
+    prof_bigworld)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bw" -o trace -- python "$R/tools/bigworld_bench.py" ${BIGWORLD_ARGS:-50000} > "$O/prof_bigworld.log" 2>&1; echo "rc=$?"
+      cd "$R"; flt < "$O/prof_bigworld.log" | tail -4 | cut -c1-300
+      f=$(find "$O/prof_bw" -name "trace_kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f" | cut -c1-200 && cp "$f" "$O/bigworld_kernel_stats.csv"
+      rm -rf "$O/prof_bw" ;;
     circle)
       for P in ${POLICY:-$R/rl-collision-avoidance_amd/mrca/data/policy_r02_stage2_circles.pth $R/rl-collision-avoidance_amd/mrca/data/policy_r02_all_circle_sizes.pth}; do
         for SPEC in "10 8" "20 12" "30 16" "40 20" "50 25"; do set -- $SPEC
