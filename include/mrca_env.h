@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MRCA_ABI_VERSION 2
+#define MRCA_ABI_VERSION 3
 
 typedef struct mrca_env mrca_env; /* opaque */
 
@@ -70,7 +70,9 @@ enum mrca_field {
     MRCA_F_GOAL,          /* f32 [N,2]   env.goal_point     stage_world1.py:173                                          */
     MRCA_F_INIT_POSE,     /* f32 [N,3]   env.init_pose      stage_world1.py:263                                          */
     MRCA_F_SCAN,          /* f32 [N,B]   base_scan ranges   stageros.cpp:479-516                                         */
-    MRCA_F_OBS,           /* f32 [N,F,B] get_laser_observation x frame deque  stage_world1.py:122-140, ppo_stage1.py:59-60,87-89 */
+    MRCA_F_OBS,           /* f32 [N,F,B] get_laser_observation x frame deque  stage_world1.py:122-140, ppo_stage1.py:59-60,87-89
+                           *             a COPY of MRCA_F_OBS_RING in deque order (oldest frame first): current after every
+                           *             call with lazy_obs = 0, otherwise after mrca_materialize_obs() */
     MRCA_F_LOCAL_GOAL,    /* f32 [N,2]   get_local_goal     stage_world1.py:155-160                                      */
     MRCA_F_REWARD,        /* f32 [N]     get_reward_and_terminate[0]  stage_world1.py:180-211                            */
     MRCA_F_DONE,          /* u8  [N]     get_reward_and_terminate[1]                                                     */
@@ -82,6 +84,9 @@ enum mrca_field {
     MRCA_F_T,             /* i32 [N]     the `step` argument of get_reward_and_terminate (ppo_stage1.py:57,118)          */
     MRCA_F_EPISODE,       /* i32 [N]     episode counter (RNG stream position)                                          */
     MRCA_F_PREV_DIST,     /* f32 [N]     self.distance      stage_world1.py:176-177,185-186                              */
+    MRCA_F_OBS_RING,      /* f32 [N,F,B] the same frame deque stored as a ring (ABI 3): a tick writes ONE frame per robot,
+                           *             logical frame f (0 = oldest) of robot n is slot (head[n] + 1 + f) mod F */
+    MRCA_F_OBS_HEAD,      /* u8  [N]     slot of robot n's newest frame in MRCA_F_OBS_RING                                */
     MRCA_F_COUNT
 };
 
@@ -112,6 +117,10 @@ typedef struct mrca_config {
      * res > 0 [m] = Stage's rule on a raster of `res` metres (worlds/stage1.world:3: 0.2): robots collide when their
      * OUTLINES SHARE A RASTER CELL, i.e. up to one cell apart.  res >= 0.1; not with robots_per_world > 64. */
     float collision_raster;
+    /* ABI 3.  0: MRCA_F_OBS (deque order) is brought up to date by every mrca_reset / mrca_step -- one extra copy of the
+     * stack per call, what a caller written against ABI 2 expects.  1: only mrca_materialize_obs() does that; callers
+     * that read MRCA_F_OBS_RING + MRCA_F_OBS_HEAD (mrca_lidar_features does) never pay for it. */
+    int32_t lazy_obs;
 } mrca_config;
 
 /* Bytes of device arena an env with this config needs (256-byte granules). */
@@ -145,6 +154,16 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
  * [first_robot, first_robot + num_robots): scan / obs / local_goal of the other robots are left untouched. */
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream);
 
+/* MRCA_F_OBS := the ring in deque order, for all robots (asynchronous on `stream`).  Needed only with lazy_obs = 1. */
+int mrca_materialize_obs(mrca_env* env, void* stream);
+
+/* Synchronises `stream` and reports (then clears) the env's sticky device-side status word: MRCA_OK, or MRCA_ERR_HIP with
+ * mrca_last_error() saying what went wrong on the device since the last check.  Today one condition: the ordered
+ * collision pass of a world with more than 64 robots ran out of its (very long) bounded wait and left a robot
+ * undecided.  mrca_step itself never synchronises; call this wherever a host round trip is acceptable (end of an
+ * evaluation, once per PPO update). */
+int mrca_check(mrca_env* env, void* stream);
+
 /* Zero-copy access to a field: device pointer, byte offset inside the arena and byte size. */
 int mrca_get_field(mrca_env* env, int field, void** ptr_dev_out, size_t* offset_out, size_t* bytes_out);
 
@@ -167,13 +186,16 @@ int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, i
 /* Rollout-path front end of the lidar actor-critic (model/net.py:19-25,37-49,57-69: Conv1d(3,32,k5,s2,p1) -> ReLU ->
  * Conv1d(32,32,k3,s2,p1) -> ReLU for the actor and the critic tower), fused into one kernel: fp32 in, fp32 MFMA
  * accumulate, the 32 x 255 intermediate never leaves the CU.
- *   obs_dev  f32[N,3,512]   the env's observation stack (field MRCA_F_OBS)
+ *   obs_dev  f32[N,3,512]   the observation stacks: MRCA_F_OBS (deque order) with obs_head_dev = NULL, or
+ *                           MRCA_F_OBS_RING with obs_head_dev = MRCA_F_OBS_HEAD (u8[N]): the kernel then reads frame f
+ *                           of robot n from slot (head[n] + 1 + f) mod 3 while staging
  *   w1_dev   f32[2,32,3,5]  b1_dev f32[2,32]    act_fea_cv1 / crt_fea_cv1 weight and bias, tower-major
  *   w2_dev   f32[2,32,32,3] b2_dev f32[2,32]    act_fea_cv2 / crt_fea_cv2
  *   feat_dev f32[2,N,4096]  out: tower-major, each row in the flatten order of [32,128] (what act_fc1 / crt_fc1 eat)
  * frames must be 3 and beams 512 (MRCA_ERR_UNSUPPORTED otherwise). */
-int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams, const float* w1_dev,
-                        const float* b1_dev, const float* w2_dev, const float* b2_dev, float* feat_dev, void* stream);
+int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t n_robots, int32_t frames, int32_t beams,
+                        const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
+                        float* feat_dev, void* stream);
 
 /* Backward pass of the same front end for the PPO update (model/ppo.py:158-192 back-propagates the loss through
  * act_fea_cv1/2 and crt_fea_cv1/2 of model/net.py:19-25 for every minibatch): given the gradient with respect to the
@@ -197,7 +219,7 @@ int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product
  * library neither exports this symbol nor contains the switches.  Results are WRONG while any of bits 0-5 is
  * set: 1 = skip robot-robot lidar tests, 2 = skip the grid march, 8 / 16 / 32 = move kernel without its outline
- * test / collision loop / resets.  Launch-shape knobs (results unchanged): bit 6: the frame-stack shift as a launch of its own;
+ * test / collision loop / resets.  Launch-shape knobs (results unchanged):
  * bits 8-10 = k > 0: 1 << (k-1) beams per marching thread; bit 11: a dedicated preparation wave; bit 12: the beams of a
  * thread marched in lock step.  0 restores the product path. */
 int mrca_set_debug_flags(mrca_env* env, int32_t flags);

@@ -50,7 +50,8 @@ struct Layout {
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
     size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield, off_head;
     // big worlds (robots_per_world > 64) only
-    size_t off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted;
+    size_t off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted, off_bw_lblock;
+    size_t off_status;
     int32_t bw_cmask, bw_lmask;
     size_t total;
 };
@@ -125,6 +126,8 @@ void make_layout(const mrca_config* c, Layout* L) {
     sz[MRCA_F_T] = N * 4;
     sz[MRCA_F_EPISODE] = N * 4;
     sz[MRCA_F_PREV_DIST] = N * 4;
+    sz[MRCA_F_OBS_RING] = N * F * B * 4;
+    sz[MRCA_F_OBS_HEAD] = N;
     size_t off = 0;
     for (int f = 0; f < MRCA_F_COUNT; ++f) {
         L->field_off[f] = off;
@@ -162,7 +165,9 @@ void make_layout(const mrca_config* c, Layout* L) {
         L->off_bw_lstart = take((ml + 2) * 4);
         L->off_bw_lcount = take((ml + 1) * 4);
         L->off_bw_lsorted = take(N * 4);
+        L->off_bw_lblock = take((ml / 1024 + 2) * 4);
     }
+    L->off_status = take(4);
     L->total = off;
 }
 
@@ -341,6 +346,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.init_pose = reinterpret_cast<float*>(a + L.field_off[MRCA_F_INIT_POSE]);
     v.scan = reinterpret_cast<float*>(a + L.field_off[MRCA_F_SCAN]);
     v.obs = reinterpret_cast<float*>(a + L.field_off[MRCA_F_OBS]);
+    v.obs_ring = reinterpret_cast<float*>(a + L.field_off[MRCA_F_OBS_RING]);
+    v.obs_head = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_OBS_HEAD]);
     v.local_goal = reinterpret_cast<float*>(a + L.field_off[MRCA_F_LOCAL_GOAL]);
     v.reward = reinterpret_cast<float*>(a + L.field_off[MRCA_F_REWARD]);
     v.prev_dist = reinterpret_cast<float*>(a + L.field_off[MRCA_F_PREV_DIST]);
@@ -373,9 +380,11 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
         v.bw_lstart = reinterpret_cast<int32_t*>(a + L.off_bw_lstart);
         v.bw_lcount = reinterpret_cast<int32_t*>(a + L.off_bw_lcount);
         v.bw_lsorted = reinterpret_cast<int32_t*>(a + L.off_bw_lsorted);
+        v.bw_lblock = reinterpret_cast<int32_t*>(a + L.off_bw_lblock);
         v.bw_cmask = L.bw_cmask;
         v.bw_lmask = L.bw_lmask;
     }
+    v.status = reinterpret_cast<uint32_t*>(a + L.off_status);
     v.ray_first = 0;
     v.ray_count = (int32_t)N;
     v.g.x0 = cfg->map_x0;
@@ -450,6 +459,15 @@ int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, c
     mrca::launch_reset(env->view, mask_dev, poses_dev, goals_dev, s);
     mrca::launch_lidar_grid(env->view, s);
     mrca::launch_raycast(env->view, /*only_fresh=*/1, s);
+    if (!env->cfg.lazy_obs) mrca::launch_materialize_obs(env->view, s);
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
+int mrca_materialize_obs(mrca_env* env, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    DeviceGuard guard(env->cfg.device);
+    mrca::launch_materialize_obs(env->view, static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return MRCA_OK;
 }
@@ -471,6 +489,7 @@ static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int
     mrca::launch_lidar_grid(v, s);
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
     mrca::launch_raycast(v, /*only_fresh=*/0, s);
+    if (!env->cfg.lazy_obs) mrca::launch_materialize_obs(v, s);   // (inside the ray cast's event pair: it is part of the tick then)
     if (rec) {
         HIP_TRY(hipEventRecord(env->ev[env->ev_used + 2], s));
         env->ev_used += 3;
@@ -485,6 +504,22 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream) {
 
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream) {
     return step_impl(env, actions_dev, first_robot, num_robots, stream);
+}
+
+int mrca_check(mrca_env* env, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    DeviceGuard guard(env->cfg.device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, env->view.status, sizeof(bits), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bits == 0) return MRCA_OK;
+    HIP_TRY(hipMemsetAsync(env->view.status, 0, sizeof(bits), s));
+    if (bits & mrca::kStatusCollideUndecided)
+        return fail(MRCA_ERR_HIP, "collision pass of a world with more than 64 robots gave up waiting for a lower-indexed "
+                                  "robot (workgroups not dispatched in index order?): at least one robot was left "
+                                  "undecided since the last check; the env's state is not to be trusted");
+    return fail(MRCA_ERR_HIP, "device status word 0x%x", bits);
 }
 
 int mrca_gae(const float* rewards_dev, const float* values_dev, const float* last_value_dev,
@@ -514,7 +549,7 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 
 #if defined(MRCA_PROFILING)
 // Profiling build only (libmrca_env_prof.so): ablation switches (results are WRONG while bits 0-5 are set) and
-// launch-shape knobs (results unchanged): bit 6: the frame-stack shift as a launch of its own; bits 8-10 = k > 0:
+// launch-shape knobs (results unchanged): bits 8-10 = k > 0:
 // 1 << (k-1) beams per marching thread; bit 11: a dedicated fifth preparation wave; bit 12: the beams of a thread marched
 // in lock step instead of one after the other.
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {

@@ -18,7 +18,9 @@ struct EnvView {
     float* goal;        // [N,2]
     float* init_pose;   // [N,3]
     float* scan;        // [N,B]
-    float* obs;         // [N,F,B]
+    float* obs;         // [N,F,B] the frame stack in deque order -- a COPY of obs_ring, made by materialize_obs_kernel
+    float* obs_ring;    // [N,F,B] the frame stack as a ring: slot obs_head[n] holds robot n's newest frame
+    uint8_t* obs_head;  // [N]
     float* local_goal;  // [N,2]
     float* reward;      // [N]
     float* prev_dist;   // [N]
@@ -45,6 +47,7 @@ struct EnvView {
     int32_t* bw_lstart;     // [bw_lmask+2] lidar hash (6.5 m cells) over the FINAL poses: bucket -> first slot
     int32_t* bw_lcount;     // [bw_lmask+1] bucket population / fill cursor
     int32_t* bw_lsorted;    // [N] robots ordered by bucket
+    int32_t* bw_lblock;     // [(bw_lmask+1)/1024 + 1] totals / offsets of the scan's 1024-bucket blocks
     int32_t bw_lmask;
     int32_t ray_first, ray_count;   // the ray cast covers robots [ray_first, ray_first + ray_count) (mrca_step_slice)
     // scenario tables, per local index
@@ -76,7 +79,11 @@ struct EnvView {
     int32_t ray_sequential; // 1 (with ray_shift 1): the two beams of a thread are marched one after the other
     int32_t ray_prep_wave;  // 1: a dedicated wave prepares the neighbour list (blockDim = beams >> ray_shift + 64)
     int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
+    uint32_t* status;     // [1] sticky device-side error bits (kStatus*), read and cleared by mrca_check()
 };
+
+// bits of EnvView::status
+constexpr uint32_t kStatusCollideUndecided = 1u;   // bw_collide_kernel gave up waiting for a lower-indexed robot
 
 // Ablation switches exist only in the profiling build of the library (csrc/build.sh --profiling ->
 // libmrca_env_prof.so, used by tools/ablate.py); in the product they fold to `false` at compile time.
@@ -94,6 +101,7 @@ void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, con
 void launch_head_init(const EnvView& e, hipStream_t s);
 void launch_lidar_grid(const EnvView& e, hipStream_t s);   // big worlds: hash of the current poses for the ray cast
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
+void launch_materialize_obs(const EnvView& e, hipStream_t s);   // obs_ring -> obs for robots [ray_first, ray_first + ray_count)
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
                 float lam, int T, int N, float* targets, float* advs, hipStream_t s);
 

@@ -9,8 +9,6 @@
 //                  lane runs the rectangle SAT against the pose it has at that point of the
 //                  order, a wavefront ballot decides revert+stall.  Reward / terminal / episode
 //                  bookkeeping (wave-parallel Philox resets, group ballots) follow.
-//                  The copy blocks of the tick's frame-stack shift ride behind the per-world blocks in the
-//                  same launch (shift_frames).
 //   raycast_kernel one workgroup per robot, beams/K threads, K beams per thread (product: K = 2, marched one
 //                  after the other; the lock-step form and a dedicated preparation wave are measured variants).
 //                  The first wave compacts the other robots of the world within lidar reach into LDS (ballot +
@@ -19,7 +17,8 @@
 //                  L2 lookups per ray).  The robot's own sin/cos and the field entry of its cell come from the
 //                  16-byte `head` record the move kernel published (scalar loads), so no wave recomputes them.
 //                  Each thread slab-tests its own beams against the flagged neighbours and stores their scan
-//                  value and newest observation frame itself.
+//                  value and newest observation frame itself -- the frame stack is a ring (one slot per tick, no shift).
+//   materialize_obs_kernel  the ring in deque order (MRCA_F_OBS), on demand.
 //   bw_*           the move kernel's tick for worlds with more than 64 robots (per-robot threads, spatial
 //                  hashes, ordered collision pass as dependency rounds); raycast_kernel<K, true> is its ray cast.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
@@ -132,63 +131,39 @@ struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
     }
 };
 
-// The frame-stack shift of the tick (ppo_stage1.py:87-89: popleft / append), frames 1.. -> 0.. for robots
-// [ray_first, ray_first + ray_count): two thirds of the observation traffic of a tick (33 MB at 4096 robots) and
-// independent of everything the tick computes -- a robot that restarts this tick gets all its frames rewritten by the
-// ray cast afterwards.  It therefore rides in the SAME launch as move_kernel (blocks behind the per-world ones):
-// the move kernel is one latency chain per world on 128 of 1024 SIMDs, and the copy streams through the rest of the
-// chip underneath it.  (Measured before, when the ray cast did the shift itself: the kernel's memory phase did not
-// overlap its own compute phase, 14 us of 33.)  A thread owns float4 columns: it loads them from every frame, then
-// stores them one frame down, so reads and writes of different threads never meet.
-__device__ __forceinline__ void shift_frames(const EnvView& e, int block, int nblocks, int tid, int nthreads) {
+// The observation stack (ppo_stage1.py:59-60,87-89: a deque of the last F normalised scans) is stored as a RING per
+// robot: obs_ring[n][slot][beam] with obs_head[n] = the slot of the NEWEST frame; logical frame f (0 = oldest) sits in
+// slot (head + 1 + f) mod F.  A tick writes ONE frame per robot (the ray cast's epilogue) and bumps the head; rounds 1-2
+// shifted the whole stack down every tick instead -- 33.6 of the tick's 56.6 MB of HBM traffic at 4096 robots.
+// Consumers that want the deque order (MRCA_F_OBS) get it from this copy kernel, on demand (mrca_materialize_obs) or
+// after every call when the env was created with lazy_obs = 0; the policy's front end reads the ring directly.
+// A thread owns float4 columns of robots [ray_first, ray_first + ray_count).
+__global__ void materialize_obs_kernel(EnvView e) {
     const int fstride = e.B >> 2;
     const long long total = (long long)e.ray_count * fstride;
-    float4* base = reinterpret_cast<float4*>(e.obs) + (size_t)e.ray_first * e.F * fstride;
-    if (e.F == 3) {
-        // four columns in flight per thread (strided by the launch width, so every load instruction is coalesced)
-        const long long stride = (long long)nblocks * nthreads;
-        for (long long k0 = (long long)block * nthreads + tid; k0 < total; k0 += 4 * stride) {
-            const long long ka = k0, kb = k0 + stride, kc = k0 + 2 * stride, kd = k0 + 3 * stride;
-            const bool hb = kb < total, hc = kc < total, hd = kd < total;
-            float4* oa = base + (ka / fstride) * 3 * fstride + (ka % fstride);
-            float4* ob = base + ((hb ? kb : ka) / fstride) * 3 * fstride + ((hb ? kb : ka) % fstride);
-            float4* oc = base + ((hc ? kc : ka) / fstride) * 3 * fstride + ((hc ? kc : ka) % fstride);
-            float4* od = base + ((hd ? kd : ka) / fstride) * 3 * fstride + ((hd ? kd : ka) % fstride);
-            const float4 a1 = oa[fstride], a2 = oa[2 * fstride];
-            const float4 b1 = ob[fstride], b2 = ob[2 * fstride];
-            const float4 c1 = oc[fstride], c2 = oc[2 * fstride];
-            const float4 d1 = od[fstride], d2 = od[2 * fstride];
-            oa[0] = a1;
-            oa[fstride] = a2;
-            if (hb) {
-                ob[0] = b1;
-                ob[fstride] = b2;
-            }
-            if (hc) {
-                oc[0] = c1;
-                oc[fstride] = c2;
-            }
-            if (hd) {
-                od[0] = d1;
-                od[fstride] = d2;
-            }
-        }
-    } else {
-        for (long long k = (long long)block * nthreads + tid; k < total; k += (long long)nblocks * nthreads) {
-            float4* ob = base + (k / fstride) * e.F * fstride + (k % fstride);
-            for (int f = 0; f + 1 < e.F; ++f) ob[f * fstride] = ob[(f + 1) * fstride];
+    const float4* ring = reinterpret_cast<const float4*>(e.obs_ring) + (size_t)e.ray_first * e.F * fstride;
+    float4* out = reinterpret_cast<float4*>(e.obs) + (size_t)e.ray_first * e.F * fstride;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        const long long r = k / fstride;
+        const int col = (int)(k - r * fstride);
+        const int hd = e.obs_head[e.ray_first + r];
+        const float4* src = ring + r * e.F * fstride + col;
+        float4* dst = out + r * e.F * fstride + col;
+        if (e.F == 3) {
+            const int s0 = hd == 2 ? 0 : hd + 1, s1 = s0 == 2 ? 0 : s0 + 1;
+            const float4 a = src[s0 * fstride], b = src[s1 * fstride], c = src[hd * fstride];
+            dst[0] = a;
+            dst[fstride] = b;
+            dst[2 * fstride] = c;
+        } else {
+            for (int f = 0; f < e.F; ++f) dst[f * fstride] = src[((hd + 1 + f) % e.F) * fstride];
         }
     }
 }
 
-__global__ void shift_frames_kernel(EnvView e) { shift_frames(e, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x); }
-
 __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
-    if ((int)blockIdx.x >= e.W) {   // the blocks behind the per-world ones: this tick's frame-stack shift
-        shift_frames(e, blockIdx.x - e.W, gridDim.x - e.W, threadIdx.x, kWave);
-        return;
-    }
     const int world = blockIdx.x;
     const int lane = threadIdx.x;
     const bool valid = lane < e.R;
@@ -584,6 +559,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
 
     const bool fresh = ((fresh_word >> ((n & 3) * 8)) & 0xFFu) != 0;
     if (only_fresh && !fresh) return;  // block-uniform
+    // slot of the newest frame so far; read by every thread BEFORE the first barrier, advanced by thread 0 after it
+    const int obs_slot = e.obs_head[n];
 
     float4* nb = reinterpret_cast<float4*>(lds);
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
@@ -621,8 +598,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         bc[k] = e.beam_cos[b];
         bs[k] = e.beam_sin[b];
     }
-    // (The frame-stack shift -- ppo_stage1.py:87-89: popleft / append -- does not depend on this tick's ranges: it ran
-    // before this kernel, next to the move kernel, see shift_frames.  Here only the newest frame is appended.)
+    // (The frame stack -- ppo_stage1.py:87-89: popleft / append -- is a ring: only the newest frame is written, into
+    // the slot behind the previous newest one; see materialize_obs_kernel.)
     // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
     // exceed the 64 a chunk holds: the preparation wave walks the nine bucket ranges 64 entries at a time and hands
     // the marching threads one chunk of <= 64 neighbours per barrier pair (see the chunk loop below)
@@ -767,19 +744,21 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     //     bytes each: one more barrier and an LDS round trip for the same two cache lines per wave.)
     {
         float* scan_row = e.scan + (size_t)n * e.B;
-        float* obs_row = e.obs + (size_t)n * e.F * e.B;
+        float* obs_row = e.obs_ring + (size_t)n * e.F * e.B;
+        const int new_slot = obs_slot + 1 == e.F ? 0 : obs_slot + 1;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int b = tid + k * T;
             const float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
             const float o = norm_obs(r);
             scan_row[b] = r;
-            if (fresh) {
+            if (fresh) {     // deque([obs] * F), ppo_stage1.py:59-60: every slot, the head stays where it is
                 for (int f = 0; f < e.F; ++f) obs_row[f * e.B + b] = o;
             } else {
-                obs_row[(e.F - 1) * e.B + b] = o;      // the older frames were shifted down by shift_frames
+                obs_row[new_slot * e.B + b] = o;
             }
         }
+        if (tid == 0 && !fresh) e.obs_head[n] = (uint8_t)new_slot;
     }
     if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
         const float gx = e.goal[n * 2 + 0] - x, gy = e.goal[n * 2 + 1] - y;
@@ -800,9 +779,9 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
 //                 its provisional centre; anybody listed there within 2 x circumradius can matter.  i is decided once
 //                 every such lower-indexed moving robot is (their outcome tells which of their two poses counts);
 //                 then it runs the SAT tests and publishes its own outcome (release / acquire on bw_state).  The
-//                 lowest undecided robot never waits, so the loop terminates; workgroups are dispatched in index
-//                 order and only ever wait for lower indices, so a waiting wave never starves the one it waits for.
-//                 Robots with nobody in reach decide in their first round.
+//                 lowest undecided robot never waits, so the loop terminates as long as lower workgroups get to run
+//                 (see the kernel: in-order dispatch is observed, not guaranteed; a bounded wait that ends in a status
+//                 word, never in a silent wrong state).  Robots with nobody in reach decide in their first round.
 //   bw_finish     thread per robot: commit, GT velocity, reward / terminal, episode bookkeeping (per-robot resets),
 //                 head record.
 //   bw_lidar_*    counting sort of the FINAL poses into the lidar hash (6.5 m cells) the ray cast enumerates.
@@ -863,13 +842,27 @@ __global__ void bw_collide_kernel(EnvView e) {
     const float nx = p0.x, ny = p0.y, ns = p1.x, nc = p1.y;
     const int world = n / e.R;
     const int icx = hash_cell_coord(nx, kCollideCell), icy = hash_cell_coord(ny, kCollideCell);
-    for (int guard = 0; guard < (1 << 22); ++guard) {   // the guard only bounds a launch that could never finish
+    // the nine bucket heads are independent loads: all in flight at once (one dependent round trip instead of nine)
+    int head9[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+        head9[q] = e.bw_chead[hash_cell(icx + q % 3 - 1, icy + q / 3 - 1, world) & (uint32_t)e.bw_cmask];
+    // Dependency rounds.  A robot only ever waits for LOWER-indexed robots, and the lowest undecided robot of the
+    // launch never waits, so somebody can always make progress -- PROVIDED the waves holding those lower indices are
+    // resident or will become resident.  Workgroups are dispatched in index order on gfx950 (observed, not an
+    // architectural guarantee: MI355X_MICROARCH.md "Dispatch order ... undefined"), and a waiting wave sleeps, so in
+    // practice a lower workgroup is never starved.  Should that ever fail, the guard below ends the launch instead of
+    // hanging the GPU, the robot stays undecided (treated as not moved) and bit 0 of the env's status word is raised:
+    // mrca_check() turns it into MRCA_ERR_HIP -- never a silent wrong state.  The release store of the outcome sits
+    // inside the loop by construction (done-flag form), not by grace of the optimiser.
+    bool done = false;
+    for (int guard = 0; !done && guard < (1 << 22); ++guard) {
         bool ready = true;
         bool hit = (flags & kFlagStaticHit) != 0;
         if (!MRCA_DBG(e, 16)) {
-            for (int q = 0; q < 9 && ready; ++q) {
-                const uint32_t h = hash_cell(icx + q % 3 - 1, icy + q / 3 - 1, world) & (uint32_t)e.bw_cmask;
-                for (int en = e.bw_chead[h]; en >= 0 && ready; en = e.bw_cnext[en]) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                for (int en = head9[q]; en >= 0 && ready; en = e.bw_cnext[en]) {
                     const int j = en >> 1;
                     if (j == n || j / e.R != world) continue;
                     const float4 q0 = e.bw_prov[2 * j], q1 = e.bw_prov[2 * j + 1];
@@ -892,15 +885,18 @@ __global__ void bw_collide_kernel(EnvView e) {
                     hit = obb_overlap(nx, ny, ns, nc, at_new ? q0.x : ox, at_new ? q0.y : oy, at_new ? q1.x : hj.x,
                                       at_new ? q1.y : hj.y) || hit;
                 }
+                if (!ready) break;
             }
         }
         if (ready) {
             e.crashed[n] = hit ? 1 : 0;
             __hip_atomic_store(&e.bw_state[n], hit ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+            done = true;
+        } else {
+            __builtin_amdgcn_s_sleep(2);
         }
-        __builtin_amdgcn_s_sleep(2);
     }
+    if (!done) atomicOr(e.status, kStatusCollideUndecided);
 }
 
 __global__ void bw_finish_kernel(EnvView e) {
@@ -1019,31 +1015,57 @@ __global__ void bw_lidar_count_kernel(EnvView e) {
     atomicAdd(&e.bw_lcount[h], 1);
 }
 
-__global__ __launch_bounds__(1024) void bw_lidar_scan_kernel(EnvView e) {   // one workgroup: exclusive scan of the counts
-    __shared__ int part[1024];
-    const int M = e.bw_lmask + 1;
-    const int per = (M + 1023) / 1024;
-    const int b0 = threadIdx.x * per;
-    int sum = 0;
-    for (int k = 0; k < per; ++k)
-        if (b0 + k < M) sum += e.bw_lcount[b0 + k];
-    part[threadIdx.x] = sum;
+// Exclusive scan of the bucket populations in three small launches (a single workgroup walking all 2N buckets took
+// 296 us at 50 000 robots -- 70 % of the move phase, profiles/r03_d_bigworld_50000_kernel_stats.csv):
+//   scan_local   one workgroup per 1024 buckets: coalesced load, block scan, local prefix -> bw_lstart, total -> bw_lblock
+//   scan_blocks  one workgroup: exclusive scan of the <= 1024 x k block totals (in place), grand total -> bw_lstart[M]
+//   scan_apply   adds its block's offset; the counts become the fill cursors (zeroed)
+__device__ __forceinline__ int block_scan_1024(int v, int* part) {     // inclusive scan over the workgroup's 1024 threads
+    const int tid = threadIdx.x;
+    part[tid] = v;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        const int add = tid >= off ? part[tid - off] : 0;
         __syncthreads();
-        part[threadIdx.x] += add;
+        part[tid] += add;
         __syncthreads();
     }
-    int run = part[threadIdx.x] - sum;
-    for (int k = 0; k < per; ++k)
-        if (b0 + k < M) {
-            const int cnt = e.bw_lcount[b0 + k];
-            e.bw_lstart[b0 + k] = run;
-            e.bw_lcount[b0 + k] = 0;           // becomes the fill cursor
-            run += cnt;
-        }
-    if (threadIdx.x == 1023) e.bw_lstart[M] = part[1023];
+    return part[tid];
+}
+
+__global__ __launch_bounds__(1024) void bw_lidar_scan_local_kernel(EnvView e) {
+    __shared__ int part[1024];
+    const int M = e.bw_lmask + 1;
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    const int cnt = b < M ? e.bw_lcount[b] : 0;
+    const int incl = block_scan_1024(cnt, part);
+    if (b < M) {
+        e.bw_lstart[b] = incl - cnt;
+        e.bw_lcount[b] = 0;                 // becomes the fill cursor
+    }
+    if (threadIdx.x == 1023) e.bw_lblock[blockIdx.x] = incl;
+}
+
+__global__ __launch_bounds__(1024) void bw_lidar_scan_blocks_kernel(EnvView e) {
+    __shared__ int part[1024];
+    const int M = e.bw_lmask + 1;
+    const int nblk = (M + 1023) / 1024;
+    int run = 0;
+    for (int base = 0; base < nblk; base += 1024) {       // one pass up to 2^20 buckets
+        const int k = base + threadIdx.x;
+        const int v = k < nblk ? e.bw_lblock[k] : 0;
+        const int incl = block_scan_1024(v, part);
+        if (k < nblk) e.bw_lblock[k] = run + incl - v;
+        run += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) e.bw_lstart[M] = run;
+}
+
+__global__ __launch_bounds__(1024) void bw_lidar_scan_apply_kernel(EnvView e) {
+    const int M = e.bw_lmask + 1;
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    if (b < M) e.bw_lstart[b] += e.bw_lblock[blockIdx.x];
 }
 
 __global__ void bw_lidar_fill_kernel(EnvView e) {
@@ -1092,27 +1114,24 @@ size_t move_lds_bytes(const EnvView& e) {
 }
 
 // blocks of 64 threads x 4 float4 columns per pass for the frame-stack shift that rides behind the move kernel
-static int shift_blocks(const EnvView& e) {
-    const long long cols = (long long)e.ray_count * (e.B >> 2);
-    long long nb = (cols + kWave * 4 - 1) / (kWave * 4);
-    if (nb > 8192) nb = 8192;
-    return e.F > 1 ? (int)nb : 0;
-}
-
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
     if (!e.big) {
-        const int extra = MRCA_DBG(e, 64) ? 0 : shift_blocks(e);
-        hipLaunchKernelGGL(move_kernel, dim3(e.W + extra), dim3(kWave), move_lds_bytes(e), s, e, actions);
-        if (MRCA_DBG(e, 64) && shift_blocks(e) > 0)      // profiling: the shift as a launch of its own, after the move
-            hipLaunchKernelGGL(shift_frames_kernel, dim3(shift_blocks(e)), dim3(kWave), 0, s, e);
+        hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), move_lds_bytes(e), s, e, actions);
         return;
     }
     const int bs = 256, nb = (e.N + bs - 1) / bs;
-    if (shift_blocks(e) > 0) hipLaunchKernelGGL(shift_frames_kernel, dim3(shift_blocks(e)), dim3(kWave), 0, s, e);
     (void)hipMemsetAsync(e.bw_chead, 0xFF, sizeof(int32_t) * (size_t)(e.bw_cmask + 1), s);
     hipLaunchKernelGGL(bw_integrate_kernel, dim3(nb), dim3(bs), 0, s, e, actions);
     hipLaunchKernelGGL(bw_collide_kernel, dim3(nb), dim3(bs), 0, s, e);
     hipLaunchKernelGGL(bw_finish_kernel, dim3(nb), dim3(bs), 0, s, e);
+}
+
+void launch_materialize_obs(const EnvView& e, hipStream_t s) {
+    if (e.ray_count <= 0) return;
+    const long long cols = (long long)e.ray_count * (e.B >> 2);
+    long long nb = (cols + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(materialize_obs_kernel, dim3((int)nb), dim3(256), 0, s, e);
 }
 
 void launch_lidar_grid(const EnvView& e, hipStream_t s) {
@@ -1120,7 +1139,10 @@ void launch_lidar_grid(const EnvView& e, hipStream_t s) {
     const int bs = 256, nb = (e.N + bs - 1) / bs;
     (void)hipMemsetAsync(e.bw_lcount, 0, sizeof(int32_t) * (size_t)(e.bw_lmask + 1), s);
     hipLaunchKernelGGL(bw_lidar_count_kernel, dim3(nb), dim3(bs), 0, s, e);
-    hipLaunchKernelGGL(bw_lidar_scan_kernel, dim3(1), dim3(1024), 0, s, e);
+    const int sb = (e.bw_lmask + 1 + 1023) / 1024;
+    hipLaunchKernelGGL(bw_lidar_scan_local_kernel, dim3(sb), dim3(1024), 0, s, e);
+    hipLaunchKernelGGL(bw_lidar_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, e);
+    hipLaunchKernelGGL(bw_lidar_scan_apply_kernel, dim3(sb), dim3(1024), 0, s, e);
     hipLaunchKernelGGL(bw_lidar_fill_kernel, dim3(nb), dim3(bs), 0, s, e);
 }
 

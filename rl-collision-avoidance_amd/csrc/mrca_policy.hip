@@ -55,8 +55,21 @@ __device__ inline f32x16 zero16() {
     return z;
 }
 
+// the six float4 a lane loads of robot n's scan: float4 q covers logical frame q / 2; with a ring (head != NULL) frame f
+// sits in slot (head[n] + 1 + f) mod 3
+__device__ __forceinline__ void request_scan(float4 (&sx)[6], const float* __restrict__ obs, int n, int hd, int lane) {
+    const float4* src = reinterpret_cast<const float4*>(obs + (size_t)n * kFrames * kBeams);
+    const int s0 = hd == 2 ? 0 : hd + 1, s1 = s0 == 2 ? 0 : s0 + 1;      // hd = 2: the identity (deque order)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int slot = (q >> 1) == 0 ? s0 : ((q >> 1) == 1 ? s1 : hd);
+        sx[q] = src[slot * (kBeams / 4) + (q & 1) * 64 + lane];
+    }
+}
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
-    const float* __restrict__ obs, int n_robots, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ obs, const uint8_t* __restrict__ head, int n_robots, const float* __restrict__ w1,
+    const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ feat) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -108,10 +121,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     const int stride = nwaves >> 1;
     int n = gwave >> 1;
     float4 sx[6];
+    // ring heads are fetched one robot further ahead than the scans whose addresses they decide
+    int hd_next = 2;
     if (n < n_robots) {
-        const float4* src = reinterpret_cast<const float4*>(obs + (size_t)n * kFrames * kBeams);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) sx[q] = src[q * 64 + lane];
+        request_scan(sx, obs, n, head ? head[n] : 2, lane);
+        if (head && n + stride < n_robots) hd_next = head[n + stride];
     }
 
     for (; n < n_robots; n += stride) {
@@ -130,9 +144,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
         }
         MRCA_PIN();
         if (n + stride < n_robots) {
-            const float4* src = reinterpret_cast<const float4*>(obs + (size_t)(n + stride) * kFrames * kBeams);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) sx[q] = src[q * 64 + lane];
+            request_scan(sx, obs, n + stride, hd_next, lane);
+            if (head && n + 2 * stride < n_robots) hd_next = head[n + 2 * stride];
         }
         MRCA_PIN();
         float* out = feat + ((size_t)tower * n_robots + n) * (kCh * kL2) + gofs;
@@ -259,8 +272,8 @@ struct DeviceInfo {
 static DeviceInfo g_dev[64];     // per DEVICE: CU count and the dynamic-LDS attribute (a second GPU needs its own)
 }  // namespace mrca_policy
 
-extern "C" int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams,
-                                   const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
+extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t n_robots, int32_t frames,
+                                   int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
                                    float* feat_dev, void* stream) {
     using namespace mrca_policy;
     if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !feat_dev)
@@ -292,7 +305,7 @@ extern "C" int mrca_lidar_features(const float* obs_dev, int32_t n_robots, int32
     const int pairs_needed = (n_robots + 1) / 2;          // a block holds two (actor, critic) pairs
     if (blocks > pairs_needed) blocks = pairs_needed;
     hipLaunchKernelGGL(lidar_features_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), lds,
-                       static_cast<hipStream_t>(stream), obs_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
+                       static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features launch: %s", hipGetErrorString(e));
     return MRCA_OK;

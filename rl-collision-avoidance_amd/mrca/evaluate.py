@@ -50,10 +50,16 @@ def staggered_roundabout_policy(num_robots, bias=1.4, near=3.5, vgain=0.8, stop=
     return fn
 
 
-def cnn_policy_fn(policy, fused=False):
+def cnn_policy_fn(policy, fused=False, env=None):
+    """``fused`` with ``env``: the policy's HIP front end reads the env's frame ring in place (no materialised stacks)."""
     def fn(obs, local_goal, speed):
-        _mean, scaled = ppo.generate_action_no_sampling(policy, obs, local_goal, speed, ACTION_BOUND, fused=fused)
+        head = None
+        if fused and env is not None:
+            obs, head = ppo.policy_input(env, True)
+        _mean, scaled = ppo.generate_action_no_sampling(policy, obs, local_goal, speed, ACTION_BOUND, fused=fused,
+                                                        obs_head=head)
         return scaled
+    fn.wants_obs = not (fused and env is not None)
     return fn
 
 
@@ -64,7 +70,7 @@ def perturbed_start(env, jitter_xy, jitter_th, seed):
     scenario: a deterministic policy either solves all of its copies or none).  Goals stay the table's.
     -> (poses f32[N,3], goals f32[N,2]) on the env's device."""
     sc = env.scenario
-    dev = env.obs.device
+    dev = env.local_goal.device
     W, R = sc.num_worlds, sc.robots_per_world
     base = torch.as_tensor(sc.init_table, dtype=torch.float32, device=dev).unsqueeze(0).expand(W, R, 3)
     goal = torch.as_tensor(sc.goal_table, dtype=torch.float32, device=dev).unsqueeze(0).expand(W, R, 2)
@@ -89,12 +95,12 @@ def circle_test(env, policy_fn, max_ticks=1200, perturb=None, seed=0):
         poses, goals = perturbed_start(env, perturb[0], perturb[1], seed)
         env.reset(None, poses, goals)
     N = env.N
-    dev = env.obs.device
+    dev = env.local_goal.device
     ticks_to_goal = torch.zeros(N, device=dev)
     path = torch.zeros(N, device=dev)
     last_terminal = torch.zeros(N, dtype=torch.bool, device=dev)
     for k in range(max_ticks):
-        a = policy_fn(env.obs, env.local_goal, env.speed).float().clone()
+        a = policy_fn(env.obs if getattr(policy_fn, "wants_obs", True) else None, env.local_goal, env.speed).float().clone()
         a[:, 0] = torch.where(last_terminal, torch.zeros_like(a[:, 0]), a[:, 0])
         pending = env.first_result == 0
         env.step(a.contiguous())
@@ -163,7 +169,7 @@ def main():
     if a.policy:
         pol = CNNPolicy(3, 2).to(env.device)
         pol.load_state_dict(torch.load(a.policy, map_location=env.device))
-        fn, name = cnn_policy_fn(pol, fused=a.fused), a.policy
+        fn, name = cnn_policy_fn(pol, fused=a.fused, env=env), a.policy
     else:
         fn, name = staggered_roundabout_policy(env.N), "staggered-roundabout stand-in (no checkpoint given)"
     perturb = tuple(float(v) for v in a.perturb.split(",")) if a.perturb else None

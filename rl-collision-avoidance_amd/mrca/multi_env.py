@@ -3,7 +3,7 @@ scenarios under one policy (e.g. Stage-2 worlds + circle worlds).  The envs step
 stream; the per-robot fields the learner reads are concatenated into preallocated tensors after every tick."""
 import torch
 
-_FIELDS = ("obs", "local_goal", "speed", "reward", "done", "result", "live", "fresh", "first_result")
+_FIELDS = ("obs_ring", "obs_head", "local_goal", "speed", "reward", "done", "result", "live", "fresh", "first_result")
 
 
 class ConcatEnv:
@@ -19,7 +19,23 @@ class ConcatEnv:
         for k in _FIELDS:
             ref = getattr(self.envs[0], k)
             setattr(self, k, torch.empty((self.N,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=self.device))
+        self._ar = torch.arange(self.N, device=self.device)
+        self._order = torch.arange(self.obs_ring.shape[1], device=self.device).view(1, -1)
         self._gather()
+
+    # the observation stacks are kept the way the parts keep them: as rings (see VecStageWorld.obs)
+    @property
+    def obs(self):
+        """f32[N,F,B] in deque order (oldest frame first), gathered from the concatenated rings."""
+        F = self.obs_ring.shape[1]
+        slots = (self.obs_head.long().view(-1, 1) + 1 + self._order) % F
+        return self.obs_ring[self._ar.view(-1, 1), slots]
+
+    def policy_obs(self):
+        return self.obs_ring, self.obs_head
+
+    def newest_frame(self):
+        return self.obs_ring[self._ar, self.obs_head.long()]
 
     def _gather(self):
         for k in _FIELDS:
@@ -31,13 +47,13 @@ class ConcatEnv:
         for e in self.envs:
             e.reset()
         self._gather()
-        return self.obs, self.local_goal, self.speed
+        return self
 
     def step(self, actions):
         for e, (lo, hi) in zip(self.envs, self.bounds):
             e.step(actions[lo:hi].contiguous())
         self._gather()
-        return self.obs, self.local_goal, self.speed, self.reward, self.done, self.result
+        return self
 
     def enable_timing(self, on=True):
         for e in self.envs:

@@ -116,14 +116,15 @@ class CNNPolicy(nn.Module):
                 self._rc = new
         return self._rc
 
-    def mean_value_fused(self, x, goal, speed):
+    def mean_value_fused(self, x, goal, speed, head=None):
         """mean_value for the rollout: the conv front end of BOTH towers in one HIP kernel (csrc/mrca_policy.hip,
         fp32 MFMA), fc1 / fc2 of both towers as batched fp32 GEMMs.  fp32 throughout; differs from mean_value by
-        summation order only (tests/test_gpu_policy_ops.py: 1e-5).  No autograd."""
+        summation order only (tests/test_gpu_policy_ops.py: 1e-5).  No autograd.  ``head``: ``x`` is the env's frame
+        ring and head[n] the slot of robot n's newest frame (VecStageWorld.policy_obs())."""
         from . import policy_ops
         rc = getattr(self, "_rc", None) or self.refresh_rollout_cache()
         with torch.no_grad():
-            feat = policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"])        # [2, N, 4096]
+            feat = policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head)   # [2, N, 4096]
             h = torch.relu(torch.baddbmm(rc["fc1_b"], feat, rc["fc1_w"]))                      # [2, N, 256]
             gs = torch.cat((goal, speed), dim=-1).unsqueeze(0).expand(2, -1, -1)
             h = torch.relu(torch.baddbmm(rc["fc2_b"], torch.cat((h, gs), dim=-1), rc["fc2_w"]))   # [2, N, 128]

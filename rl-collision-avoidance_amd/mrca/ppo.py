@@ -23,15 +23,19 @@ def _bounds(action_bound, device, dtype):
 
 
 # ---------------------------------------------------------------------------------------------
-def generate_action(policy, obs, goal, speed, action_bound, generator=None, autocast_dtype=None, fused=False):
+def generate_action(policy, obs, goal, speed, action_bound, generator=None, autocast_dtype=None, fused=False,
+                    obs_head=None):
     """model/ppo.py:57-82: sample a ~ N(mean, std); the UNclipped action and its logprob are what
     the buffer stores, the clipped one drives the robot.  ``fused=True`` evaluates the policy through its fp32
     rollout path (HIP conv front end + batched GEMMs, net.CNNPolicy.mean_value_fused; same numbers to 1e-5);
-    ``autocast_dtype=torch.bfloat16`` runs the stock towers on the bf16 MFMA path (opt-in)."""
+    ``autocast_dtype=torch.bfloat16`` runs the stock towers on the bf16 MFMA path (opt-in).  ``obs_head`` (fused
+    only): ``obs`` is the env's frame ring, see ``policy_input``."""
     from .net import gaussian_logprob
+    if obs_head is not None and not fused:
+        raise ValueError("a frame ring (obs_head) can only be read by the fused policy path")
     with torch.no_grad():
         if fused:
-            mean, v = policy.mean_value_fused(obs, goal, speed)
+            mean, v = policy.mean_value_fused(obs, goal, speed, head=obs_head)
         elif autocast_dtype is not None:
             with torch.autocast(obs.device.type, dtype=autocast_dtype):
                 mean, v = policy.mean_value(obs, goal, speed)
@@ -47,10 +51,18 @@ def generate_action(policy, obs, goal, speed, action_bound, generator=None, auto
     return v, a, logprob, scaled
 
 
-def generate_action_no_sampling(policy, obs, goal, speed, action_bound, fused=False):
+def policy_input(env, fused):
+    """-> (obs, obs_head) to hand to generate_action / generate_action_no_sampling: the env's frame ring when the
+    fused policy path can read it in place (VecStageWorld.policy_obs), the stacks in deque order otherwise."""
+    if fused and hasattr(env, "policy_obs"):
+        return env.policy_obs()
+    return env.obs, None
+
+
+def generate_action_no_sampling(policy, obs, goal, speed, action_bound, fused=False, obs_head=None):
     """model/ppo.py:84-107: deterministic mean action (circle_test.py:58-59)."""
     with torch.no_grad():
-        mean, _v = policy.mean_value_fused(obs, goal, speed) if fused else policy.mean_value(obs, goal, speed)
+        mean, _v = policy.mean_value_fused(obs, goal, speed, head=obs_head) if fused else policy.mean_value(obs, goal, speed)
         lo, hi = _bounds(action_bound, mean.device, mean.dtype)
         scaled = torch.minimum(torch.maximum(mean, lo), hi)
     return mean, scaled
@@ -126,12 +138,12 @@ class RolloutBuffer:
             self.frames[: self.nframes - 1].copy_(obs[:, : self.nframes - 1].transpose(0, 1))
             self._cur.copy_(self._first.expand_as(self._cur))
 
-    def _store_obs_at(self, t_idx, obs, fresh):
+    def _store_obs_at(self, t_idx, obs, fresh, newest=None):
         if not self.single_frame:
             self.obs.index_copy_(0, t_idx, obs.unsqueeze(0))
             return
         row = t_idx + self._two                                         # the newest frame of tick t lives in row t+F-1
-        self.frames.index_copy_(0, row, obs[:, -1].unsqueeze(0))
+        self.frames.index_copy_(0, row, (obs[:, -1] if newest is None else newest).unsqueeze(0))
         shifted = torch.cat((self._cur[:, 1:], row.view(1, 1).expand(self.num_env, 1)), dim=1)
         # tick 0 of a horizon: rows 0..F-1 whatever the flags say (begin_horizon copied the real older frames)
         at_start = (t_idx == 0).view(1, 1)
@@ -146,9 +158,11 @@ class RolloutBuffer:
         T, N = self.horizon, self.num_env
         return self.obs.reshape(T * N, self.nframes, -1)
 
-    def store_state(self, t, obs, goal, speed, action, logprob, value, fresh=None):
+    def store_state(self, t, obs, goal, speed, action, logprob, value, fresh=None, newest=None):
+        """``newest`` f32[N,B] (single_frame only): the frame the last tick appended, for callers that keep the stacks
+        as a ring and would rather not materialise ``obs`` (VecStageWorld.newest_frame()); ``obs`` may then be None."""
         if self.single_frame:
-            self._store_obs_at(torch.tensor([t], dtype=torch.int64, device=obs.device), obs, fresh)
+            self._store_obs_at(torch.tensor([t], dtype=torch.int64, device=goal.device), obs, fresh, newest)
         else:
             self.obs[t].copy_(obs)
         self.goal[t].copy_(goal)
@@ -163,8 +177,8 @@ class RolloutBuffer:
 
     # the same two stores with the row given as a DEVICE index tensor (int64[1]): no host value enters the launch, so a
     # whole tick can be captured once as a hipGraph and replayed for every row of the horizon
-    def store_state_at(self, t_idx, obs, goal, speed, action, logprob, value, fresh=None):
-        self._store_obs_at(t_idx, obs, fresh)
+    def store_state_at(self, t_idx, obs, goal, speed, action, logprob, value, fresh=None, newest=None):
+        self._store_obs_at(t_idx, obs, fresh, newest)
         self.goal.index_copy_(0, t_idx, goal.unsqueeze(0))
         self.speed.index_copy_(0, t_idx, speed.unsqueeze(0))
         self.action.index_copy_(0, t_idx, action.unsqueeze(0))

@@ -89,12 +89,21 @@ class Stage1Trainer:
         """The device work of one tick with the buffer row taken from ``self._t_idx`` (a device tensor): nothing in
         here depends on a host value, so it can be captured as a hipGraph."""
         env, hp, buf = self.env, self.hp, self.buffer
-        v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
-                                                    hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused)
-        buf.store_state_at(self._t_idx, env.obs, env.local_goal, env.speed, a, logprob, v, env.fresh)
+        obs, head = ppo.policy_input(env, hp.rollout_fused)
+        v, a, logprob, scaled = ppo.generate_action(self.policy, obs, env.local_goal, env.speed,
+                                                    hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused, head)
+        so, sn = self._stored_obs()
+        buf.store_state_at(self._t_idx, so, env.local_goal, env.speed, a, logprob, v, env.fresh, newest=sn)
         env.step(scaled.contiguous())
         buf.store_outcome_at(self._t_idx, env.reward, env.done)
         self._t_idx.add_(1)
+
+    def _stored_obs(self):
+        """-> (obs, newest) for the rollout buffer: with the one-frame store and an env that keeps its stacks as a ring
+        only the newest frame is read (no materialised copy of the stacks per tick)."""
+        if self.hp.single_frame_buffer and hasattr(self.env, "newest_frame"):
+            return None, self.env.newest_frame()
+        return self.env.obs, None
 
     def _capture(self):
         """One tick as a hipGraph: ~50 launches (policy layers, sampling, the two env kernels, eight buffer stores)
@@ -130,10 +139,14 @@ class Stage1Trainer:
             buf.begin_horizon(env.obs)      # one-frame store: the older frames of the stack the first tick sees
         if hp.graph_tick:
             self._graph.replay()
+            if hasattr(env, "_obs_current"):
+                env._obs_current = False        # the replayed tick advanced the ring behind the binding's back
         else:
-            v, a, logprob, scaled = ppo.generate_action(self.policy, env.obs, env.local_goal, env.speed,
-                                                        hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused)
-            buf.store_state(self.t, env.obs, env.local_goal, env.speed, a, logprob, v, env.fresh)
+            obs, head = ppo.policy_input(env, hp.rollout_fused)
+            v, a, logprob, scaled = ppo.generate_action(self.policy, obs, env.local_goal, env.speed,
+                                                        hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused, head)
+            so, sn = self._stored_obs()
+            buf.store_state(self.t, so, env.local_goal, env.speed, a, logprob, v, env.fresh, newest=sn)
             env.step(scaled.contiguous())
             buf.store_outcome(self.t, env.reward, env.done)
         self.t += 1
@@ -145,8 +158,11 @@ class Stage1Trainer:
     def update(self):
         env, hp, buf = self.env, self.hp, self.buffer
         with torch.no_grad():                                                           # ppo_stage1.py:94-97
-            _mean, last_v = (self.policy.mean_value_fused if hp.rollout_fused else self.policy.mean_value)(
-                env.obs, env.local_goal, env.speed)
+            obs, head = ppo.policy_input(env, hp.rollout_fused)
+            if hp.rollout_fused:
+                _mean, last_v = self.policy.mean_value_fused(obs, env.local_goal, env.speed, head=head)
+            else:
+                _mean, last_v = self.policy.mean_value(obs, env.local_goal, env.speed)
         targets, advs = ppo.generate_train_data(buf.reward, hp.gamma, buf.value, last_v, buf.done, hp.lam)
         memory = (buf.obs_rows(), buf.goal, buf.speed, buf.action, buf.logprob, targets, buf.value, buf.reward, advs)
         kw = dict(policy=self.policy, optimizer=self.optimizer, batch_size=hp.batch_size, memory=memory,
@@ -187,8 +203,9 @@ def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, upd
             tr.policy.refresh_rollout_cache()
 
         def body():
-            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, env.obs, env.local_goal, env.speed,
-                                                      hp.action_bound, tr.gen, hp.inference_dtype, hp.rollout_fused)
+            obs, head = ppo.policy_input(env, hp.rollout_fused)
+            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, obs, env.local_goal, env.speed,
+                                                      hp.action_bound, tr.gen, hp.inference_dtype, hp.rollout_fused, head)
             env.step(scaled.contiguous())
         env.enable_timing(False)
         side = torch.cuda.Stream(device=env.device)
@@ -204,8 +221,9 @@ def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, upd
         return lambda _k: g.replay()
     if mode == "rollout":
         def step_fn(_k):
-            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, env.obs, env.local_goal, env.speed,
-                                                      hp.action_bound, tr.gen, hp.inference_dtype, hp.rollout_fused)
+            obs, head = ppo.policy_input(env, hp.rollout_fused)
+            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, obs, env.local_goal, env.speed,
+                                                      hp.action_bound, tr.gen, hp.inference_dtype, hp.rollout_fused, head)
             env.step(scaled.contiguous())
         return step_fn
 

@@ -49,7 +49,8 @@ class VecStageWorld:
             auto_reset=sc.auto_reset, seed=sc.seed, reset_mode=reset_mode.ctypes.data,
             goal_mode=goal_mode.ctypes.data, init_table=init_table.ctypes.data,
             goal_table=goal_table.ctypes.data, group_id=group_id.ctypes.data,
-            collision_raster=float(getattr(sc, "collision_raster", 0.0)))
+            collision_raster=float(getattr(sc, "collision_raster", 0.0)),
+            lazy_obs=1)      # MRCA_F_OBS is materialised by the ``obs`` property when somebody asks for it
         nbytes = C.c_size_t()
         _lib.check(self.lib.mrca_arena_bytes(C.byref(cfg), C.byref(nbytes)), "mrca_arena_bytes")
         # the arena is a torch allocation so that every field is a plain torch view (zero copy)
@@ -72,7 +73,29 @@ class VecStageWorld:
                 t = flat.view(self.N)
             else:
                 t = flat.view(self.N, shape)
-            setattr(self, name, t)
+            setattr(self, "_obs" if name == "obs" else name, t)
+        self._obs_current = False
+        self._ar = torch.arange(self.N, device=self.device)
+
+    # ------------------------------------------------------------------ the observation stack
+    @property
+    def obs(self):
+        """f32[N,F,B] the frame stacks in deque order (oldest frame first; what ``CNNPolicy.forward`` eats,
+        ppo_stage1.py:59-60,87-89).  The env keeps the stacks as a RING (``obs_ring`` + ``obs_head``: a tick writes one
+        frame per robot instead of shifting three) and brings this copy up to date when it is read after a tick
+        (mrca_materialize_obs: one copy kernel on the current stream).  The fused policy path reads the ring itself."""
+        if not self._obs_current:
+            _lib.check(self.lib.mrca_materialize_obs(self._h, self._stream()), "mrca_materialize_obs")
+            self._obs_current = True
+        return self._obs
+
+    def policy_obs(self):
+        """-> (stacks, heads) for consumers that understand the ring: (obs_ring f32[N,F,B], obs_head u8[N])."""
+        return self.obs_ring, self.obs_head
+
+    def newest_frame(self):
+        """f32[N,B]: every robot's newest normalised scan (the frame a tick appended), gathered from the ring."""
+        return self.obs_ring[self._ar, self.obs_head.long()]
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -105,7 +128,8 @@ class VecStageWorld:
         _lib.check(self.lib.mrca_reset(self._h, self._ptr(mask, torch.uint8, self.N),
                                        self._ptr(poses, torch.float32, self.N * 3),
                                        self._ptr(goals, torch.float32, self.N * 2), self._stream()), "mrca_reset")
-        return self.obs, self.local_goal, self.speed
+        self._obs_current = False
+        return self
 
     def step(self, actions, ray_slice=None):
         """control_vel + one Stage tick + get_reward_and_terminate + next observation for every
@@ -118,7 +142,12 @@ class VecStageWorld:
         else:
             _lib.check(self.lib.mrca_step_slice(self._h, a, int(ray_slice[0]), int(ray_slice[1]), self._stream()),
                        "mrca_step_slice")
-        return self.obs, self.local_goal, self.speed, self.reward, self.done, self.result
+        self._obs_current = False
+        return self
+
+    def check(self):
+        """Host round trip: raises if a kernel flagged a device-side failure since the last check (mrca_check)."""
+        _lib.check(self.lib.mrca_check(self._h, self._stream()), "mrca_check")
 
     # ------------------------------------------------------------------ timing (bench / profiles)
     def enable_timing(self, on=True):

@@ -78,6 +78,32 @@ def test_jam_of_500_robots_bit_exact(hip):
     assert o.crashed.sum() > 20
 
 
+def test_the_jam_leaves_the_status_word_clear_and_a_raised_word_is_reported(hip):
+    """The ordered collision pass waits (bounded) for lower-indexed robots; had it ever given up, the env's sticky status
+    word would say so and mrca_check would fail loudly.  Through the jam -- where almost every robot is in a dependency
+    chain -- the word must stay clear; a word raised by hand must come back as an error, once."""
+    sc = S.circle_big(500)
+    rng = np.random.default_rng(11)
+    ij = np.stack(np.meshgrid(np.arange(23), np.arange(23)), -1).reshape(-1, 2)[:500]
+    xy = (ij - 23 / 2) * 0.8 + rng.uniform(-0.12, 0.12, (500, 2))
+    poses = np.concatenate([xy, rng.uniform(-np.pi, np.pi, (500, 1))], 1).astype(np.float32)
+    env = hip.VecStageWorld(sc)
+    env.reset(torch.ones(500, dtype=torch.uint8, device="cuda"), torch.from_numpy(poses).cuda(), None)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for _ in range(30):
+        env.step(torch.stack([torch.rand(500, generator=g), torch.rand(500, generator=g) * 2 - 1], 1).float().cuda())
+    env.check()
+    assert int(env.crashed.sum()) > 20
+    # raise the word by hand (the last 4 bytes the layout hands out: behind every field)
+    status = env.arena[-256:].view(torch.int32)
+    assert int(status.abs().sum()) == 0
+    status[0] = 1
+    with pytest.raises(RuntimeError, match="collision pass"):
+        env.check()
+    env.check()                                     # reported once, then clear again
+    env.close()
+
+
 def test_two_big_worlds_are_independent(hip):
     sc2 = S.circle_big(100, num_worlds=2, spacing=0.9)
     sc1 = S.circle_big(100, num_worlds=1, spacing=0.9)

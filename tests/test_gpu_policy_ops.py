@@ -143,3 +143,31 @@ def test_bf16_inference_is_bounded_against_fp32():
     assert m["crash_rate"] < 0.5
     env.close()
     env1.close()
+
+
+def test_front_end_reads_the_envs_frame_ring_in_place(pol):
+    """The env keeps the observation stacks as a ring (one frame written per tick); the kernel must see exactly the
+    stacks the deque-ordered copy (env.obs, mrca_materialize_obs) holds -- bit for bit, at every phase of the ring and
+    across restarts (a restarted robot has all its slots rewritten)."""
+    from mrca import policy_ops
+    from mrca.vec_env import VecStageWorld
+    from util import S
+    env = VecStageWorld(S.stage1(num_worlds=8, robots_per_world=24, seed=2), device="cuda:0")
+    env.reset()
+    rc = pol.refresh_rollout_cache()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    seen_heads = set()
+    for k in range(12):
+        a = torch.stack([torch.rand(env.N, generator=g, device="cuda"), torch.rand(env.N, generator=g, device="cuda") * 2 - 1], 1)
+        env.step(a.contiguous())
+        ring, head = env.policy_obs()
+        seen_heads |= set(head.unique().tolist())
+        via_ring = policy_ops.lidar_features(ring, rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head)
+        via_copy = policy_ops.lidar_features(env.obs, rc["w1"], rc["b1"], rc["w2"], rc["b2"])
+        assert torch.equal(via_ring, via_copy), k
+        assert torch.equal(env.newest_frame(), env.obs[:, -1])
+        m0, v0 = pol.mean_value_fused(ring, env.local_goal, env.speed, head=head)
+        m1, v1 = pol.mean_value_fused(env.obs, env.local_goal, env.speed)
+        assert torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert seen_heads == {0, 1, 2}
+    env.close()

@@ -30,7 +30,7 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
         env.step(pool[k % 8])
     for flags, label in ((0, "full (product shape)"), (1, "no neighbour tests"), (2, "no march"), (3, "no march, no neighbours"),
                          (8, "move: no outline test"), (16, "move: no collision loop"), (32, "move: no resets"),
-                         (56, "move: none of the three"), (64, "frame-stack shift as a launch of its own"),
+                         (56, "move: none of the three"),
                          (256, "1 beam/thread, 512 thr, wave 0 prepares"), (512, "2 beams sequential, wave 0 prepares (product)"),
                          (512 + 4096, "2 beams lock-step, wave 0 prepares"), (768, "4 beams lock-step, wave 0 prepares"),
                          (256 + 2048, "1 beam/thread + dedicated prep wave"), (512 + 2048, "2 beams sequential + prep wave"),
