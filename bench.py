@@ -32,10 +32,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BYTES_PER_AGENT_STEP = 10332   # SURVEY 8(d) B_env_stack: 2140 + frame-stack shift (4096 read + 4096 write), per TICK
-# per LAUNCH, since round 2 (the frame-stack shift rides in the move kernel's launch):
-RAY_BYTES_PER_AGENT_STEP = 2 * 4 * 512 + 48    # scan + newest obs frame written, pose / head / goal / flag read, local goal
-MOVE_BYTES_PER_AGENT_STEP = 2 * 4096 + 108     # two frames read + written one slot down, ~0.1 kB of robot state
+# Algorithmic HBM bytes per agent-step.  Since round 3 the frame stack is a ring: a tick writes the scan and
+# ONE observation frame per robot and ~0.1 kB of state -- no shift (rounds 1-2: + 4096 read + 4096 written, B_env_stack).
+B_ENV_STRICT = 4 * 512 + 92                    # SURVEY 8(d) B_env: ONE 2 kB row (scan or frame) + 92 B of state = 2140
+BYTES_PER_AGENT_STEP = 2 * 4 * 512 + 92        # what the tick really owes: scan + newest frame + state = 4188, per TICK
+RAY_BYTES_PER_AGENT_STEP = 2 * 4 * 512 + 48    # per LAUNCH: scan + newest obs frame written, pose / head / goal / flag read, local goal
+MOVE_BYTES_PER_AGENT_STEP = 140                # per LAUNCH: pose, speeds, goal, counters, flags, head record read + written
 
 
 def code_only(src):
@@ -77,7 +79,7 @@ def pmc_traffic(robots, scenario):
             "2*FETCH_SIZE + WRITE_SIZE)")
     if d.get("move_fetch_kib") is not None:
         mv = (2.0 * d["move_fetch_kib"] + d["move_write_kib"]) * 1024.0 / d["robots"] * robots
-        note += f"; the move kernel's launch (incl. the frame-stack shift): {mv / 1e6:.1f} MB"
+        note += f"; the move kernel's launch: {mv / 1e6:.2f} MB"
     return per_robot * robots, note
 
 
@@ -348,8 +350,11 @@ def main():
                          "bytes_per_agent_step": RAY_BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
                          "tick": {"achieved": tick_achieved, "frac": tick_achieved / HBM_PEAK_GBS if tick_achieved else None,
                                   "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
-                                  "note": "SURVEY 8d B_env_stack over BOTH launches of the tick (move + frame-stack "
-                                          "shift, ray cast)"},
+                                  "frac_at_survey_B_env_2140": (tick_achieved * B_ENV_STRICT / BYTES_PER_AGENT_STEP / HBM_PEAK_GBS)
+                                  if tick_achieved else None,
+                                  "note": "both launches of the tick (move, ray cast) against scan + newest frame + state "
+                                          "= 4188 B per agent-step; the frame stack is a ring since round 3 (no shift: "
+                                          "rounds 1-2 owed SURVEY's B_env_stack = 10 332 B)"},
                          "move_launch": {"achieved": move_achieved,
                                          "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
@@ -357,8 +362,7 @@ def main():
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
                          "note": "HBM is the nominal roof (SURVEY 8d); the ray cast is bound by its per-robot latency chain and the "
                                  "march, not by traffic or VALU issue (608 VALU instructions per wave, 63 % of the launch's "
-                                 "issue cycles) -- it no longer moves the frame stack (that is the move launch's 8.2 kB per "
-                                 "agent-step); see DESIGN.md 5"},
+                                 "issue cycles); see DESIGN.md 5"},
         }
         if args.mode == "rollout":
             # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2

@@ -109,11 +109,11 @@ def test_policy_gradients_with_the_hip_front_end_equal_the_stock_gradients():
     """evaluate_actions -> PPO-like loss -> backward, through the stock layers (MIOpen), through lidar_features_fn, and
     in float64 on the CPU: the two fp32 device results differ from each other by summation order only.  The conv
     gradients of a real loss cancel heavily (sums of 2048 x 255 signed products whose total is ~1e-3 of the sum of their
-    magnitudes), so neither fp32 result is better than ~1e-4 .. 1e-3 of the tensor's largest entry: MIOpen's must be
-    within 5e-4 of the float64 gradient, the kernel's -- one sequential fp32 MFMA chain per wave over its items' 255
-    positions, where MIOpen reduces in blocks -- within 2e-3 (measured on conv1's weights, the worst tensor: 1.2e-3 vs
-    MIOpen's 2.8e-4; every other tensor below 2e-4).  The reference-run learner goldens (tests/test_golden_learner.py,
-    'cuda-fused' legs) bound what that means for the parameters after an update: 1e-5."""
+    magnitudes), so neither fp32 result is better than ~1e-4 .. 1e-3 of the tensor: the kernel accumulates one sequential
+    fp32 MFMA chain per wave over its items' 255 positions where MIOpen reduces in blocks (measured on conv1's weights,
+    the worst tensor: 1.2e-3 vs MIOpen's 2.8e-4 of the largest entry).  Bars: see the loop.  The reference-run learner
+    goldens (tests/test_golden_learner.py, 'cuda-fused' legs) bound what that means for the parameters after an update:
+    1e-5."""
     import copy
     from mrca.net import CNNPolicy
     torch.manual_seed(5)
@@ -147,11 +147,20 @@ def test_policy_gradients_with_the_hip_front_end_equal_the_stock_gradients():
     ref = grads_of(ref_pol, tuple(a.cpu().double() for a in args))
     worst = {}
     for k in ref:
+        # relative L2 error of the whole tensor, and its largest entry error relative to the largest entry.  The latter
+        # is NOT an arithmetic bound: a pre-activation of fc1 / fc2 within rounding distance of 0 flips its ReLU between
+        # two evaluations that differ by 1e-6 .. 1e-5, and ONE flipped (sample, unit) moves that unit's row of the weight
+        # gradient by ~1/sqrt(N) of its magnitude (measured: 6e-3 on act_fc1.weight with N = 2048) -- in either fp32
+        # path.  The L2 error averages such rows out.
+        n2 = float(ref[k].norm())
         scale = float(ref[k].abs().max())
-        e_f, e_s = float((fused[k] - ref[k]).abs().max()) / scale, float((stock[k] - ref[k]).abs().max()) / scale
-        worst[k] = (e_f, e_s)
-        assert e_s <= 5e-4, (k, e_f, e_s)
-        assert e_f <= 2e-3, (k, e_f, e_s)
-    print("relative error vs float64 (fused, stock):", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in worst.items()
-                                                         if "fea_cv" in k})
+        l2_f, l2_s = float((fused[k] - ref[k]).norm()) / n2, float((stock[k] - ref[k]).norm()) / n2
+        mx_f, mx_s = float((fused[k] - ref[k]).abs().max()) / scale, float((stock[k] - ref[k]).abs().max()) / scale
+        worst[k] = (l2_f, l2_s, mx_f, mx_s)
+    print("relative L2 error vs float64 (fused, stock), max-entry error (fused, stock):")
+    for k, w in worst.items():
+        print(f"  {k:22s} {w[0]:.1e} {w[1]:.1e}   {w[2]:.1e} {w[3]:.1e}")
+    for k, w in worst.items():
+        assert w[1] <= 1e-3 and w[0] <= 2e-3, (k, w)
+        assert w[3] <= 3e-2 and w[2] <= 3e-2, (k, w)
     assert float(fused["act_fea_cv1.weight"].abs().max()) > 0 and float(fused["crt_fea_cv2.bias"].abs().max()) > 0
