@@ -50,7 +50,7 @@ struct Layout {
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
     size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield, off_head;
     // big worlds (robots_per_world > 64) only
-    size_t off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted, off_bw_lblock;
+    size_t off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted, off_bw_lblock, off_bw_lcursor;
     size_t off_status;
     int32_t bw_cmask, bw_lmask;
     size_t total;
@@ -166,6 +166,7 @@ void make_layout(const mrca_config* c, Layout* L) {
         L->off_bw_lcount = take((ml + 1) * 4);
         L->off_bw_lsorted = take(N * 4);
         L->off_bw_lblock = take((ml / 1024 + 2) * 4);
+        L->off_bw_lcursor = take((ml + 1) * 4);
     }
     L->off_status = take(4);
     L->total = off;
@@ -322,6 +323,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
         mrca::build_cell_field(cfg->map_bits, cfg->map_width, cfg->map_height, cfg->map_words_per_row, &cf);
         HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_cellfield, cf.data(), cf.size(), hipMemcpyHostToDevice));
     }
+    if (R > 64)    // the collision hash starts empty; every tick leaves it empty again (bw_finish_kernel)
+        HIP_TRY_BAIL(hipMemset(env->arena + L.off_bw_chead, 0xFF, ((size_t)L.bw_cmask + 1) * 4));
     // live = 1, t = 1 at construction (a robot exists and is idle before the first reset)
     HIP_TRY_BAIL(hipMemset(env->arena + L.field_off[MRCA_F_LIVE], 1, N));
     {
@@ -381,6 +384,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
         v.bw_lcount = reinterpret_cast<int32_t*>(a + L.off_bw_lcount);
         v.bw_lsorted = reinterpret_cast<int32_t*>(a + L.off_bw_lsorted);
         v.bw_lblock = reinterpret_cast<int32_t*>(a + L.off_bw_lblock);
+        v.bw_lcursor = reinterpret_cast<int32_t*>(a + L.off_bw_lcursor);
         v.bw_cmask = L.bw_cmask;
         v.bw_lmask = L.bw_lmask;
     }
@@ -457,7 +461,7 @@ int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, c
     DeviceGuard guard(env->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     mrca::launch_reset(env->view, mask_dev, poses_dev, goals_dev, s);
-    mrca::launch_lidar_grid(env->view, s);
+    mrca::launch_lidar_grid(env->view, /*counted=*/0, s);
     mrca::launch_raycast(env->view, /*only_fresh=*/1, s);
     if (!env->cfg.lazy_obs) mrca::launch_materialize_obs(env->view, s);
     HIP_TRY(hipGetLastError());
@@ -486,7 +490,7 @@ static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int
     v.ray_count = count;
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 0], s));
     mrca::launch_move(v, actions_dev, s);
-    mrca::launch_lidar_grid(v, s);
+    mrca::launch_lidar_grid(v, /*counted=*/1, s);
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
     mrca::launch_raycast(v, /*only_fresh=*/0, s);
     if (!env->cfg.lazy_obs) mrca::launch_materialize_obs(v, s);   // (inside the ray cast's event pair: it is part of the tick then)

@@ -45,7 +45,8 @@ struct EnvView {
     int32_t* bw_cnext;      // [2N] entry e = 2*robot + (0: pose at tick start | 1: provisional pose) -> next entry
     int32_t bw_cmask;
     int32_t* bw_lstart;     // [bw_lmask+2] lidar hash (6.5 m cells) over the FINAL poses: bucket -> first slot
-    int32_t* bw_lcount;     // [bw_lmask+1] bucket population / fill cursor
+    int32_t* bw_lcount;     // [bw_lmask+1] bucket population (counted by bw_finish_kernel, zeroed again by the scan)
+    int32_t* bw_lcursor;    // [bw_lmask+1] fill cursor of the counting sort
     int32_t* bw_lsorted;    // [N] robots ordered by bucket
     int32_t* bw_lblock;     // [(bw_lmask+1)/1024 + 1] totals / offsets of the scan's 1024-bucket blocks
     int32_t bw_lmask;
@@ -99,7 +100,7 @@ size_t move_lds_bytes(const EnvView& e);
 void launch_move(const EnvView& e, const float* actions, hipStream_t s);
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s);
 void launch_head_init(const EnvView& e, hipStream_t s);
-void launch_lidar_grid(const EnvView& e, hipStream_t s);   // big worlds: hash of the current poses for the ray cast
+void launch_lidar_grid(const EnvView& e, int counted, hipStream_t s);   // big worlds: hash of the current poses for the ray cast
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
 void launch_materialize_obs(const EnvView& e, hipStream_t s);   // obs_ring -> obs for robots [ray_first, ray_first + ray_count)
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,

@@ -33,7 +33,7 @@ namespace mrca {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kPatchBatch = 4;   // footprint patches fetched per memory round trip in move_kernel
+constexpr int kPatchLoads = 16;  // independent patch-word loads a lane of move_kernel keeps in flight
 
 __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
                                               float* py, float* pth, float* gx, float* gy, float* pdist,
@@ -185,6 +185,10 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     const int rmode = valid ? e.reset_mode[lane] : 0;
     const int gmode = valid ? e.goal_mode[lane] : 0;
     const int gid = valid ? e.group_id[lane] : -1;
+    // this lane's rows of the pose / goal tables: a restart below takes them by broadcast instead of a load per robot
+    const float tix = valid ? e.init_table[lane * 3 + 0] : 0.0f, tiy = valid ? e.init_table[lane * 3 + 1] : 0.0f;
+    const float tith = valid ? e.init_table[lane * 3 + 2] : 0.0f;
+    const float tgx = valid ? e.goal_table[lane * 2 + 0] : 0.0f, tgy = valid ? e.goal_table[lane * 2 + 1] : 0.0f;
     const float4 hd = e.head[n];   // sin / cos of th and the field entry of the robot's cell, kept by whoever moved it
     const float v = live ? sane_cmd(act_v) : 0.0f;
     const float w = live ? sane_cmd(act_w) : 0.0f;
@@ -202,8 +206,8 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
 
     // --- outline-vs-grid test.  Skipped (same answer: free) when the coarse free-distance field says
     //     every block within the footprint's circumradius of the provisional centre is empty.  For the
-    //     others the (2*hc+1)-row patch under the footprint is pulled into LDS by the WHOLE wave, kPatchBatch
-    //     robots' loads in flight at a time, and each robot then walks its outline in LDS.
+    //     others the (2*hc+1)-row patch under the footprint is pulled into LDS by the WHOLE wave, every robot's words
+    //     in flight together, and each robot then walks its outline in LDS.
     const int hc = e.foot_hc;
     const int prow = 2 * hc + 1;
     const int pwords = (prow + 31) / 32 + 1;
@@ -247,42 +251,43 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         __syncthreads();   // the patches below reuse this LDS
     }
     const bool need = check_map && !(inside && clearance > hc);
-    {
-        unsigned long long todo = __ballot(need);
-        while (todo) {
-            int src[kPatchBatch];
-#pragma unroll
-            for (int q = 0; q < kPatchBatch; ++q) {
-                src[q] = todo ? (__ffsll((long long)todo) - 1) : -1;
-                if (todo) todo &= todo - 1;
-            }
-            for (int k0 = 0; k0 < psize; k0 += kWave) {
-                const int k = k0 + lane;
-                const int r = k / pwords, wi = k - r * pwords;
-                uint32_t val[kPatchBatch];
-#pragma unroll
-                for (int q = 0; q < kPatchBatch; ++q) {
-                    val[q] = 0u;
-                    if (src[q] >= 0 && k < psize) {
-                        const int gy = ibcast(py0, src[q]) + r;
-                        const int gw = ibcast(pw0, src[q]) + wi;
-                        if (gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val[q] = e.map_bits[gy * e.g.wpr + gw];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < kPatchBatch; ++q)
-                    if (src[q] >= 0 && k < psize) mini[src[q] * psize + k] = val[q];
-            }
-        }
-    }
-    // outline walks, four lanes per robot (one per edge, 16 robots per pass): a walk is a chain of
-    // dependent LDS reads, so spreading the edges over lanes cuts the chain by four
+    // the robots that need the walk, compacted; then ALL their patches in as few memory round trips as the lanes'
+    // load queues allow: (robot, word) pairs are dealt round-robin to the lanes, kPatchLoads independent loads per
+    // lane in flight (a Stage-2 world keeps ~30 of its 44 robots near walls: 30 words each -- round 2 fetched four
+    // robots per round trip, eight dependent trips)
     int* need_list = reinterpret_cast<int*>(mini + kWave * psize);   // [64] lanes that need the walk
     int* hit_flag = need_list + kWave;                               // [64] result per robot lane
     const unsigned long long need_mask = __ballot(need);
     if (need) need_list[__popcll(need_mask & ((1ull << lane) - 1ull))] = lane;
     hit_flag[lane] = 0;
-    __syncthreads();  // one wave per block: orders the cooperative LDS writes before the reads below
+    __syncthreads();  // one wave per block: orders the LDS writes before the reads below
+    {
+        const int total = __popcll(need_mask) * psize;
+        for (int k0 = 0; k0 < total; k0 += kWave * kPatchLoads) {
+            uint32_t val[kPatchLoads];
+            int dst[kPatchLoads];
+#pragma unroll
+            for (int u = 0; u < kPatchLoads; ++u) {
+                const int idx = k0 + u * kWave + lane;
+                const bool on = idx < total;
+                const int q = on ? idx / psize : 0;
+                const int k = idx - q * psize;
+                const int src = need_list[q];
+                const int r = k / pwords, wi = k - r * pwords;
+                const int gy = __shfl(py0, src, kWave) + r;
+                const int gw = __shfl(pw0, src, kWave) + wi;
+                val[u] = 0u;
+                dst[u] = on ? src * psize + k : -1;
+                if (on && gy >= 0 && gy < e.g.height && gw >= 0 && gw < e.g.wpr) val[u] = e.map_bits[gy * e.g.wpr + gw];
+            }
+#pragma unroll
+            for (int u = 0; u < kPatchLoads; ++u)
+                if (dst[u] >= 0) mini[dst[u]] = val[u];
+        }
+    }
+    // outline walks, four lanes per robot (one per edge, 16 robots per pass): a walk is a chain of
+    // dependent LDS reads, so spreading the edges over lanes cuts the chain by four
+    __syncthreads();
     const int n_need = __popcll(need_mask);
     for (int base = 0; base < n_need; base += 16) {
         const int q = base + (lane >> 2);
@@ -423,16 +428,16 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         const int rm = ibcast(rmode, src), gm = ibcast(gmode, src);
         float px, py, pth, qx, qy;
         if (rm == 0) {
-            px = e.init_table[src * 3 + 0];
-            py = e.init_table[src * 3 + 1];
-            pth = wrap_angle(e.init_table[src * 3 + 2]);
+            px = fbcast(tix, src);
+            py = fbcast(tiy, src);
+            pth = wrap_angle(fbcast(tith, src));
         } else {
             wave_sample_pose(lane, rm, (uint32_t)nsrc, eps, e.key0, e.key1, fbcast(x, src), fbcast(y, src), &px, &py,
                              &pth);
         }
         if (gm == 0) {
-            qx = e.goal_table[src * 2 + 0];
-            qy = e.goal_table[src * 2 + 1];
+            qx = fbcast(tgx, src);
+            qy = fbcast(tgy, src);
         } else {
             wave_sample_goal(lane, gm, (uint32_t)nsrc, eps, e.key0, e.key1, px, py, &qx, &qy);
         }
@@ -908,8 +913,9 @@ __global__ void bw_finish_kernel(EnvView e) {
     const bool live = (flags & kFlagLive) != 0;
     const bool moved = e.bw_state[n] == 2;
     const float4 hd = e.head[n];
-    float x = moved ? p0.x : e.pose[n * 3 + 0];
-    float y = moved ? p0.y : e.pose[n * 3 + 1];
+    const float ox0 = e.pose[n * 3 + 0], oy0 = e.pose[n * 3 + 1];    // the pose at tick start (hashed by bw_integrate)
+    float x = moved ? p0.x : ox0;
+    float y = moved ? p0.y : oy0;
     float th = moved ? p0.z : e.pose[n * 3 + 2];
     float s = moved ? p1.x : hd.x, c = moved ? p1.y : hd.y;
     const float v = p1.z, w = p1.w;
@@ -1004,9 +1010,20 @@ __global__ void bw_finish_kernel(EnvView e) {
     e.episode[n] = ep;
     e.fresh[n] = fresh ? 1 : 0;
     e.head[n] = make_float4(s, c, __uint_as_float(cellv), 0.0f);
+    // the collision hash is per tick: every robot empties the (at most two) buckets it filled, so the next tick needs
+    // no 4N-entry memset; and the lidar hash's population count of the FINAL pose rides here as well
+    const int world = n / e.R;
+    e.bw_chead[hash_cell(hash_cell_coord(ox0, kCollideCell), hash_cell_coord(oy0, kCollideCell), world) &
+               (uint32_t)e.bw_cmask] = -1;
+    if (flags & kFlagMoving)
+        e.bw_chead[hash_cell(hash_cell_coord(p0.x, kCollideCell), hash_cell_coord(p0.y, kCollideCell), world) &
+                   (uint32_t)e.bw_cmask] = -1;
+    atomicAdd(&e.bw_lcount[hash_cell(hash_cell_coord(x, kLidarCell), hash_cell_coord(y, kLidarCell), world) &
+                           (uint32_t)e.bw_lmask], 1);
 }
 
-// lidar hash = counting sort of the robots by the bucket of their (final) cell
+// lidar hash = counting sort of the robots by the bucket of their (final) cell.  (Stand-alone count: after explicit
+// resets; a tick counts inside bw_finish_kernel.)
 __global__ void bw_lidar_count_kernel(EnvView e) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= e.N) return;
@@ -1017,9 +1034,9 @@ __global__ void bw_lidar_count_kernel(EnvView e) {
 
 // Exclusive scan of the bucket populations in three small launches (a single workgroup walking all 2N buckets took
 // 296 us at 50 000 robots -- 70 % of the move phase, profiles/r03_d_bigworld_50000_kernel_stats.csv):
-//   scan_local   one workgroup per 1024 buckets: coalesced load, block scan, local prefix -> bw_lstart, total -> bw_lblock
-//   scan_blocks  one workgroup: exclusive scan of the <= 1024 x k block totals (in place), grand total -> bw_lstart[M]
-//   scan_apply   adds its block's offset; the counts become the fill cursors (zeroed)
+//   scan_local   one workgroup per 1024 buckets: coalesced load, block scan, local prefix -> bw_lstart, total -> bw_lblock;
+//                zeroes the counts (for the next tick) and the fill cursors
+//   scan_apply   adds its block's offset (the totals of the blocks before it, summed by the block itself)
 __device__ __forceinline__ int block_scan_1024(int v, int* part) {     // inclusive scan over the workgroup's 1024 threads
     const int tid = threadIdx.x;
     part[tid] = v;
@@ -1041,31 +1058,28 @@ __global__ __launch_bounds__(1024) void bw_lidar_scan_local_kernel(EnvView e) {
     const int incl = block_scan_1024(cnt, part);
     if (b < M) {
         e.bw_lstart[b] = incl - cnt;
-        e.bw_lcount[b] = 0;                 // becomes the fill cursor
+        e.bw_lcount[b] = 0;                 // ready for the next count (no memset per tick)
+        e.bw_lcursor[b] = 0;                // the fill cursor
     }
     if (threadIdx.x == 1023) e.bw_lblock[blockIdx.x] = incl;
 }
 
-__global__ __launch_bounds__(1024) void bw_lidar_scan_blocks_kernel(EnvView e) {
+// adds the offset of its 1024-bucket block = the sum of the totals of the blocks before it (every block adds those up
+// itself: at most 1024 values per pass, cheaper than a launch of its own)
+__global__ __launch_bounds__(1024) void bw_lidar_scan_apply_kernel(EnvView e) {
     __shared__ int part[1024];
     const int M = e.bw_lmask + 1;
-    const int nblk = (M + 1023) / 1024;
-    int run = 0;
-    for (int base = 0; base < nblk; base += 1024) {       // one pass up to 2^20 buckets
+    int offset = 0;
+    for (int base = 0; base < (int)blockIdx.x; base += 1024) {
         const int k = base + threadIdx.x;
-        const int v = k < nblk ? e.bw_lblock[k] : 0;
-        const int incl = block_scan_1024(v, part);
-        if (k < nblk) e.bw_lblock[k] = run + incl - v;
-        run += part[1023];
+        const int v = k < (int)blockIdx.x ? e.bw_lblock[k] : 0;
+        block_scan_1024(v, part);
+        offset += part[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) e.bw_lstart[M] = run;
-}
-
-__global__ __launch_bounds__(1024) void bw_lidar_scan_apply_kernel(EnvView e) {
-    const int M = e.bw_lmask + 1;
     const int b = blockIdx.x * 1024 + threadIdx.x;
-    if (b < M) e.bw_lstart[b] += e.bw_lblock[blockIdx.x];
+    if (b < M) e.bw_lstart[b] += offset;
+    if (b == M - 1) e.bw_lstart[M] = e.N;   // every robot is in exactly one bucket
 }
 
 __global__ void bw_lidar_fill_kernel(EnvView e) {
@@ -1073,7 +1087,7 @@ __global__ void bw_lidar_fill_kernel(EnvView e) {
     if (n >= e.N) return;
     const uint32_t h = hash_cell(hash_cell_coord(e.pose[n * 3 + 0], kLidarCell), hash_cell_coord(e.pose[n * 3 + 1], kLidarCell),
                                  n / e.R) & (uint32_t)e.bw_lmask;
-    e.bw_lsorted[e.bw_lstart[h] + atomicAdd(&e.bw_lcount[h], 1)] = n;
+    e.bw_lsorted[e.bw_lstart[h] + atomicAdd(&e.bw_lcursor[h], 1)] = n;
 }
 
 // generate_train_data (model/ppo.py:122-139)
@@ -1119,11 +1133,12 @@ void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
         hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), move_lds_bytes(e), s, e, actions);
         return;
     }
+    // (the collision hash's heads and the lidar hash's counts are left clean by the tick before: bw_finish_kernel /
+    // bw_lidar_scan_local_kernel; mrca_create clears them once)
     const int bs = 256, nb = (e.N + bs - 1) / bs;
-    (void)hipMemsetAsync(e.bw_chead, 0xFF, sizeof(int32_t) * (size_t)(e.bw_cmask + 1), s);
     hipLaunchKernelGGL(bw_integrate_kernel, dim3(nb), dim3(bs), 0, s, e, actions);
     hipLaunchKernelGGL(bw_collide_kernel, dim3(nb), dim3(bs), 0, s, e);
-    hipLaunchKernelGGL(bw_finish_kernel, dim3(nb), dim3(bs), 0, s, e);
+    hipLaunchKernelGGL(bw_finish_kernel, dim3(nb), dim3(bs), 0, s, e);      // + the lidar hash's counts
 }
 
 void launch_materialize_obs(const EnvView& e, hipStream_t s) {
@@ -1134,14 +1149,13 @@ void launch_materialize_obs(const EnvView& e, hipStream_t s) {
     hipLaunchKernelGGL(materialize_obs_kernel, dim3((int)nb), dim3(256), 0, s, e);
 }
 
-void launch_lidar_grid(const EnvView& e, hipStream_t s) {
+// the lidar hash of the current poses.  counted = 1: the populations are in bw_lcount already (a tick: bw_finish_kernel)
+void launch_lidar_grid(const EnvView& e, int counted, hipStream_t s) {
     if (!e.big) return;
     const int bs = 256, nb = (e.N + bs - 1) / bs;
-    (void)hipMemsetAsync(e.bw_lcount, 0, sizeof(int32_t) * (size_t)(e.bw_lmask + 1), s);
-    hipLaunchKernelGGL(bw_lidar_count_kernel, dim3(nb), dim3(bs), 0, s, e);
+    if (!counted) hipLaunchKernelGGL(bw_lidar_count_kernel, dim3(nb), dim3(bs), 0, s, e);
     const int sb = (e.bw_lmask + 1 + 1023) / 1024;
     hipLaunchKernelGGL(bw_lidar_scan_local_kernel, dim3(sb), dim3(1024), 0, s, e);
-    hipLaunchKernelGGL(bw_lidar_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, e);
     hipLaunchKernelGGL(bw_lidar_scan_apply_kernel, dim3(sb), dim3(1024), 0, s, e);
     hipLaunchKernelGGL(bw_lidar_fill_kernel, dim3(nb), dim3(bs), 0, s, e);
 }
