@@ -223,6 +223,10 @@ int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t
  * bits 8-10 = k > 0: 1 << (k-1) beams per marching thread; bit 11: a dedicated preparation wave; bit 12: the beams of a
  * thread marched in lock step.  0 restores the product path. */
 int mrca_set_debug_flags(mrca_env* env, int32_t flags);
+/* s_memtime ticks between the move kernel's phase stamps of the last launch, averaged over worlds: [0..7] = state loaded
+ * and integrated | clearance + broad phase | patches in LDS | outline walks | ordered collision pass | reward / ballots
+ * | restarts | stores drained; [8] = entry to end.  Every stamp drains the memory queues first. */
+int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out);
 #endif
 
 #ifdef __cplusplus

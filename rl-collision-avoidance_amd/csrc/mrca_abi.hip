@@ -575,6 +575,28 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
 }
 #endif
 
+#if defined(MRCA_PROFILING)
+// Profiling build only: average s_memtime ticks between the move kernel's phase stamps (0 -> 1 ... 7 -> 8) over the worlds
+// of the LAST launch (synchronises the device).
+int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out /* [9]: 8 deltas + entry-to-end */) {
+    if (!env || !avg_ticks_out) return fail(MRCA_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(env->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    const int W = env->view.W < 4096 ? env->view.W : 4096;
+    std::vector<unsigned long long> h((size_t)10 * W);
+    mrca::read_move_stamps(h.data(), W);
+    for (int k = 0; k < 8; ++k) {
+        double sum = 0.0;
+        for (int w = 0; w < W; ++w) sum += (double)(h[(size_t)(k + 1) * W + w] - h[(size_t)k * W + w]);
+        avg_ticks_out[k] = sum / W;
+    }
+    double sum = 0.0;
+    for (int w = 0; w < W; ++w) sum += (double)(h[(size_t)8 * W + w] - h[w]);
+    avg_ticks_out[8] = sum / W;
+    return MRCA_OK;
+}
+#endif
+
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     float mv = 0.0f, ry = 0.0f;

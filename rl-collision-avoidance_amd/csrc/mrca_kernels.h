@@ -102,6 +102,9 @@ void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, con
 void launch_head_init(const EnvView& e, hipStream_t s);
 void launch_lidar_grid(const EnvView& e, int counted, hipStream_t s);   // big worlds: hash of the current poses for the ray cast
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
+#if defined(MRCA_PROFILING)
+void read_move_stamps(unsigned long long* host, int worlds);   // profiling build: s_memtime stamps of move_kernel's phases
+#endif
 void launch_materialize_obs(const EnvView& e, hipStream_t s);   // obs_ring -> obs for robots [ray_first, ray_first + ray_count)
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
                 float lam, int T, int N, float* targets, float* advs, hipStream_t s);

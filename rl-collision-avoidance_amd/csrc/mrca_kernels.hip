@@ -33,7 +33,8 @@ namespace mrca {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kPatchLoads = 16;  // independent patch-word loads a lane of move_kernel keeps in flight
+constexpr int kPatchLoads = 6;   // independent patch-word loads a thread of move_kernel keeps in flight
+constexpr int kMoveWaves = 4;    // wavefronts per world in move_kernel
 
 __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
                                               float* py, float* pth, float* gx, float* gy, float* pdist,
@@ -162,10 +163,33 @@ __global__ void materialize_obs_kernel(EnvView e) {
     }
 }
 
-__global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __restrict__ actions) {
+#if defined(MRCA_PROFILING)
+// profiling build only: s_memtime stamps of the move kernel's phases (every memory operation drained first, so that a
+// phase owns its latency), one row per world; read through mrca_debug_move_stamps (tools/ablate.py)
+constexpr int kMoveStamps = 10, kMoveStampWorlds = 4096;
+__device__ unsigned long long g_move_stamps[kMoveStamps][kMoveStampWorlds];
+#define MRCA_STAMP(k)                                                                      \
+    do {                                                                                   \
+        __builtin_amdgcn_s_waitcnt(0);                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < kMoveStampWorlds)                             \
+            g_move_stamps[k][blockIdx.x] = __builtin_amdgcn_s_memtime();                   \
+    } while (0)
+#else
+#define MRCA_STAMP(k) do { } while (0)
+#endif
+
+// kMoveWaves wavefronts per world.  Every wave loads and integrates the whole world (lane = robot: ~100 B per robot, and
+// each wave can then shuffle any robot's values without a trip through LDS); the three phases that are loops over
+// robots -- the broad phase of the collision pass, the patch loads, the outline walks -- are split across the waves;
+// wave 0 alone carries on with the ordered pass, rewards, restarts and the stores.  (One wave per world, rounds 1-2:
+// those three phases were 73 % of the kernel's chain on the Stage-2 map, profiles/r03_g_ablate.txt.)
+__global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, const float* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
+    MRCA_STAMP(0);
     const int world = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
     const bool valid = lane < e.R;
     const int n = world * e.R + (valid ? lane : 0);
 
@@ -203,6 +227,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     float ns, nc;
     sincos_det(nth, &ns, &nc);
     const bool moving = valid && ((v != 0.0f) || (w != 0.0f));
+    MRCA_STAMP(1);      // state loaded, integrated
 
     // --- outline-vs-grid test.  Skipped (same answer: free) when the coarse free-distance field says
     //     every block within the footprint's circumradius of the provisional centre is empty.  For the
@@ -231,49 +256,64 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     //     can only touch robot j if its provisional centre comes within 2 x circumradius of j's old or
     //     new centre, so only the (few) robots with such a neighbour take a turn in the ordered pass;
     //     everybody else commits straight away -- their outcome does not depend on the order.
+    int* need_list = reinterpret_cast<int*>(mini + kWave * psize);   // [64] lanes that need the walk
+    int* hit_flag = need_list + kWave;                               // [64] result per robot lane
+    int* inv_part = hit_flag + kWave;                                // [kMoveWaves][64] broad-phase partial results
     bool involved = false;
     if (!MRCA_DBG(e, 16)) {
         // every robot's old and provisional centre goes through LDS once (the patch area is free until the outline test
-        // below) and is read back as ONE broadcast 16-byte load per candidate: four v_readlane + their VALU hazards per
-        // candidate before
+        // below) and is read back as ONE broadcast 16-byte load per candidate; wave q looks at candidates q, q + 4, ...
         float4* centres = reinterpret_cast<float4*>(mini);
-        centres[lane] = make_float4(x, y, nx, ny);
+        if (wave == 0) centres[lane] = make_float4(x, y, nx, ny);
         __syncthreads();
+        bool part = false;
 #pragma unroll 4
-        for (int j = 0; j < e.R; ++j) {
+        for (int j = wave; j < e.R; j += kMoveWaves) {
             const float4 q = centres[j];
             const float ax = nx - q.x, ay = ny - q.y;
             const float bx2 = nx - q.z, by2 = ny - q.w;
             const float d_old = ax * ax + ay * ay, d_new = bx2 * bx2 + by2 * by2;
-            if (j != lane && (d_old <= e.collide_reach2 || d_new <= e.collide_reach2)) involved = true;  // (2*0.2907 + 0.001)^2
+            if (j != lane && (d_old <= e.collide_reach2 || d_new <= e.collide_reach2)) part = true;  // (2*0.2907 + 0.001)^2
         }
-        involved = involved && valid;
-        __syncthreads();   // the patches below reuse this LDS
+        inv_part[wave * kWave + lane] = (part && valid) ? 1 : 0;
+        __syncthreads();   // ... which also ends the reads of `centres`: the patches below reuse this LDS
+        int any = 0;
+#pragma unroll
+        for (int q = 0; q < kMoveWaves; ++q) any |= inv_part[q * kWave + lane];
+        involved = any != 0;
     }
+    MRCA_STAMP(2);      // clearance byte + field entry loaded, broad phase done
     const bool need = check_map && !(inside && clearance > hc);
-    // the robots that need the walk, compacted; then ALL their patches in as few memory round trips as the lanes'
-    // load queues allow: (robot, word) pairs are dealt round-robin to the lanes, kPatchLoads independent loads per
-    // lane in flight (a Stage-2 world keeps ~30 of its 44 robots near walls: 30 words each -- round 2 fetched four
-    // robots per round trip, eight dependent trips)
-    int* need_list = reinterpret_cast<int*>(mini + kWave * psize);   // [64] lanes that need the walk
-    int* hit_flag = need_list + kWave;                               // [64] result per robot lane
-    const unsigned long long need_mask = __ballot(need);
-    if (need) need_list[__popcll(need_mask & ((1ull << lane) - 1ull))] = lane;
-    hit_flag[lane] = 0;
-    __syncthreads();  // one wave per block: orders the LDS writes before the reads below
+    // the robots that need the walk, compacted; then ALL their patches in one or two memory round trips: (robot, word)
+    // pairs are dealt round-robin to the block's threads, kPatchLoads independent loads per thread in flight (a Stage-2
+    // world keeps ~30 of its 44 robots near walls, 30 words each -- round 2 fetched four robots per round trip)
+    const unsigned long long need_mask = __ballot(need);             // identical in every wave
+    const int n_need = __popcll(need_mask);
+    if (wave == 0) {
+        if (need) need_list[__popcll(need_mask & ((1ull << lane) - 1ull))] = lane;
+        hit_flag[lane] = 0;
+    }
+    __syncthreads();
     {
-        const int total = __popcll(need_mask) * psize;
-        for (int k0 = 0; k0 < total; k0 += kWave * kPatchLoads) {
+        const int total = n_need * psize;
+        const float inv_psize = 1.0f / (float)psize, inv_pwords = 1.0f / (float)pwords;
+        for (int k0 = 0; k0 < total; k0 += kWave * kMoveWaves * kPatchLoads) {
             uint32_t val[kPatchLoads];
             int dst[kPatchLoads];
 #pragma unroll
             for (int u = 0; u < kPatchLoads; ++u) {
-                const int idx = k0 + u * kWave + lane;
+                const int idx = k0 + u * kWave * kMoveWaves + tid;
                 const bool on = idx < total;
-                const int q = on ? idx / psize : 0;
+                // idx / psize and k / pwords by float reciprocal + one correction step (all operands < 2^24)
+                int q = on ? (int)((float)idx * inv_psize) : 0;
+                q -= (q * psize > idx) ? 1 : 0;
+                q += ((q + 1) * psize <= idx && on) ? 1 : 0;
                 const int k = idx - q * psize;
-                const int src = need_list[q];
-                const int r = k / pwords, wi = k - r * pwords;
+                int r = (int)((float)k * inv_pwords);
+                r -= (r * pwords > k) ? 1 : 0;
+                r += ((r + 1) * pwords <= k) ? 1 : 0;
+                const int wi = k - r * pwords;
+                const int src = need_list[on ? q : 0];
                 const int gy = __shfl(py0, src, kWave) + r;
                 const int gw = __shfl(pw0, src, kWave) + wi;
                 val[u] = 0u;
@@ -285,12 +325,12 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
                 if (dst[u] >= 0) mini[dst[u]] = val[u];
         }
     }
-    // outline walks, four lanes per robot (one per edge, 16 robots per pass): a walk is a chain of
-    // dependent LDS reads, so spreading the edges over lanes cuts the chain by four
     __syncthreads();
-    const int n_need = __popcll(need_mask);
-    for (int base = 0; base < n_need; base += 16) {
-        const int q = base + (lane >> 2);
+    MRCA_STAMP(3);      // patches in LDS
+    // outline walks, four lanes per robot (one per edge): a walk is a chain of dependent LDS reads, so spreading the
+    // edges over lanes cuts the chain by four; 64 robots per pass over the block's threads
+    for (int base = 0; base < n_need; base += kWave * kMoveWaves / 4) {
+        const int q = base + (tid >> 2);
         const bool act = q < n_need;
         const int src = act ? need_list[q] : 0;
         const float sx_ = __shfl(nx, src, kWave), sy_ = __shfl(ny, src, kWave);
@@ -298,17 +338,19 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         const int sy0 = __shfl(py0, src, kWave), sw0 = __shfl(pw0, src, kWave);
         if (act) {
             const MiniGrid mg{mini + src * psize, sy0, sw0, pwords};
-            if (static_edge_hit(mg, e.g, sx_, sy_, ss_, sc_, lane & 3)) hit_flag[src] = 1;
+            if (static_edge_hit(mg, e.g, sx_, sy_, ss_, sc_, tid & 3)) hit_flag[src] = 1;
         }
     }
     __syncthreads();
+    if (wave != 0) return;      // the helpers are done; wave 0 carries the rest of the tick
     const bool shit = need && hit_flag[lane] != 0;
+    MRCA_STAMP(4);      // outline walks done
 
     // --- fidelity mode (collision_raster): robots collide when their OUTLINES SHARE A RASTER CELL (Stage's rule) instead
     //     of when their rectangles overlap.  Every robot's current outline cells live in LDS; a robot that commits a
     //     move inside the ordered pass replaces its own.
     const bool raster = e.raster_inv > 0.0f;
-    long long* cur_cells = reinterpret_cast<long long*>(hit_flag + kWave);      // [64][kMaxOutlineCells]
+    long long* cur_cells = reinterpret_cast<long long*>(inv_part + kMoveWaves * kWave);   // [64][kMaxOutlineCells]
     int* cur_n = reinterpret_cast<int*>(cur_cells + kWave * kMaxOutlineCells);   // [64]
     long long* turn_cells = reinterpret_cast<long long*>(cur_n + kWave);         // [kMaxOutlineCells]
     int* turn_n = reinterpret_cast<int*>(turn_cells + kMaxOutlineCells);
@@ -374,6 +416,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         }
     }
 
+    MRCA_STAMP(5);      // ordered collision pass done
     // GT velocity = finite difference of the pose (stageros.cpp:585-590)
     const float vgt = moved ? fabsf(v) : 0.0f;
     const float wgt = moved ? w : 0.0f;
@@ -418,6 +461,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
     }
     float spv = v, spw = w, ovgt = vgt, owgt = wgt;
     if (MRCA_DBG(e, 32)) fresh = false;
+    MRCA_STAMP(6);      // reward / terminal / group ballots done
     // new episodes, one robot at a time with the whole wave sampling for it
     unsigned long long pending = __ballot(fresh);
     while (pending) {
@@ -469,6 +513,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         }
     }
 
+    MRCA_STAMP(7);      // restarts done
     if (valid) {
         e.pose[n * 3 + 0] = x;
         e.pose[n * 3 + 1] = y;
@@ -491,6 +536,7 @@ __global__ __launch_bounds__(kWave) void move_kernel(EnvView e, const float* __r
         e.fresh[n] = fresh ? 1 : 0;
         e.head[n] = make_float4(s, c, __uint_as_float(cellv), 0.0f);
     }
+    MRCA_STAMP(8);      // stores drained
 }
 
 __device__ __forceinline__ void write_head(const EnvView& e, int n, float x, float y, float th) {
@@ -1114,6 +1160,15 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 
 }  // namespace
 
+#if defined(MRCA_PROFILING)
+void read_move_stamps(unsigned long long* host, int worlds) {      // [kMoveStamps][worlds]
+    for (int k = 0; k < kMoveStamps; ++k)
+        (void)hipMemcpyFromSymbol(host + (size_t)k * worlds, HIP_SYMBOL(g_move_stamps), sizeof(unsigned long long) * worlds,
+                                  sizeof(unsigned long long) * ((size_t)k * kMoveStampWorlds), hipMemcpyDeviceToHost);
+}
+#endif
+
+
 size_t ray_lds_bytes(const EnvView& e) {
     return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 8;
 }
@@ -1121,7 +1176,7 @@ size_t ray_lds_bytes(const EnvView& e) {
 size_t move_lds_bytes(const EnvView& e) {
     const int rows = 2 * e.foot_hc + 1;
     const int words = (rows + 31) / 32 + 1;
-    size_t b = (size_t)kWave * rows * words * 4 + 2 * kWave * sizeof(int);
+    size_t b = (size_t)kWave * rows * words * 4 + (2 + kMoveWaves) * kWave * sizeof(int);
     if (e.raster_inv > 0.0f)   // outline cells of every robot + of the robot taking its turn (fidelity mode)
         b = (b + 7) / 8 * 8 + (size_t)(kWave + 1) * kMaxOutlineCells * sizeof(long long) + (kWave + 2) * sizeof(int);
     return b;
@@ -1130,7 +1185,7 @@ size_t move_lds_bytes(const EnvView& e) {
 // blocks of 64 threads x 4 float4 columns per pass for the frame-stack shift that rides behind the move kernel
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
     if (!e.big) {
-        hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave), move_lds_bytes(e), s, e, actions);
+        hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e, actions);
         return;
     }
     // (the collision hash's heads and the lidar hash's counts are left clean by the tick before: bw_finish_kernel /

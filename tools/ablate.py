@@ -52,4 +52,19 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
         print(f"{name:<14} flags={flags:<5} {label:<52} ray {ry / n * 1e3:8.1f} us   move {mv / n * 1e3:7.1f} us   "
               f"sum {(ry + mv) / n * 1e3:7.1f} us")
     env.set_debug_flags(0)
+    # where the move kernel's chain goes: s_memtime stamps of its phases (averaged over the worlds of one launch)
+    import ctypes as C
+    for k in range(20):
+        env.step(pool[k % 8])
+    ticks = (C.c_double * 9)()
+    acc = [0.0] * 9
+    for k in range(16):
+        env.step(pool[k % 8])
+        _lib.check(env.lib.mrca_debug_move_stamps(env._h, ticks), "mrca_debug_move_stamps")
+        acc = [a + t for a, t in zip(acc, ticks)]
+    names = ("state loaded + integrated", "clearance load + broad phase", "patches to LDS", "outline walks",
+             "ordered collision pass", "reward / terminal / group ballots", "restarts", "stores drained", "entry -> end")
+    print(f"{name:<14} move kernel phases (s_memtime ticks, memory drained at every stamp, mean of 16 launches):")
+    for nm, a in zip(names, acc):
+        print(f"{'':<14}   {nm:<36} {a / 16:9.1f} ticks  {100.0 * a / acc[8]:5.1f} %")
     env.close()
