@@ -197,6 +197,24 @@ int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32
                         const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
                         float* feat_dev, void* stream);
 
+/* The rest of the rollout inference behind fc1 in one kernel (model/net.py:41-55,61-70: ReLU, cat with goal and speed,
+ * fc2 + ReLU of both towers, actor1 / actor2 / critic heads with sigmoid / tanh; model/ppo.py:57-82 generate_action:
+ * a = mean + exp(logstd) * noise, log-density, clip to the action bounds).  fp32, exact-fp32 MFMA for fc2.
+ *   h1_dev    f32[2,N,256]  act_fc1 / crt_fc1 outputs INCLUDING their bias, before the ReLU (tower-major)
+ *   goal_dev  f32[N,2]  speed_dev f32[N,2]          MRCA_F_LOCAL_GOAL, MRCA_F_SPEED
+ *   fc2_w_dev f32[2,260,128] (input-major: act_fc2.weight^T, crt_fc2.weight^T)   fc2_b_dev f32[2,128]
+ *   head_w_dev f32[128,2] (columns actor1.weight, actor2.weight)  head_b_dev f32[2]  critic_w_dev f32[128]  critic_b_dev f32[1]
+ *   logstd_dev f32[2]   noise_dev f32[N,2] standard normal draws, or NULL: the deterministic mean action
+ *                       (generate_action_no_sampling, model/ppo.py:84-107)
+ *   lo_dev, hi_dev f32[2]   the action bounds (ppo_stage1.py:170)
+ *   out: value_dev f32[N], action_dev f32[N,2] (UNclipped sample: what the rollout buffer stores), logprob_dev f32[N],
+ *        scaled_dev f32[N,2] (clipped: what drives the robot), mean_dev f32[N,2] */
+int mrca_policy_tail(const float* h1_dev, const float* goal_dev, const float* speed_dev, int32_t n_robots,
+                     const float* fc2_w_dev, const float* fc2_b_dev, const float* head_w_dev, const float* head_b_dev,
+                     const float* critic_w_dev, const float* critic_b_dev, const float* logstd_dev, const float* noise_dev,
+                     const float* lo_dev, const float* hi_dev, float* value_dev, float* action_dev, float* logprob_dev,
+                     float* scaled_dev, float* mean_dev, void* stream);
+
 /* Backward pass of the same front end for the PPO update (model/ppo.py:158-192 back-propagates the loss through
  * act_fea_cv1/2 and crt_fea_cv1/2 of model/net.py:19-25 for every minibatch): given the gradient with respect to the
  * forward kernel's output it returns the gradients of both towers' convolution weights and biases; h1 is recomputed,

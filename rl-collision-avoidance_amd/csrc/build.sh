@@ -17,6 +17,6 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
     -Wall -Wno-unused-function "${extra[@]}" \
-    "${here}/mrca_kernels.hip" "${here}/mrca_abi.hip" "${here}/mrca_policy.hip" "${here}/mrca_policy_bwd.hip" \
+    "${here}/mrca_kernels.hip" "${here}/mrca_abi.hip" "${here}/mrca_policy.hip" "${here}/mrca_policy_bwd.hip" "${here}/mrca_policy_tail.hip" \
     -o "${out}" "$@"
 echo "built ${out}"

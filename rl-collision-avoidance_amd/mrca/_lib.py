@@ -21,7 +21,8 @@ FIELDS = [  # order = enum mrca_field
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
            "mrca_step", "mrca_step_slice", "mrca_materialize_obs", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
-           "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward"]
+           "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
+           "mrca_policy_tail"]
 
 
 class MrcaConfig(C.Structure):
@@ -73,6 +74,7 @@ def load(path=None):
     lib.mrca_lidar_features_backward_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + \
         [C.c_size_t, C.c_void_p]
+    lib.mrca_policy_tail.argtypes = [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 16
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only
         lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]

@@ -107,6 +107,9 @@ class CNNPolicy(nn.Module):
                 "fc2_b": st(self.act_fc2.bias, self.crt_fc2.bias).unsqueeze(1),      # [2, 1, 128]
                 "head_w": torch.cat([self.actor1.weight, self.actor2.weight]).detach().t().contiguous(),   # [128, 2]
                 "head_b": torch.cat([self.actor1.bias, self.actor2.bias]).detach(),
+                "critic_w": self.critic.weight.detach().reshape(-1).contiguous(),     # [128]
+                "critic_b": self.critic.bias.detach().reshape(1).contiguous(),
+                "logstd": self.logstd.detach().reshape(-1).contiguous(),
             }
             old = getattr(self, "_rc", None)
             if old is not None and all(old[k].shape == v.shape and old[k].device == v.device for k, v in new.items()):
@@ -132,6 +135,20 @@ class CNNPolicy(nn.Module):
             mean = torch.stack((torch.sigmoid(m[:, 0]), torch.tanh(m[:, 1])), dim=-1)
             v = self.critic(h[1])
         return mean, v
+
+    def act_fused(self, x, goal, speed, noise, lo, hi, head=None):
+        """generate_action for the rollout in three launches: the conv front end of both towers (csrc/mrca_policy.hip),
+        fc1 of both towers as one batched fp32 GEMM, and everything behind it -- ReLU, cat, fc2, heads, sample, logprob,
+        clip -- in csrc/mrca_policy_tail.hip.  ``noise`` f32[N,2] standard normal draws or None (mean action).
+        -> value [N,1], action [N,2], logprob [N,1], scaled [N,2], mean [N,2].  fp32; differs from the stock path by
+        summation order only (tests/test_gpu_policy_ops.py)."""
+        from . import policy_ops
+        rc = getattr(self, "_rc", None) or self.refresh_rollout_cache()
+        with torch.no_grad():
+            feat = policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head)   # [2, N, 4096]
+            h1 = torch.baddbmm(rc["fc1_b"], feat, rc["fc1_w"])                                        # [2, N, 256], pre-ReLU
+            return policy_ops.policy_tail(h1, goal.contiguous(), speed.contiguous(), rc["fc2_w"], rc["fc2_b"], rc["head_w"],
+                                          rc["head_b"], rc["critic_w"], rc["critic_b"], rc["logstd"], noise, lo, hi)
 
     def forward(self, x, goal, speed, generator=None):
         """-> (value, sampled action, logprob, mean)   (model/net.py:37-70)"""

@@ -34,6 +34,35 @@ def lidar_features(obs, w1, b1, w2, b2, out=None, head=None):
     return out
 
 
+def policy_tail(h1, goal, speed, fc2_w, fc2_b, head_w, head_b, critic_w, critic_b, logstd, noise, lo, hi):
+    """Everything of the rollout inference behind fc1 in one launch (include/mrca_env.h: mrca_policy_tail).
+    h1 f32[2,N,256] = fc1 outputs with bias, before the ReLU.  noise f32[N,2] or None (deterministic mean action).
+    -> value [N,1], action [N,2], logprob [N,1], scaled [N,2], mean [N,2]"""
+    lib = _lib.load()
+    N = h1.shape[1]
+    dev = h1.device
+    tensors = [h1, goal, speed, fc2_w, fc2_b, head_w, head_b, critic_w, critic_b, logstd, lo, hi] + ([] if noise is None else [noise])
+    shapes = [(2, N, 256), (N, 2), (N, 2), (2, 260, 128), None, (128, 2), (2,), None, None, (2,), (2,), (2,)] + ([] if noise is None else [(N, 2)])
+    for t, shp in zip(tensors, shapes):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and (shp is None or tuple(t.shape) == shp)):
+            raise ValueError(f"policy_tail: expected a contiguous cuda float32 tensor of shape {shp}, got {tuple(t.shape)} {t.dtype}")
+    if fc2_b.numel() != 256 or critic_w.numel() != 128 or critic_b.numel() != 1:
+        raise ValueError("policy_tail: fc2_b / critic_w / critic_b sizes")
+    value = torch.empty(N, 1, dtype=torch.float32, device=dev)
+    action = torch.empty(N, 2, dtype=torch.float32, device=dev)
+    logprob = torch.empty(N, 1, dtype=torch.float32, device=dev)
+    scaled = torch.empty(N, 2, dtype=torch.float32, device=dev)
+    mean = torch.empty(N, 2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.mrca_policy_tail(h1.data_ptr(), goal.data_ptr(), speed.data_ptr(), N, fc2_w.data_ptr(), fc2_b.data_ptr(),
+                                        head_w.data_ptr(), head_b.data_ptr(), critic_w.data_ptr(), critic_b.data_ptr(),
+                                        logstd.data_ptr(), None if noise is None else noise.data_ptr(), lo.data_ptr(),
+                                        hi.data_ptr(), value.data_ptr(), action.data_ptr(), logprob.data_ptr(),
+                                        scaled.data_ptr(), mean.data_ptr(), stream), "mrca_policy_tail")
+    return value, action, logprob, scaled, mean
+
+
 _scratch = {}
 
 

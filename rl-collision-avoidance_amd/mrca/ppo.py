@@ -33,6 +33,11 @@ def generate_action(policy, obs, goal, speed, action_bound, generator=None, auto
     from .net import gaussian_logprob
     if obs_head is not None and not fused:
         raise ValueError("a frame ring (obs_head) can only be read by the fused policy path")
+    if fused and hasattr(policy, "act_fused"):
+        lo, hi = _bounds(action_bound, goal.device, torch.float32)
+        noise = torch.randn((goal.shape[0], 2), device=goal.device, dtype=torch.float32, generator=generator)
+        v, a, logprob, scaled, _mean = policy.act_fused(obs, goal, speed, noise, lo, hi, head=obs_head)
+        return v, a, logprob, scaled
     with torch.no_grad():
         if fused:
             mean, v = policy.mean_value_fused(obs, goal, speed, head=obs_head)
@@ -61,6 +66,10 @@ def policy_input(env, fused):
 
 def generate_action_no_sampling(policy, obs, goal, speed, action_bound, fused=False, obs_head=None):
     """model/ppo.py:84-107: deterministic mean action (circle_test.py:58-59)."""
+    if fused and hasattr(policy, "act_fused"):
+        lo, hi = _bounds(action_bound, goal.device, torch.float32)
+        _v, _a, _lp, scaled, mean = policy.act_fused(obs, goal, speed, None, lo, hi, head=obs_head)
+        return mean, scaled
     with torch.no_grad():
         mean, _v = policy.mean_value_fused(obs, goal, speed, head=obs_head) if fused else policy.mean_value(obs, goal, speed)
         lo, hi = _bounds(action_bound, mean.device, mean.dtype)

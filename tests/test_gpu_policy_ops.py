@@ -171,3 +171,35 @@ def test_front_end_reads_the_envs_frame_ring_in_place(pol):
         assert torch.equal(m0, m1) and torch.equal(v0, v1)
     assert seen_heads == {0, 1, 2}
     env.close()
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 4096])
+def test_act_fused_equals_the_stock_generate_action(pol, n):
+    """The three-launch rollout inference (conv front end, batched fc1 GEMM, mrca_policy_tail) against the stock PyTorch
+    layers with the SAME noise draws: value, unclipped action, log-probability and clipped action to fp32 summation
+    order; and the deterministic mean action of generate_action_no_sampling."""
+    from mrca import ppo
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.rand(n, 3, 512, device="cuda", generator=g) - 0.5
+    goal = torch.rand(n, 2, device="cuda", generator=g) * 20 - 10
+    speed = torch.rand(n, 2, device="cuda", generator=g)
+    bound = ((0.0, -1.0), (1.0, 1.0))
+    with torch.no_grad():
+        pol.logstd.copy_(torch.tensor([-0.3, 0.2], device="cuda"))
+    pol.refresh_rollout_cache()
+    g0 = torch.Generator(device="cuda").manual_seed(77)
+    g1 = torch.Generator(device="cuda").manual_seed(77)
+    v0, a0, lp0, s0 = ppo.generate_action(pol, x, goal, speed, bound, g0, fused=False)
+    v1, a1, lp1, s1 = ppo.generate_action(pol, x, goal, speed, bound, g1, fused=True)
+    assert v1.shape == v0.shape == (n, 1) and a1.shape == (n, 2) and lp1.shape == lp0.shape == (n, 1) and s1.shape == (n, 2)
+    assert float((v0 - v1).abs().max()) < 1e-4 * max(1.0, float(v0.abs().max()))
+    assert float((a0 - a1).abs().max()) < 1e-5
+    assert float((lp0 - lp1).abs().max()) < 1e-4
+    assert float((s0 - s1).abs().max()) < 1e-5
+    assert float(s1[:, 0].min()) >= 0.0 and float(s1[:, 0].max()) <= 1.0 and float(s1[:, 1].abs().max()) <= 1.0
+    m0, sc0 = ppo.generate_action_no_sampling(pol, x, goal, speed, bound, fused=False)
+    m1, sc1 = ppo.generate_action_no_sampling(pol, x, goal, speed, bound, fused=True)
+    assert float((m0 - m1).abs().max()) < 1e-5 and float((sc0 - sc1).abs().max()) < 1e-5
+    with torch.no_grad():
+        pol.logstd.zero_()
+    pol.refresh_rollout_cache()
