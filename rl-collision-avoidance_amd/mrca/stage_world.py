@@ -101,6 +101,17 @@ class SharedWorld:
             self.ticks += 1
             self.cache.clear()
 
+    def reset_positions(self):
+        """The ``reset_positions`` service (stageros.cpp:260-269): every model back at its world-file pose
+        (worlds/*.world agent lines), stall flags cleared; goals stay."""
+        with self.lock:
+            table = S.load_tables()[self.variant]["world_agents"]
+            poses = np.asarray(table, np.float32)[: self.num_env].copy()
+            poses[:, 2] = np.arctan2(np.sin(poses[:, 2]), np.cos(poses[:, 2]))
+            goals = self.field("goal").astype(np.float32).copy()
+            self.backend.reset(np.ones(self.num_env, np.uint8), poses, goals)
+            self.cache.clear()
+
     def teleport(self, index, pose=None, goal=None):
         with self.lock:
             mask = np.zeros(self.num_env, np.uint8)
@@ -206,7 +217,9 @@ class StageWorldBase:
         self.world.teleport(self.index, pose=[pose[0], pose[1], th])
 
     def reset_world(self):
-        """reset_positions (stageros.cpp:260-269): initial world-file poses, stall cleared."""
+        """stage_world1.py:162-168: the reset_positions service (stageros.cpp:260-269: every model back at its world-file
+        pose, stall flags cleared), then the bookkeeping fields."""
+        self.world.reset_positions()
         self.self_speed = [0.0, 0.0]
         self.step_goal = [0.0, 0.0]
         self.step_r_cnt = 0.0

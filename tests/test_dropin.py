@@ -17,7 +17,7 @@ import torch
 
 import util as U
 
-REF = "/root/reference"
+REF = os.environ.get("MRCA_REFERENCE", "/root/reference")     # wherever a checkout of the reference exists
 MINI = os.path.join(U.ROOT, "tests", "dropin_script_mini.py")
 
 
@@ -67,6 +67,27 @@ def test_unchanged_ppo_stage1_runs_through_an_update(monkeypatch):
     assert np.isfinite(vals).all()
     out_logs = glob.glob(os.path.join(tmp, "log", "*", "output.log"))
     assert out_logs
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ppo_stage1.py")),
+                    reason="reference checkout absent (point MRCA_REFERENCE at one to run the unchanged script on the GPU)")
+def test_unchanged_ppo_stage1_on_the_hip_backend():
+    """The UNCHANGED ppo_stage1.py (24 rank threads, its own model/ppo.py and model/net.py with real .cuda() calls) on the
+    product backend: HipBackend <-> reference script, through one PPO update."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    from mrca import spmd, stage_world
+    stage_world.set_backend_factory(None)          # the product default: mrca.stage_world.HipBackend
+    tmp = tempfile.mkdtemp()
+    errs = spmd.run_script(os.path.join(REF, "ppo_stage1.py"), 24, max_ticks=132, chdir=tmp)
+    assert not errs, errs
+    ppo_logs = glob.glob(os.path.join(tmp, "log", "*", "ppo.log"))
+    lines = [ln for ln in open(ppo_logs[0]).read().splitlines() if ln.strip()]
+    assert len(lines) >= 6
+    assert np.isfinite(np.array([[float(x) for x in ln.split(",")] for ln in lines[:6]])).all()
 
 
 @pytest.mark.gpu
