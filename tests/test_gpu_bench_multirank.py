@@ -88,3 +88,50 @@ def test_bench_single_rank_json_contract():
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert j["vs_baseline"] is None and j["data"] == "synthetic" and "workload" in j["config"]
+
+
+@pytest.mark.gpu
+def test_two_envs_on_two_devices_in_one_process():
+    """Two envs, the policy ops and the GAE kernel on two GPUs of ONE process while the caller's current device stays
+    cuda:0: every entry point launches where its buffers live (per-device launch state, device guards keyed on the
+    pointers).  Skips below two GPUs -- the first multi-GPU box runs it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import __graft_entry__ as g
+    g.build()
+    from mrca import policy_ops, ppo, scenario as S
+    from mrca.net import CNNPolicy
+    from mrca.vec_env import VecStageWorld
+    torch.cuda.set_device(0)
+    sc = S.stage1(num_worlds=4, robots_per_world=24, seed=3)
+    envs = [VecStageWorld(sc, device=f"cuda:{d}") for d in (0, 1)]
+    gen = torch.Generator().manual_seed(0)
+    for e in envs:
+        e.reset()
+    for _ in range(5):
+        a = torch.stack([torch.rand(sc.num_robots, generator=gen), torch.rand(sc.num_robots, generator=gen) * 2 - 1], 1)
+        for e in envs:
+            e.step(a.to(e.device).contiguous())
+    for f in ("pose", "scan", "obs", "reward", "done", "local_goal"):
+        assert torch.equal(getattr(envs[0], f).cpu(), getattr(envs[1], f).cpu()), f
+    torch.manual_seed(1)
+    pols = [CNNPolicy(3, 2).to(f"cuda:{d}") for d in (0, 1)]
+    pols[1].load_state_dict(pols[0].state_dict())
+    outs = []
+    for e, p in zip(envs, pols):                       # current device is still cuda:0
+        ring, head = e.policy_obs()
+        lo, hi = (torch.tensor(b, device=e.device) for b in ((0.0, -1.0), (1.0, 1.0)))
+        outs.append([t.cpu() for t in p.act_fused(ring, e.local_goal, e.speed, None, lo, hi, head=head)])
+        t, adv = ppo.generate_train_data(torch.rand(8, e.N, device=e.device), 0.99, torch.rand(8, e.N, device=e.device),
+                                         torch.rand(e.N, device=e.device),
+                                         torch.zeros(8, e.N, dtype=torch.uint8, device=e.device), 0.95)
+        assert t.device == e.device and bool(torch.isfinite(t).all())
+        p.fused_train = True
+        v, lp, ent = p.evaluate_actions(e.obs, e.local_goal, e.speed, torch.rand(e.N, 2, device=e.device))
+        (lp.mean() + v.pow(2).mean()).backward()
+        assert bool(torch.isfinite(p.act_fea_cv1.weight.grad).all())
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, atol=1e-6)
+    assert torch.cuda.current_device() == 0
+    for e in envs:
+        e.close()

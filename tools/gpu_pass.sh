@@ -12,6 +12,7 @@
 #   prof_train       rocprofv3 --kernel-trace --stats of bench.py --mode train (one update)
 #   prof_rollout     rocprofv3 --kernel-trace --stats of bench.py --mode rollout --no-graph
 #   sq               tools/pmc_profile.sh (SQ counter sets of the env kernels)
+#   pmc_policy       SQ counter sets of the policy's forward / backward kernels (tools/update_bench.py 16384)
 #   bigworld         tools/bigworld_bench.py
 #   prof_bigworld    rocprofv3 --kernel-trace --stats of tools/bigworld_bench.py (BIGWORLD_ARGS: robot counts)
 #   circle           mrca.evaluate of the committed checkpoints (POLICY=... overrides)
@@ -72,6 +73,19 @@ for STAGE in "$@"; do
     sq)
       TAG="${TAG}_sq" timeout 900 bash tools/pmc_profile.sh > "$O/pmc_sq.log" 2>&1; cp "gpurun_out/pmc_${TAG}_sq/summary.txt" "$O/pmc_sq_summary.txt" 2>/dev/null
       grep -E "raycast|move_kernel" "$O/pmc_sq_summary.txt" | head -60 | cut -c1-200 ;;
+    pmc_policy)
+      # SQ counters of the policy's forward / backward kernels (counters only: no extra trace domains)
+      cd /tmp; i=0
+      for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+                 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_LDS" \
+                 "SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU" \
+                 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "GRBM_GUI_ACTIVE"; do
+        i=$((i+1))
+        timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$O/pmc_policy" -o "set$i" -- python "$R/tools/update_bench.py" 16384 > "$O/pmc_policy_set$i.log" 2>&1; echo "set $i ($SET) rc=$?"
+      done
+      cd "$R"
+      python tools/pmc_summary.py "$O/pmc_policy" > "$O/pmc_policy_summary.txt" 2>&1; grep -E "lidar_features|policy_tail" "$O/pmc_policy_summary.txt" | cut -c1-200 | head -40
+      rm -rf "$O/pmc_policy" ;;
     bigworld)
       timeout 900 python tools/bigworld_bench.py ${BIGWORLD_ARGS:-} 2>&1 | flt | tee "$O/bigworld.jsonl" | cut -c1-300 ;;
     prof_bigworld)
