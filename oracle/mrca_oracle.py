@@ -5,7 +5,7 @@ this module, and only as the checker / the reported CPU baseline.  The product p
 (``rl-collision-avoidance_amd/``) never imports it and has no CPU fallback.
 
 PARITY STATUS
-  * env tick (kinematics / collision / ray cast): **parity unpinned**.  The arithmetic lives in
+  * env tick, libstage half (kinematics / collision / ray cast): **parity unpinned**.  The arithmetic lives in
     libstage (un-vendored, no version pin: stage_ros-add_pose_and_crash/package.xml:25,35;
     "Stage 4.1.1" per stageros.cpp:346,814), which is not under /root/reference, and the
     reference holds no golden vectors for it.  This file *restates* the published
@@ -13,8 +13,11 @@ PARITY STATUS
     The four qualitative rostest assertions the reference does hold
     (stage_ros-add_pose_and_crash/test/cmdpose_tests.py:87-203) are restated in
     tests/test_oracle_invariants.py.
-  * reward / observation / local goal / reset distributions: follow the reference's Python
-    exactly (citations on each function).
+  * env tick, Python half (reward / terminal, observation, local goal, episode set-up, reset
+    distributions): follows the reference's Python line by line (citations on each function) and is
+    PINNED by golden vectors made by running the reference's own stage_world1.py / stage_world2.py /
+    circle_world.py (tools/make_golden_env.py -> tests/golden/env_python_*.npz; fp64 mode == reference
+    to 1e-12, tests/test_golden_env.py).
   * GAE / filter-index / policy: pinned against the reference's own importable functions
     (tests/golden/, tools/make_golden.py).
 
