@@ -2,9 +2,14 @@
 
 Every rank holds the WHOLE world and owns a contiguous slice of its robots.  Per tick there is exactly one
 exchange step: an all-gather of the commands ``act[N,2]`` (400 kB at 50 000 robots).  Each rank then advances all
-robots -- the collision pass is sequential in robot order and needs every provisional pose, it costs ~1 % of a tick,
-and identical arithmetic on identical inputs keeps the replicas bit-identical, so no pose ever has to travel --
-and casts the 512-beam lidar only for its own slice (``mrca_step_slice``), which is where the time goes.
+robots -- the collision pass is sequential in robot order and needs every provisional pose, and identical arithmetic
+on identical inputs keeps the replicas bit-identical, so no pose ever has to travel -- and casts the 512-beam lidar only
+for its own slice (``mrca_step_slice``).
+
+The replicated move phase is what bounds the speed-up (Amdahl): at 50 000 robots it is 69 us of a 579 us tick on one
+MI355X, so 8 GPUs can give at most 4.4x on this design and one rank's share of 8 measures 3.85x
+(``tools/bigworld_bench.py --shards 8``, profiles/r03_f_bigworld_shards8.jsonl).  Sharding the move phase
+too would need a halo exchange of provisional poses inside the ordered collision pass -- not built.
 """
 import torch
 
