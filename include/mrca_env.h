@@ -121,6 +121,12 @@ typedef struct mrca_config {
      * stack per call, what a caller written against ABI 2 expects.  1: only mrca_materialize_obs() does that; callers
      * that read MRCA_F_OBS_RING + MRCA_F_OBS_HEAD (mrca_lidar_features does) never pay for it. */
     int32_t lazy_obs;
+    /* ABI 3, fidelity.  0: a robot that is not acting any more (MRCA_F_LIVE = 0: finished, waiting for its group,
+     * ppo_stage2.py:72-107) is commanded (0, 0), and MRCA_F_SPEED restarts at 0 with every episode.  1: what stageros
+     * does -- SetSpeed persists (stageros.cpp:272-280; the watchdog of :466-471 is global and the other robots keep it
+     * fed): such a robot keeps driving at the last command it was given, still collides and is still seen, and the odom
+     * twist get_self_speed reads (stage_world1.py:106-108,146-147) survives reset_pose's teleport. */
+    int32_t hold_velocity;
 } mrca_config;
 
 /* Bytes of device arena an env with this config needs (256-byte granules). */

@@ -357,7 +357,7 @@ class OracleConfig:
     def __init__(self, num_worlds, robots_per_world, grid, *, timeout=150, w_thresh=1.05,
                  pre_dist_zero=False, auto_reset=AUTO_ROBOT, seed=0, reset_mode=None,
                  init_table=None, goal_table=None, group_id=None, beams=BEAMS, frames=3, first_world=0,
-                 collision_raster=0.0):
+                 collision_raster=0.0, hold_velocity=False):
         self.W, self.R = int(num_worlds), int(robots_per_world)
         self.grid = grid
         self.timeout, self.w_thresh = int(timeout), float(w_thresh)
@@ -370,6 +370,10 @@ class OracleConfig:
         self.group_id = np.zeros(R, np.int32) if group_id is None else np.asarray(group_id, np.int32)
         self.beams, self.frames = int(beams), int(frames)
         self.first_world = int(first_world)   # simulate worlds [first_world, first_world+W) of a larger batch
+        # fidelity: Stage keeps the last SetSpeed (stageros.cpp:272-280) -- a robot that is no longer commanded (dead,
+        # ppo_stage2.py:72-74 sends nothing for it) keeps driving at it, and get_self_speed (the odom twist) still shows
+        # it after reset_pose's teleport.  False: dead robots idle, the speed input restarts at 0
+        self.hold_velocity = bool(hold_velocity)
         self.collision_raster = float(collision_raster)   # fidelity mode: > 0 = Stage-like raster collision between robots
 
 
@@ -504,7 +508,8 @@ class OracleEnv:
         self.t[idx] = 1
         self.crashed[idx] = 0
         self.live[idx] = 1
-        self.speed[idx] = 0
+        if not self.cfg.hold_velocity:
+            self.speed[idx] = 0
         self.speed_gt[idx] = 0
 
     def reset(self, mask=None, poses=None, goals=None):
@@ -533,8 +538,9 @@ class OracleEnv:
         act = np.asarray(actions, dtype=f).reshape(N, 2)
         act = np.where(np.isfinite(act), act, f(0.0)).astype(f)   # a non-finite command idles the robot
         live = self.live.astype(bool)
-        v = np.where(live, act[:, 0], f(0.0)).astype(f)
-        w = np.where(live, act[:, 1], f(0.0)).astype(f)
+        held = self.speed if cfg.hold_velocity else np.zeros_like(self.speed)
+        v = np.where(live, act[:, 0], held[:, 0]).astype(f)
+        w = np.where(live, act[:, 1], held[:, 1]).astype(f)
         self.speed[:, 0], self.speed[:, 1] = v, w
 
         # -- integrate (explicit Euler, heading at tick start)

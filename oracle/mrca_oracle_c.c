@@ -37,6 +37,8 @@ typedef struct {
     float w_thresh;
     int32_t pre_dist_zero, auto_reset, num_groups;
     uint32_t key0, key1;
+    int32_t hold_velocity; /* 1: Stage keeps the last SetSpeed (stageros.cpp:272-280): a robot that is no longer commanded
+                            * (dead, ppo_stage2.py:72-74) keeps driving, and the odom twist survives a teleport */
     int32_t first_world;
     float raster_res; /* fidelity mode: > 0 = robots collide when their outlines share a raster cell of this size */
 } oc_env;
@@ -322,7 +324,7 @@ static void oc_begin(const oc_env* e, int n, const float* po, const float* go) {
     e->goal[n * 2] = gx; e->goal[n * 2 + 1] = gy;
     e->prev_dist[n] = e->pre_dist_zero ? 0.0f : d;
     e->t[n] = 1; e->crashed[n] = 0; e->live[n] = 1;
-    e->speed[n * 2] = e->speed[n * 2 + 1] = 0.0f;
+    if (!e->hold_velocity) e->speed[n * 2] = e->speed[n * 2 + 1] = 0.0f;
     e->speed_gt[n * 2] = e->speed_gt[n * 2 + 1] = 0.0f;
 }
 
@@ -411,8 +413,8 @@ void oc_step(const oc_env* e, const float* actions) {
             const int n = world * R + l;
             x[l] = e->pose[n * 3]; y[l] = e->pose[n * 3 + 1]; th[l] = e->pose[n * 3 + 2];
             lv[l] = e->live[n] != 0;
-            v[l] = lv[l] ? actions[n * 2] : 0.0f;
-            w[l] = lv[l] ? actions[n * 2 + 1] : 0.0f;
+            v[l] = lv[l] ? actions[n * 2] : (e->hold_velocity ? e->speed[n * 2] : 0.0f);
+            w[l] = lv[l] ? actions[n * 2 + 1] : (e->hold_velocity ? e->speed[n * 2 + 1] : 0.0f);
             if (!isfinite(v[l])) v[l] = 0.0f; /* a non-finite command idles the robot */
             if (!isfinite(w[l])) w[l] = 0.0f;
             oc_sincos(th[l], &s[l], &c[l]);

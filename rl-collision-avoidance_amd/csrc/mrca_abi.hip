@@ -401,6 +401,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.timeout = cfg->timeout;
     v.w_thresh = cfg->w_thresh;
     v.pre_dist_zero = cfg->pre_dist_zero;
+    v.hold_velocity = cfg->hold_velocity ? 1 : 0;
     v.auto_reset = cfg->auto_reset;
     v.num_groups = num_groups;
     v.key0 = (uint32_t)(cfg->seed & 0xFFFFFFFFull);

@@ -72,6 +72,7 @@ struct EnvView {
     int32_t pre_dist_zero;
     int32_t auto_reset;
     int32_t num_groups;
+    int32_t hold_velocity;  // 1: Stage's SetSpeed persistence (dead robots keep driving, speed survives a reset)
     uint32_t key0, key1;
     float raster_inv;     // fidelity mode: 1 / collision_raster (0 = exact rectangles), see mrca_device.h outline_cells
     float collide_reach2; // squared centre distance beyond which two robots cannot collide (broad phase)

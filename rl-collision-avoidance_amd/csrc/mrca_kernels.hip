@@ -214,8 +214,15 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
     const float tith = valid ? e.init_table[lane * 3 + 2] : 0.0f;
     const float tgx = valid ? e.goal_table[lane * 2 + 0] : 0.0f, tgy = valid ? e.goal_table[lane * 2 + 1] : 0.0f;
     const float4 hd = e.head[n];   // sin / cos of th and the field entry of the robot's cell, kept by whoever moved it
-    const float v = live ? sane_cmd(act_v) : 0.0f;
-    const float w = live ? sane_cmd(act_w) : 0.0f;
+    // a robot whose script no longer sends cmd_vel (dead, ppo_stage2.py:72-74): idles, or -- hold_velocity, what Stage
+    // does with the last SetSpeed -- keeps driving at the command it was given last
+    float held_v = 0.0f, held_w = 0.0f;
+    if (e.hold_velocity) {
+        held_v = e.speed[n * 2 + 0];
+        held_w = e.speed[n * 2 + 1];
+    }
+    const float v = live ? sane_cmd(act_v) : held_v;
+    const float w = live ? sane_cmd(act_w) : held_w;
 
     // integrate: explicit Euler with the heading at tick start
     float s = hd.x, c = hd.y;
@@ -509,7 +516,8 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
             t = 1;
             crashed = 0;
             lv = 1;
-            spv = spw = ovgt = owgt = 0.0f;
+            ovgt = owgt = 0.0f;
+            if (!e.hold_velocity) spv = spw = 0.0f;   // hold_velocity: the odom twist survives the teleport
         }
     }
 
@@ -575,8 +583,10 @@ __global__ void reset_kernel(EnvView e, const uint8_t* __restrict__ mask, const 
     e.t[n] = 1;
     e.crashed[n] = 0;
     e.live[n] = 1;
-    e.speed[n * 2 + 0] = 0.0f;
-    e.speed[n * 2 + 1] = 0.0f;
+    if (!e.hold_velocity) {
+        e.speed[n * 2 + 0] = 0.0f;
+        e.speed[n * 2 + 1] = 0.0f;
+    }
     e.speed_gt[n * 2 + 0] = 0.0f;
     e.speed_gt[n * 2 + 1] = 0.0f;
     e.done[n] = 0;
@@ -845,8 +855,8 @@ __global__ void bw_integrate_kernel(EnvView e, const float* __restrict__ actions
     const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
     const float4 hd = e.head[n];
     const bool live = e.live[n] != 0;
-    const float v = live ? sane_cmd(actions[n * 2 + 0]) : 0.0f;
-    const float w = live ? sane_cmd(actions[n * 2 + 1]) : 0.0f;
+    const float v = live ? sane_cmd(actions[n * 2 + 0]) : (e.hold_velocity ? e.speed[n * 2 + 0] : 0.0f);
+    const float w = live ? sane_cmd(actions[n * 2 + 1]) : (e.hold_velocity ? e.speed[n * 2 + 1] : 0.0f);
     const float s = hd.x, c = hd.y;
     const float d = v * kDt;
     const float nx = x + d * c;
@@ -1032,7 +1042,8 @@ __global__ void bw_finish_kernel(EnvView e) {
         t = 1;
         crashed = 0;
         lv = 1;
-        spv = spw = ovgt = owgt = 0.0f;
+        ovgt = owgt = 0.0f;
+        if (!e.hold_velocity) spv = spw = 0.0f;
     }
     const FreeRectField rect_field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
     const uint32_t cellv = rect_field((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell));

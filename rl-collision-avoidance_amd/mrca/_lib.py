@@ -36,7 +36,7 @@ class MrcaConfig(C.Structure):
         ("seed", C.c_uint64),
         ("reset_mode", C.c_void_p), ("goal_mode", C.c_void_p), ("init_table", C.c_void_p),
         ("goal_table", C.c_void_p), ("group_id", C.c_void_p),
-        ("collision_raster", C.c_float), ("lazy_obs", C.c_int32),
+        ("collision_raster", C.c_float), ("lazy_obs", C.c_int32), ("hold_velocity", C.c_int32),
     ]
 
 

@@ -68,6 +68,7 @@ class Scenario:
     pre_dist_zero: bool = False   # stage_world2.py:170-171 / circle_world.py:166-167
     auto_reset: int = AUTO_ROBOT
     seed: int = 0
+    hold_velocity: bool = False    # fidelity: Stage's SetSpeed persistence (dead robots keep driving, speed survives a reset)
     collision_raster: float = 0.0  # fidelity mode: > 0 = robots collide when their outlines share a raster cell of this size
     beams: int = 512              # stage1.world:14
     frames: int = 3               # LASER_HIST ppo_stage1.py:24
@@ -115,15 +116,15 @@ def _map(name, stage_resolution):
     return load_map(_STAGE_RES_MAPS[name] if stage_resolution else name)
 
 
-def stage1(num_worlds=1, robots_per_world=24, seed=0, grid=None, stage_resolution=False):
+def stage1(num_worlds=1, robots_per_world=24, seed=0, grid=None, stage_resolution=False, hold_velocity=False):
     """Stage-1 rink: random poses/goals in the 9 m disc (stage_world1.py), NUM_ENV=24
     (ppo_stage1.py:32), every robot restarts on its own (ppo_stage1.py:51-58)."""
     return Scenario("stage1", num_worlds, robots_per_world, grid or _map("stage1_rink", stage_resolution), timeout=150,
                     w_thresh=1.05, pre_dist_zero=False, auto_reset=AUTO_ROBOT, seed=seed,
-                    collision_raster=0.2 if stage_resolution else 0.0)
+                    collision_raster=0.2 if stage_resolution else 0.0, hold_velocity=hold_velocity)
 
 
-def stage2(num_worlds=1, seed=0, grid=None, stage_resolution=False):
+def stage2(num_worlds=1, seed=0, grid=None, stage_resolution=False, hold_velocity=False):
     """Stage-2 map: 44 robots, tables for 0..33, random region for 34..43 (stage_world2.py:164-171,
     210-221), group-synchronous episodes (ppo_stage2.py:72-107, model/utils.py:83)."""
     tb = load_tables()["stage2"]
@@ -140,7 +141,8 @@ def stage2(num_worlds=1, seed=0, grid=None, stage_resolution=False):
         gid[bounds[g]: bounds[g + 1]] = g
     return Scenario("stage2", num_worlds, R, grid or _map("stage2_testenv", stage_resolution), timeout=200, w_thresh=1.05,
                     pre_dist_zero=True, auto_reset=AUTO_GROUP, seed=seed, reset_mode=mode, goal_mode=mode.copy(),
-                    init_table=init, goal_table=goal, group_id=gid, collision_raster=0.2 if stage_resolution else 0.0)
+                    init_table=init, goal_table=goal, group_id=gid, collision_raster=0.2 if stage_resolution else 0.0,
+                    hold_velocity=hold_velocity)
 
 
 def circle(num_worlds=1, seed=0, grid=None, stage_resolution=False):

@@ -12,6 +12,7 @@ The batched world is created by a *backend factory*.  The product factory is the
 (``HipBackend``); there is no CPU fallback -- tests may inject their own checker backend through
 ``set_backend_factory``.
 """
+import os
 import threading
 
 import numpy as np
@@ -93,9 +94,13 @@ class SharedWorld:
     def tick(self):
         """One Stage tick with the latched commands.  A robot that sent no cmd_vel this round
         keeps its previous command in Stage (stageros.cpp:272-280; the watchdog is global,
-        :466-471); here it idles with (0,0) -- DESIGN.md "Oracle decisions" (vi)."""
+        :466-471); here it idles with (0,0) -- DESIGN.md "Oracle decisions" 7 -- unless the scenario
+        asks for Stage's behaviour (``hold_velocity``, MRCA_HOLD_VELOCITY=1): then the last command stays."""
         with self.lock:
-            act = np.where(self.has_cmd[:, None], self.latched, 0.0).astype(np.float32)
+            if getattr(self.sc, "hold_velocity", False):
+                act = self.latched.astype(np.float32).copy()
+            else:
+                act = np.where(self.has_cmd[:, None], self.latched, 0.0).astype(np.float32)
             self.backend.step(act)
             self.has_cmd[:] = False
             self.ticks += 1
@@ -139,6 +144,7 @@ def shared_world(variant, num_env):
             if sc.robots_per_world != num_env:
                 raise ValueError(f"{variant} world has {sc.robots_per_world} robots, NUM_ENV={num_env}")
             sc.auto_reset = S.AUTO_NONE  # the calling script owns the episode structure
+            sc.hold_velocity = os.environ.get("MRCA_HOLD_VELOCITY", "0") not in ("", "0")
             _shared[key] = SharedWorld(variant, num_env, sc)
         return _shared[key]
 

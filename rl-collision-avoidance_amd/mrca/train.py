@@ -97,6 +97,10 @@ def main(argv=None):
                                                           "4096 robots, the tick is GPU-bound; profiles/r02_e_bench_rollout*.json)")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch the rollout tick kernel by kernel")
     ap.add_argument("--log-every", type=int, default=1)
+    ap.add_argument("--hold-velocity", action="store_true", help="fidelity: Stage's SetSpeed persistence -- a robot that finished "
+                                                                  "keeps driving at its last command until its group is done "
+                                                                  "(what ppo_stage2.py's dead robots do under stageros), and the "
+                                                                  "speed input survives a reset")
     a = ap.parse_args(argv)
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,11 +121,12 @@ def main(argv=None):
 
     from .vec_env import VecStageWorld
     if a.stage == 1:
-        sc = scenario.stage1(num_worlds=a.worlds, robots_per_world=a.robots_per_world, seed=a.seed * 1000 + rank)
+        sc = scenario.stage1(num_worlds=a.worlds, robots_per_world=a.robots_per_world, seed=a.seed * 1000 + rank,
+                             hold_velocity=a.hold_velocity)
         hp = HParams()                                         # ppo_stage1.py:22-35
         resume, pattern = "stage1_2.pth", "Stage1_{}"
     else:
-        sc = scenario.stage2(num_worlds=a.worlds, seed=a.seed * 1000 + rank)
+        sc = scenario.stage2(num_worlds=a.worlds, seed=a.seed * 1000 + rank, hold_velocity=a.hold_velocity)
         hp = HParams(batch_size=512, epoch=4)                  # ppo_stage2.py:28-29
         resume, pattern = "stage2.pth", "stage2_{}.pth"
     for k, v in (("learning_rate", a.lr), ("epoch", a.epoch), ("horizon", a.horizon),

@@ -50,6 +50,7 @@ class VecStageWorld:
             goal_mode=goal_mode.ctypes.data, init_table=init_table.ctypes.data,
             goal_table=goal_table.ctypes.data, group_id=group_id.ctypes.data,
             collision_raster=float(getattr(sc, "collision_raster", 0.0)),
+            hold_velocity=int(bool(getattr(sc, "hold_velocity", False))),
             lazy_obs=1)      # MRCA_F_OBS is materialised by the ``obs`` property when somebody asks for it
         nbytes = C.c_size_t()
         _lib.check(self.lib.mrca_arena_bytes(C.byref(cfg), C.byref(nbytes)), "mrca_arena_bytes")

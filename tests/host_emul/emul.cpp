@@ -36,6 +36,7 @@ struct EmulEnv {
     float w_thresh;
     int32_t pre_dist_zero, auto_reset, num_groups;
     uint32_t key0, key1;
+    int32_t hold_velocity;
 };
 
 // the free-rectangle field of a map, built once per distinct map (keyed by a hash of the bitmap)
@@ -95,7 +96,7 @@ static void begin_episode(const EmulEnv* e, int n, int local, float curx, float 
     e->t[n] = 1;
     e->crashed[n] = 0;
     e->live[n] = 1;
-    e->speed[n * 2] = e->speed[n * 2 + 1] = 0.0f;
+    if (!e->hold_velocity) e->speed[n * 2] = e->speed[n * 2 + 1] = 0.0f;
     e->speed_gt[n * 2] = e->speed_gt[n * 2 + 1] = 0.0f;
 }
 
@@ -194,8 +195,8 @@ void emul_step(const EmulEnv* e, const float* actions) {
             const int n = world * R + l;
             x[l] = e->pose[n * 3]; y[l] = e->pose[n * 3 + 1]; th[l] = e->pose[n * 3 + 2];
             livev[l] = e->live[n] != 0;
-            v[l] = livev[l] ? sane_cmd(actions[n * 2]) : 0.0f;
-            w[l] = livev[l] ? sane_cmd(actions[n * 2 + 1]) : 0.0f;
+            v[l] = livev[l] ? sane_cmd(actions[n * 2]) : (e->hold_velocity ? e->speed[n * 2] : 0.0f);
+            w[l] = livev[l] ? sane_cmd(actions[n * 2 + 1]) : (e->hold_velocity ? e->speed[n * 2 + 1] : 0.0f);
             sincos_det(th[l], &s[l], &c[l]);
             const float d = v[l] * kDt;
             nx[l] = x[l] + d * c[l];

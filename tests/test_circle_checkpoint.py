@@ -35,6 +35,14 @@ def test_checkpoint_is_the_one_the_profiles_describe():
     assert set(sd) >= {"logstd", "act_fea_cv1.weight", "crt_fc2.bias", "actor1.weight", "critic.bias"}   # reference keys
 
 
+def test_round3_checkpoint_is_the_one_the_profiles_describe():
+    p = os.path.join(os.path.dirname(CHECKPOINT), "policy_r03_fused_update_11min.pth")
+    assert hashlib.sha256(open(p, "rb").read()).hexdigest().startswith("5729e04243095894")
+    sd = torch.load(p, map_location="cpu")
+    ref = torch.load(CHECKPOINT, map_location="cpu")
+    assert set(sd) == set(ref) and all(sd[k].shape == ref[k].shape for k in ref)
+
+
 def test_trained_checkpoint_solves_the_circle_test_on_the_oracle_env():
     from mrca import evaluate
     from mrca.net import CNNPolicy

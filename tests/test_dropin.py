@@ -122,6 +122,37 @@ def test_get_reward_and_terminate_honours_the_callers_step_counter():
         stage_world.set_backend_factory(None)
 
 
+@pytest.mark.parametrize("hold", [False, True])
+def test_a_rank_that_stops_commanding(monkeypatch, hold):
+    """ppo_stage2.py:72-74: a finished rank sends no cmd_vel.  Default: its robot idles.  MRCA_HOLD_VELOCITY=1: Stage's
+    SetSpeed persistence (stageros.cpp:272-280) -- the robot drives on at its last command and get_self_speed shows it,
+    also right after reset_pose's teleport (stage_world1.py:106-108: the odom twist)."""
+    from mrca import stage_world
+    monkeypatch.setenv("MRCA_HOLD_VELOCITY", "1" if hold else "0")
+    stage_world.set_backend_factory(U.OracleBackend)
+    try:
+        a, b = (stage_world.Stage1World(512, index=i, num_env=2) for i in range(2))
+        a.control_pose([-2.0, 0.0, 0.0])
+        b.control_pose([2.0, 3.0, 0.0])
+        a.control_vel([0.5, 0.2])
+        b.control_vel([0.5, 0.0])
+        a.world.tick()
+        x1 = a.get_self_stateGT()[0]
+        assert abs(x1 - (-1.95)) < 1e-6
+        for _ in range(4):
+            b.control_vel([0.5, 0.0])        # rank 0 says nothing any more
+            a.world.tick()
+        x5, sp = a.get_self_stateGT()[0], a.get_self_speed()
+        if hold:
+            assert x5 > x1 + 0.19 and np.allclose(sp, [0.5, 0.2])
+        else:
+            assert x5 == x1 and np.allclose(sp, [0.0, 0.0])
+        a.control_pose([-4.0, -4.0, 1.0])
+        assert np.allclose(a.get_self_speed(), [0.5, 0.2] if hold else [0.0, 0.0])
+    finally:
+        stage_world.set_backend_factory(None)
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ppo_stage2.py")), reason="reference checkout absent")
 def test_unchanged_ppo_stage2_runs(monkeypatch):
     """44 ranks of the UNCHANGED ppo_stage2.py (group-synchronous episodes, liveflag, bcast,

@@ -34,6 +34,16 @@ def test_stage2_bit_exact_group_episodes():
     assert o.episode.max() >= 2  # at least one group restarted (timeout 200)
 
 
+def test_stage2_hold_velocity_bit_exact():
+    """Fidelity switch: Stage keeps the last SetSpeed -- dead robots keep driving, the speed input survives the restart."""
+    o = _run(S.stage2(num_worlds=1, seed=5, hold_velocity=True), 215, 3, check_every=5)
+    assert o.episode.max() >= 2
+
+
+def test_stage1_hold_velocity_bit_exact():
+    _run(S.stage1(num_worlds=2, robots_per_world=8, seed=11, hold_velocity=True), 120, 3, check_every=3)
+
+
 def test_circle_bit_exact():
     _run(S.circle(num_worlds=1, seed=2), 25, 4)
 

@@ -107,6 +107,31 @@ def test_success_rate_under_perturbed_starts_every_circle_size(stage_resolution)
         assert m["success_rate"] >= 0.98, (robots, stage_resolution, m)
 
 
+def test_checkpoint_trained_through_the_hip_backward_kernels():
+    """mrca/data/policy_r03_fused_update_11min.pth: Stage-1 from scratch for 300 s, then the Stage-2 mix for 330 s, on one
+    MI355X, every PPO update through lidar_features_kernel / lidar_features_bwd_kernel (tools/train_recipe.sh,
+    profiles/r03_j_train_fused_*_curve.txt; selected on perturbed validation circles of a held-out seed).  Measured there
+    with 100 perturbed circles per size: 1.000 / 1.000 / 1.000 / 1.000 / 0.9998.  Here: 40 circles per size, another
+    seed, inference through the HIP front end reading the frame ring in place."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    from mrca import evaluate
+    from mrca.net import CNNPolicy
+    from mrca.vec_env import VecStageWorld
+    pol = CNNPolicy(3, 2).cuda()
+    pol.load_state_dict(torch.load(os.path.join(os.path.dirname(CHECKPOINT), "policy_r03_fused_update_11min.pth"),
+                                   map_location="cuda"))
+    for robots, radius in ((10, 8.0), (20, 12.0), (30, 16.0), (40, 20.0), (50, 25.0)):
+        sc = S.circle(num_worlds=40) if robots == 50 else S.circle_n(robots, radius, num_worlds=40)
+        env = VecStageWorld(sc)
+        m = evaluate.circle_test(env, evaluate.cnn_policy_fn(pol, fused=True, env=env), max_ticks=2000, perturb=(0.2, 0.1),
+                                 seed=777)
+        env.close()
+        assert m["success_rate_ci95"][0] >= 0.95 and m["success_rate"] >= 0.98, (robots, m)
+
+
 def test_second_checkpoint_on_circles_of_every_size():
     """mrca/data/policy_r02_all_circle_sizes.pth (profiles/r02_h_*): circles of 10 ... 50 robots, 20 circles each."""
     if not torch.cuda.is_available():

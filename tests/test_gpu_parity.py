@@ -66,6 +66,14 @@ def test_stage2_bit_exact_group_episodes(hip):
     assert o.episode.max() >= 2
 
 
+def test_stage2_hold_velocity_bit_exact(hip):
+    """mrca_config.hold_velocity: dead robots keep driving at their last command until the group restarts (stageros'
+    SetSpeed persistence under ppo_stage2.py:72-74), and the speed input survives the restart."""
+    o = _run_exact(hip, S.stage2(num_worlds=2, seed=5, hold_velocity=True), 215, 3, check_every=5)
+    assert o.episode.max() >= 2
+    _run_exact(hip, S.stage1(num_worlds=3, robots_per_world=8, seed=11, hold_velocity=True), 100, 3, check_every=4)
+
+
 def test_stage2_two_worlds(hip):
     _run_exact(hip, S.stage2(num_worlds=2, seed=8), 30, 5, check_every=3)
 

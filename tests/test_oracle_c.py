@@ -29,6 +29,10 @@ def test_c_oracle_stage2_groups():
     _run(S.stage2(num_worlds=1, seed=6), 210, 2, every=7)
 
 
+def test_c_oracle_stage2_hold_velocity():
+    _run(S.stage2(num_worlds=1, seed=6, hold_velocity=True), 210, 2, every=7)
+
+
 def test_c_oracle_circle():
     _run(S.circle(num_worlds=1, seed=1), 15, 3)
 

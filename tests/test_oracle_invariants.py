@@ -161,6 +161,39 @@ def test_goal_and_crash_same_tick_both_apply():
         assert env.result[0] == O.RESULT_CRASH and abs(env.reward[0]) < 1e-6 and env.done[0] == 1
 
 
+@pytest.mark.parametrize("hold", [False, True])
+def test_finished_robot_waiting_for_its_group(hold):
+    """ppo_stage2.py:72-74 sends no cmd_vel for a robot whose episode is over; stageros keeps the last SetSpeed
+    (stageros.cpp:272-280) and its watchdog is global (:466-471), so under Stage that robot DRIVES ON.  Default: it
+    idles.  hold_velocity: it keeps its last command, stays an obstacle on the move, its stale
+    (reward, done) keep being reported -- and the odom twist survives the restart's teleport."""
+    sc = _open_world(R=2, auto_reset=S.AUTO_GROUP, hold_velocity=hold, pre_dist_zero=True)
+    for env in _both(sc):
+        _place(env, [[0.0, 0.0, 0.0], [0.0, 5.0, 0.0]], [[0.55, 0.0], [8.0, 5.0]])
+        env.step(np.array([[1.0, 0.25], [1.0, 0.0]], np.float32))          # robot 0: 0.45 m from its goal -> Reach Goal
+        assert env.done[0] == 1 and env.result[0] == O.RESULT_REACH and env.live[0] == 0 and env.live[1] == 1
+        r0, x0 = float(env.reward[0]), float(env.pose[0, 0])
+        for _ in range(5):
+            env.step(np.array([[0.3, -0.9], [1.0, 0.0]], np.float32))      # whatever the policy says for robot 0 is ignored
+        assert env.live[0] == 0 and env.done[0] == 1 and float(env.reward[0]) == r0
+        if hold:
+            assert float(env.pose[0, 0]) > x0 + 0.4 and abs(float(env.pose[0, 2]) - 6 * 0.025) < 1e-5
+            assert np.allclose(env.speed[0], [1.0, 0.25]) and np.allclose(env.speed_gt[0], [1.0, 0.25])
+        else:
+            assert float(env.pose[0, 0]) == x0 and np.allclose(env.speed[0], [0.0, 0.0])
+        # robot 1 reaches its goal too: the group restarts, both robots begin episode 2
+        ep = int(env.episode[0])
+        for _ in range(80):
+            env.step(np.array([[0.0, 0.0], [1.0, 0.0]], np.float32))
+            if env.episode[0] > ep:
+                break
+        assert env.episode[0] == ep + 1 and env.episode[1] == ep + 1 and env.live.all() and env.t[0] == 1
+        if hold:
+            assert np.allclose(env.speed[0], [1.0, 0.25]) and np.allclose(env.speed[1], [1.0, 0.0])
+        else:
+            assert np.allclose(env.speed, 0.0)
+
+
 def test_local_goal_transform():
     for env in _both(_open_world()):
         _place(env, [[1.0, 1.0, np.pi / 2]], [[1.0, 4.0]])

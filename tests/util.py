@@ -27,7 +27,8 @@ def oracle_env(sc, dtype=np.float32, first_world=0, num_worlds=None):
                          pre_dist_zero=sc.pre_dist_zero, auto_reset=sc.auto_reset, seed=sc.seed,
                          reset_mode=sc.reset_mode, init_table=sc.init_table, goal_table=sc.goal_table,
                          group_id=sc.group_id, beams=sc.beams, frames=sc.frames, first_world=first_world,
-                         collision_raster=getattr(sc, "collision_raster", 0.0))
+                         collision_raster=getattr(sc, "collision_raster", 0.0),
+                         hold_velocity=getattr(sc, "hold_velocity", False))
     cfg.goal_mode = np.asarray(sc.goal_mode, np.int32)
     return O.OracleEnv(cfg, dtype)
 
@@ -65,7 +66,7 @@ class _EmulEnvStruct(C.Structure):
                 [(k, C.c_int32) for k in ("width", "height", "wpr", "timeout")] +
                 [("w_thresh", C.c_float)] +
                 [(k, C.c_int32) for k in ("pre_dist_zero", "auto_reset", "num_groups")] +
-                [("key0", C.c_uint32), ("key1", C.c_uint32)])
+                [("key0", C.c_uint32), ("key1", C.c_uint32), ("hold_velocity", C.c_int32)])
 
 
 _emul_lib = None
@@ -138,6 +139,7 @@ class EmulEnv:
         st.pre_dist_zero, st.auto_reset = int(sc.pre_dist_zero), sc.auto_reset
         st.num_groups = int(self._group_id.max()) + 1
         st.key0, st.key1 = sc.seed & 0xFFFFFFFF, (sc.seed >> 32) & 0xFFFFFFFF
+        st.hold_velocity = int(bool(getattr(sc, "hold_velocity", False)))
         self._st = st
 
     def reset(self, mask=None, poses=None, goals=None):
