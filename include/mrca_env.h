@@ -247,12 +247,18 @@ int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t
  * set: 1 = skip robot-robot lidar tests, 2 = skip the grid march, 8 / 16 / 32 = move kernel without its outline
  * test / collision loop / resets.  Launch-shape knobs (results unchanged):
  * bits 8-10 = k > 0: 1 << (k-1) beams per marching thread; bit 11: a dedicated preparation wave; bit 12: the beams of a
- * thread marched in lock step.  0 restores the product path. */
+ * thread marched in lock step.  64 (results unchanged): the ray cast's phase stamps drain the memory queues first.
+ * 0 restores the product path. */
 int mrca_set_debug_flags(mrca_env* env, int32_t flags);
 /* s_memtime ticks between the move kernel's phase stamps of the last launch, averaged over worlds: [0..7] = state loaded
  * and integrated | clearance + broad phase | patches in LDS | outline walks | ordered collision pass | reward / ballots
  * | restarts | stores drained; [8] = entry to end.  Every stamp drains the memory queues first. */
 int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out);
+/* s_memtime stamps of the last ray-cast launch, lane 0 of wave 0 (builds the neighbour list, then marches) and of wave 1
+ * (marches only): out[w * 7 + k] = mean over workgroups of stamp k - the workgroup's entry, k = entry | loads requested |
+ * neighbour list built | beams marched | through the barrier | slab tests done | stores issued; out[14] = first entry to
+ * last end, out[15] = mean workgroup entry, out[16] = share of workgroups starting in the first tenth of the launch. */
+int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */);
 #endif
 
 #ifdef __cplusplus

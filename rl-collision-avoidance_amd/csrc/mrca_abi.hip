@@ -598,6 +598,43 @@ int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out /* [9]: 8 deltas
 }
 #endif
 
+#if defined(MRCA_PROFILING)
+// Profiling build only: s_memtime stamps of the LAST ray-cast launch (synchronises the device).  out[w * 7 + k], w = 0, 1
+// (wave 0 prepares the neighbour list, wave 1 only marches), k = 0..6: mean over workgroups of stamp k minus the
+// workgroup's entry stamp; out[14] = last end - first entry over all workgroups (the launch as the shader clock sees it),
+// out[15] = mean workgroup entry - first entry, out[16] = share of workgroups that started in the first 10 % of the launch.
+int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */) {
+    if (!env || !out) return fail(MRCA_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(env->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    const int nb = env->view.N < 8192 ? env->view.N : 8192;
+    std::vector<unsigned long long> h((size_t)14 * nb);
+    mrca::read_ray_stamps(h.data(), nb);
+    auto at = [&](int w, int k, int b) { return h[((size_t)w * 7 + k) * nb + b]; };
+    unsigned long long first = ~0ull, last = 0;
+    for (int b = 0; b < nb; ++b) {
+        first = at(0, 0, b) < first ? at(0, 0, b) : first;
+        for (int w = 0; w < 2; ++w) last = at(w, 6, b) > last ? at(w, 6, b) : last;
+    }
+    for (int w = 0; w < 2; ++w)
+        for (int k = 0; k < 7; ++k) {
+            double sum = 0.0;
+            for (int b = 0; b < nb; ++b) sum += (double)(long long)(at(w, k, b) - at(0, 0, b));
+            out[w * 7 + k] = sum / nb;
+        }
+    out[14] = (double)(last - first);
+    double sum = 0.0;
+    int early = 0;
+    for (int b = 0; b < nb; ++b) {
+        sum += (double)(at(0, 0, b) - first);
+        early += (double)(at(0, 0, b) - first) < 0.1 * out[14];
+    }
+    out[15] = sum / nb;
+    out[16] = (double)early / nb;
+    return MRCA_OK;
+}
+#endif
+
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     float mv = 0.0f, ry = 0.0f;

@@ -104,6 +104,7 @@ void launch_head_init(const EnvView& e, hipStream_t s);
 void launch_lidar_grid(const EnvView& e, int counted, hipStream_t s);   // big worlds: hash of the current poses for the ray cast
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
 #if defined(MRCA_PROFILING)
+void read_ray_stamps(unsigned long long* host, int blocks);     // profiling build: [2 waves][7 stamps][blocks] of raycast_kernel
 void read_move_stamps(unsigned long long* host, int worlds);   // profiling build: s_memtime stamps of move_kernel's phases
 #endif
 void launch_materialize_obs(const EnvView& e, hipStream_t s);   // obs_ring -> obs for robots [ray_first, ray_first + ray_count)

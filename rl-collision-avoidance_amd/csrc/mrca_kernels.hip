@@ -174,8 +174,21 @@ __device__ unsigned long long g_move_stamps[kMoveStamps][kMoveStampWorlds];
         if (threadIdx.x == 0 && blockIdx.x < kMoveStampWorlds)                             \
             g_move_stamps[k][blockIdx.x] = __builtin_amdgcn_s_memtime();                   \
     } while (0)
+// the same for the ray cast: lane 0 of waves 0 and 1 of every workgroup; memory is drained at a stamp only with debug
+// flag 64 (without it the stamps leave the kernel's overlap as it is)
+constexpr int kRayStamps = 7, kRayStampBlocks = 8192;
+__device__ unsigned long long g_ray_stamps[2][kRayStamps][kRayStampBlocks];
+#define MRCA_RSTAMP(k)                                                                                  \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        if (MRCA_DBG(e, 64)) __builtin_amdgcn_s_waitcnt(0);                                             \
+        if ((threadIdx.x & 63) == 0 && threadIdx.x < 128 && blockIdx.x < kRayStampBlocks)               \
+            g_ray_stamps[threadIdx.x >> 6][k][blockIdx.x] = __builtin_amdgcn_s_memtime();               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
 #else
 #define MRCA_STAMP(k) do { } while (0)
+#define MRCA_RSTAMP(k) do { } while (0)
 #endif
 
 // kMoveWaves wavefronts per world.  Every wave loads and integrates the whole world (lane = robot: ~100 B per robot, and
@@ -612,6 +625,7 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 template <int K, bool BIG, bool SEQ>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    MRCA_RSTAMP(0);
     const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
     const int tid = threadIdx.x;
     // the fresh flag comes through the scalar cache (n is block-uniform; the aligned word holding the byte),
@@ -718,6 +732,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             for (int b = iv.x + pl; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
         }
     };
+    MRCA_RSTAMP(1);     // robot record, beam table, neighbour candidate requested (debug flag 64: arrived)
     if (is_prep) {
       if constexpr (BIG) {
         big_chunk();
@@ -747,6 +762,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
       }
     }
+    MRCA_RSTAMP(2);     // wave 0: neighbour list and per-beam masks built
     // --- the march: K beams per thread in lock step
     float dx[K], dy[K], rng[K];
 #pragma unroll
@@ -770,7 +786,9 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             grid_march_skip_n<K>(field, e.g, org, dx, dy, kRangeMax, rng);
         }
     }
+    MRCA_RSTAMP(3);     // this wave's beams marched
     __syncthreads();  // neighbour list ready (the preparation wave built it while the others marched)
+    MRCA_RSTAMP(4);     // through the barrier
     if constexpr (!BIG) {
         if (!marches) return;  // the dedicated preparation wave is done (whole wave: the barrier below counts live waves)
     }
@@ -799,6 +817,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         __syncthreads();          // ... and the next one is ready
     }
     if (!marches) return;
+    MRCA_RSTAMP(5);     // neighbour slab tests done
     // --- scan, normalised observation (stage_world1.py:140), newest frame of the stack (ppo_stage1.py:59-60,87-89):
     //     every thread stores its own beams -- lane l of a wave holds beam base + l, so each store instruction of a
     //     wave covers 256 contiguous bytes.  (Round 1 went through LDS so that a quarter of the threads could move 16
@@ -826,6 +845,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         e.local_goal[n * 2 + 0] = gx * c + gy * s;
         e.local_goal[n * 2 + 1] = gy * c - gx * s;
     }
+    MRCA_RSTAMP(6);     // stores issued (debug flag 64: acknowledged)
 }
 
 
@@ -1172,6 +1192,11 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
 }  // namespace
 
 #if defined(MRCA_PROFILING)
+void read_ray_stamps(unsigned long long* host, int blocks) {      // [2][kRayStamps][blocks]
+    for (int k = 0; k < 2 * kRayStamps; ++k)
+        (void)hipMemcpyFromSymbol(host + (size_t)k * blocks, HIP_SYMBOL(g_ray_stamps), sizeof(unsigned long long) * blocks,
+                                  sizeof(unsigned long long) * ((size_t)k * kRayStampBlocks), hipMemcpyDeviceToHost);
+}
 void read_move_stamps(unsigned long long* host, int worlds) {      // [kMoveStamps][worlds]
     for (int k = 0; k < kMoveStamps; ++k)
         (void)hipMemcpyFromSymbol(host + (size_t)k * worlds, HIP_SYMBOL(g_move_stamps), sizeof(unsigned long long) * worlds,

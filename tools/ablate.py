@@ -67,4 +67,24 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
     print(f"{name:<14} move kernel phases (s_memtime ticks, memory drained at every stamp, mean of 16 launches):")
     for nm, a in zip(names, acc):
         print(f"{'':<14}   {nm:<36} {a / 16:9.1f} ticks  {100.0 * a / acc[8]:5.1f} %")
+    # the ray cast: where a workgroup's time goes, wave 0 (prepares the neighbour list, then marches) vs wave 1 (marches)
+    rnames = ("entry", "loads requested", "neighbour list built", "beams marched", "through the barrier",
+              "neighbour slab tests", "stores issued")
+    for flags, label in ((0, "overlap untouched"), (64, "memory drained at every stamp"), (64 + 1, "drained, no neighbour tests"),
+                         (64 + 2, "drained, no march")):
+        env.set_debug_flags(flags)
+        out = (C.c_double * 17)()
+        acc = [0.0] * 17
+        for k in range(20):
+            env.step(pool[k % 8])
+        for k in range(16):
+            env.step(pool[k % 8])
+            _lib.check(env.lib.mrca_debug_ray_stamps(env._h, out), "mrca_debug_ray_stamps")
+            acc = [a + t / 16 for a, t in zip(acc, out)]
+        print(f"{name:<14} ray cast stamps, {label} (s_memtime ticks since the workgroup's entry, mean over workgroups and 16 launches):")
+        for k, nm in enumerate(rnames):
+            print(f"{'':<14}   {nm:<24} wave 0 {acc[k]:9.1f}   wave 1 {acc[7 + k]:9.1f}")
+        print(f"{'':<14}   first entry -> last end {acc[14]:9.1f} ticks; mean workgroup entry at {acc[15]:9.1f}; "
+              f"{100 * acc[16]:.0f} % of the workgroups start in the first tenth of the launch")
+    env.set_debug_flags(0)
     env.close()
