@@ -14,9 +14,22 @@ if [[ "${1:-}" == "--profiling" ]]; then
     extra=(-DMRCA_PROFILING)
 fi
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-    -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
-    -Wall -Wno-unused-function "${extra[@]}" \
-    "${here}/mrca_kernels.hip" "${here}/mrca_abi.hip" "${here}/mrca_policy.hip" "${here}/mrca_policy_bwd.hip" "${here}/mrca_policy_tail.hip" \
-    -o "${out}" "$@"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC
+    -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math
+    -Wall -Wno-unused-function "${extra[@]}")
+# One object per source: mrca_policy.hip is compiled with the MFMA accumulators in VGPRs (its epilogues read them lane by
+# lane while the next MFMAs run; in AGPRs every read is a v_accvgpr_read_b32 first and the compiler lumps 32 of them
+# behind the last MFMA of a tile pair) -- a per-file flag: the backward kernel needs AGPRs for its 242 accumulator
+# registers.
+pids=()
+obj="$(mktemp -d)"
+trap 'rm -rf "${obj}"' EXIT
+for src in mrca_kernels mrca_abi mrca_policy mrca_policy_bwd mrca_policy_tail; do
+    per=()
+    [[ "${src}" == "mrca_policy" ]] && per=(-mllvm --amdgpu-mfma-vgpr-form)
+    "${HIPCC}" "${FLAGS[@]}" "${per[@]}" -c "${here}/${src}.hip" -o "${obj}/${src}.o" "$@" &
+    pids+=($!)
+done
+for pid in "${pids[@]}"; do wait "${pid}"; done      # set -e: the first failed compile ends the build
+"${HIPCC}" --offload-arch=gfx950 -fPIC -shared "${obj}"/*.o -o "${out}"
 echo "built ${out}"

@@ -608,6 +608,11 @@ __global__ void reset_kernel(EnvView e, const uint8_t* __restrict__ mask, const 
     e.first_result[n] = 0;
 }
 
+// LDS |= without a return value (ds_or_b64): nothing to wait for
+__device__ __forceinline__ void mask_or(unsigned long long* p, unsigned long long v) {
+    (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // blockIdx -> robot: consecutive robots (one world's robots) share an XCD's L2 (block b runs on
 // XCD b % 8, guide T1); a pure permutation, so correctness never depends on it.
 __device__ __forceinline__ int block_to_robot(int b, int N) {
@@ -622,20 +627,20 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
 // no difference.)  Marching the K beams of a thread in LOCK STEP (grid_march_skip_n: K lookups in flight per wait) is
 // implemented and measured too: slower than one after the other (34.7 vs 28.1 us, profiles/r02_c_*), see mrca_abi.hip.
-template <int K, bool BIG, bool SEQ>
+// ALL: the launch behind a step -- every robot is cast, no early exit, nothing to wait for before the requests are out.
+template <int K, bool BIG, bool SEQ, bool ALL>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     MRCA_RSTAMP(0);
     const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
     const int tid = threadIdx.x;
-    // the fresh flag comes through the scalar cache (n is block-uniform; the aligned word holding the byte),
-    // so nothing below queues behind it in the vector-memory counter
-    const uint32_t fresh_word = reinterpret_cast<const uint32_t*>(e.fresh)[n >> 2];
-
-    const bool fresh = ((fresh_word >> ((n & 3) * 8)) & 0xFFu) != 0;
-    if (only_fresh && !fresh) return;  // block-uniform
-    // slot of the newest frame so far; read by every thread BEFORE the first barrier, advanced by thread 0 after it
-    const int obs_slot = e.obs_head[n];
+    // The fresh flag and the ring head are needed by the epilogue only (after a step every robot is cast), so they must
+    // not hold up the requests below: the workgroup's chain used to be kernel arguments -> flag -> head -> robot record ->
+    // neighbour candidate, four dependent round trips, 3 500 of a workgroup's 19 000 ticks before the first request was
+    // out (profiles/r03_k_ablate_raycast_phase_stamps.txt).  Now both are requested behind the candidate (see below).
+    if constexpr (!ALL) {
+        if (only_fresh && e.fresh[n] == 0) return;  // block-uniform
+    }
 
     float4* nb = reinterpret_cast<float4*>(lds);
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
@@ -650,9 +655,14 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const bool marches = tid < T;                                       // wave-uniform
     const int world = n / e.R;
     const int local = n - world * e.R;
-    // the robot's own record is block-uniform: pose, sin / cos and the field entry of its cell
-    const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1];
-    const float4 hd = e.head[n];
+    // the robot's own record: pose, sin / cos and the field entry of its cell.  Block-uniform -- but fetched with VECTOR
+    // loads (the index goes through an opaque zero): as scalar loads they shared the out-of-order scalar counter with
+    // the kernel arguments, and the neighbour candidate below could not be requested before they were back.
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const int nv = n + lane_zero;
+    const float x = e.pose[nv * 3 + 0], y = e.pose[nv * 3 + 1];
+    const float4 hd = e.head[nv];
     const float s = hd.x, c = hd.y;
     // the preparation wave requests "its" neighbour candidate in the same memory round trip
     const int pl = tid - prep_base;
@@ -673,6 +683,10 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         bc[k] = e.beam_cos[b];
         bs[k] = e.beam_sin[b];
     }
+    // slot of the newest frame so far (read by every thread BEFORE the first barrier, advanced by thread 0 after it) and
+    // the fresh flag: requested last, used last
+    const uint8_t fresh_byte = e.fresh[n];
+    const int obs_slot = e.obs_head[n];
     // (The frame stack -- ppo_stage1.py:87-89: popleft / append -- is a ring: only the newest frame is written, into
     // the slot behind the previous newest one; see materialize_obs_kernel.)
     // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
@@ -729,7 +743,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
         for (int k = 0; k < cnt; ++k) {
             const int2 iv = nbi[k];
-            for (int b = iv.x + pl; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
+            for (int b = iv.x + pl; b <= iv.y; b += kWave) mask_or(&nbmask[b], 1ull << k);
         }
     };
     MRCA_RSTAMP(1);     // robot record, beam table, neighbour candidate requested (debug flag 64: arrived)
@@ -754,11 +768,12 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
         const int cnt0 = MRCA_DBG(e, 1) ? 0 : __popcll(m);
         if (pl == 0) *nb_count = cnt0;
-        // scatter: bit k of nbmask[b] = "neighbour k can touch beam b".  One wave, program order: the
-        // read-modify-writes of successive k never race, and within one k the lanes hit distinct beams.
+        // scatter: bit k of nbmask[b] = "neighbour k can touch beam b".  ds_or_b64 without a return value: the wave
+        // fires one per neighbour and moves on (as a read-modify-write every neighbour cost an LDS round trip, ~2 000
+        // of the 5 600 ticks wave 0 spent preparing, profiles/r03_k_ablate_raycast_phase_stamps.txt).
         for (int k = 0; k < cnt0; ++k) {
             const int2 iv = nbi[k];
-            for (int b = iv.x + pl; b <= iv.y; b += kWave) nbmask[b] |= 1ull << k;
+            for (int b = iv.x + pl; b <= iv.y; b += kWave) mask_or(&nbmask[b], 1ull << k);
         }
       }
     }
@@ -826,6 +841,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         float* scan_row = e.scan + (size_t)n * e.B;
         float* obs_row = e.obs_ring + (size_t)n * e.F * e.B;
         const int new_slot = obs_slot + 1 == e.F ? 0 : obs_slot + 1;
+        const bool fresh = __builtin_amdgcn_readfirstlane((int)fresh_byte) != 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int b = tid + k * T;
@@ -1267,22 +1283,27 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
     const bool seq = e.ray_sequential != 0;
-#define MRCA_RAY(K, BIG, SEQ) hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, e, only_fresh)
+#define MRCA_RAY(K, BIG, SEQ, ALL) \
+    hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, ALL>), grid, dim3(threads), lds, s, e, only_fresh)
     if (e.big) {
         switch (e.ray_shift) {
-            case 0: MRCA_RAY(1, true, false); break;
-            case 1: MRCA_RAY(2, true, false); break;
-            default: MRCA_RAY(4, true, false); break;
+            case 0: MRCA_RAY(1, true, false, false); break;
+            case 1:
+                if (only_fresh) MRCA_RAY(2, true, false, false);
+                else MRCA_RAY(2, true, false, true);
+                break;
+            default: MRCA_RAY(4, true, false, false); break;
         }
         return;
     }
     switch (e.ray_shift) {
-        case 0: MRCA_RAY(1, false, false); break;
+        case 0: MRCA_RAY(1, false, false, false); break;
         case 1:
-            if (seq) MRCA_RAY(2, false, true);
-            else MRCA_RAY(2, false, false);
+            if (seq && !only_fresh) MRCA_RAY(2, false, true, true);       // the product's step
+            else if (seq) MRCA_RAY(2, false, true, false);
+            else MRCA_RAY(2, false, false, false);
             break;
-        default: MRCA_RAY(4, false, false); break;
+        default: MRCA_RAY(4, false, false, false); break;
     }
 #undef MRCA_RAY
 }

@@ -37,6 +37,7 @@ namespace mrca_policy {
 
 using namespace mrca_pfwd;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;     // (HIP's float4 is a struct around a union: arrays of it stay in scratch)
 
 #define MRCA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MRCA_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -47,6 +48,11 @@ __device__ inline f32x16 splat16(const float (&v)[16]) {
     for (int r = 0; r < 16; ++r) z[r] = v[r];
     return z;
 }
+
+// ReLU as ONE integer instruction: the bit pattern of a negative float is a negative integer (-0.0 included), that of a
+// positive float a positive one, so relu(x) = as_float(max(as_int(x), 0)).  (x > 0 ? x : 0 compiles to two v_max_f32 under
+// IEEE rules; a negative NaN becomes 0 here -- the layers never produce one from finite inputs.)
+__device__ __forceinline__ float relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 __device__ inline f32x16 zero16() {
     f32x16 z;
@@ -120,146 +126,207 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
 
     const int stride = nwaves >> 1;
     int n = gwave >> 1;
+    if (n >= n_robots) return;       // wave-uniform; the kernel has no barrier
+
+    // ---- software pipeline (round 3, v3).  One wave per SIMD (the LDS image decides that), so everything that is not an
+    // MFMA has to ISSUE IN THE SHADOW of one: an MFMA occupies the matrix pipe for 64 cycles and the wave may issue ~12
+    // other instructions meanwhile.  Per robot, in program order (LDS operations of one wave complete in order, so
+    // program order is the only hazard rule):
+    //   conv1 pair 0   | + the PREVIOUS robot's conv2 pair 1 leaves: accumulators -> H1E[c][64..127]
+    //   conv1 pair 1   | + pair 0's ReLU + stores to H1; those rows back as float4 (registers)
+    //   conv1 pair 2   | + pair 1's stores; the float4 rows out to HBM
+    //   conv1 pair 3   | + pair 2's stores (these overwrite H1E[c][64..]: the rows were read two pairs ago)
+    //   conv2 pair 0   | + pair 3's stores (conv2 pair 0 reads positions <= 127 = conv1 pairs 0, 1 only);
+    //                  |   the NEXT robot's scan -> XE / XO (conv1 is through with them), the one after requested from HBM
+    //   conv2 pair 1   | + pair 0's output through H1E[c][0..63] and out; the next robot's first conv1 operands
+    // Every LDS operand is requested a chunk ahead, across the phase boundaries too.
     float4 sx[6];
-    // ring heads are fetched one robot further ahead than the scans whose addresses they decide
     int hd_next = 2;
-    if (n < n_robots) {
-        request_scan(sx, obs, n, head ? head[n] : 2, lane);
-        if (head && n + stride < n_robots) hd_next = head[n + stride];
+    request_scan(sx, obs, n, head ? head[n] : 2, lane);
+    if (head && n + stride < n_robots) hd_next = head[n + stride];
+
+#define MRCA_STAGE_SCAN(q)                                                                               \
+    {                                                                                                    \
+        const int idx = (q) * 64 + lane; /* float4 index: ci = idx / 128, m = idx % 128 -> x[ci][4m .. 4m+3] */ \
+        const float4 v = sx[q];                                                                          \
+        const int ci = idx >> 7, m = idx & 127;                                                          \
+        float* xe = lds + kXE + ci * kXPitch + 2 * m;                                                    \
+        float* xo = lds + kXO + ci * kXPitch + 2 * m + 1;                                                \
+        xe[0] = v.x;                                                                                     \
+        xo[0] = v.y;                                                                                     \
+        xe[1] = v.z;                                                                                     \
+        xo[1] = v.w;                                                                                     \
     }
-
-    for (; n < n_robots; n += stride) {
-        // --- stage the scan de-interleaved: 3 x 512 floats = 384 float4, 6 per lane; then request the next robot's
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int idx = q * 64 + lane;            // float4 index: ci = idx / 128, m = idx % 128 -> x[ci][4m .. 4m+3]
-            const float4 v = sx[q];
-            const int ci = idx >> 7, m = idx & 127;
-            float* xe = lds + kXE + ci * kXPitch + 2 * m;
-            float* xo = lds + kXO + ci * kXPitch + 2 * m + 1;
-            xe[0] = v.x;
-            xo[0] = v.y;
-            xe[1] = v.z;
-            xo[1] = v.w;
-        }
-        MRCA_PIN();
-        if (n + stride < n_robots) {
-            request_scan(sx, obs, n + stride, hd_next, lane);
-            if (head && n + 2 * stride < n_robots) hd_next = head[n + 2 * stride];
-        }
-        MRCA_PIN();
-        float* out = feat + ((size_t)tower * n_robots + n) * (kCh * kL2) + gofs;
-
-        // --- conv1: 8 position tiles of 32 in pairs; the operands of the next pair are requested before this pair's MFMAs
-        {
-            float ba[2][8], bb[2][8];
+#define MRCA_REQUEST_NEXT()                                                                              \
+    if (n + stride < n_robots) {                                                                         \
+        request_scan(sx, obs, n + stride, hd_next, lane);                                                \
+        if (head && n + 2 * stride < n_robots) hd_next = head[n + 2 * stride];                           \
+    }
+#define MRCA_REQUEST_NEXT_AFTER() /* inside the loop: robot n + stride has just been staged */             \
+    if (n + 2 * stride < n_robots) {                                                                     \
+        request_scan(sx, obs, n + 2 * stride, hd_next, lane);                                            \
+        if (head && n + 3 * stride < n_robots) hd_next = head[n + 3 * stride];                           \
+    }
 #define MRCA_CONV1_LOAD(buf, T)                                                                          \
-    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                      \
-        const float* base = conv1_family(s) == 1 ? x1 : (conv1_family(s) == 2 ? x2 : x3);                \
-        ba[buf][s] = base[conv1_step_off(s) + 32 * (T)];                                                 \
-        bb[buf][s] = base[conv1_step_off(s) + 32 * (T) + 32];                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                   \
+        const float* base = conv1_family(s_) == 1 ? x1 : (conv1_family(s_) == 2 ? x2 : x3);              \
+        ba[buf][s_] = base[conv1_step_off(s_) + 32 * (T)];                                               \
+        bb[buf][s_] = base[conv1_step_off(s_) + 32 * (T) + 32];                                          \
     }                                                                                                    \
     ba[buf][7] = hl ? 1.0f : ba[buf][7];                                                                 \
     bb[buf][7] = hl ? 1.0f : bb[buf][7];
-            MRCA_CONV1_LOAD(0, 0)
+// ReLU + store of register r of conv1 pair tpp.  (Position 255 does not exist and its slot H1O[c][128] is conv2's right
+// padding: the last tile stores there like everywhere else -- no divergent branch -- and MRCA_H1_PAD puts the zero back
+// before conv2's pair 1 reads it.)
+#define MRCA_CONV1_OUT(tpp, r)                                                                           \
+    {                                                                                                    \
+        hst[32 * (tpp) + rowmap(r, 0) * kHPitch] = relu(c1a[(tpp) & 1][r]);                              \
+        hst[32 * (tpp) + 16 + rowmap(r, 0) * kHPitch] = relu(c1b[(tpp) & 1][r]);                         \
+    }
+#define MRCA_H1_PAD() lds[kH1O + col * kHPitch + 128] = 0.0f;
+// chunk g = 12 P + ch of conv2's 24 chunks of four K steps: operands of step k of the tile pair P
+#define MRCA_CONV2_LOAD_K(buf, g, k)                                                                     \
+    {                                                                                                    \
+        const int s_ = 4 * ((g) % 12) + (k);                                                             \
+        const float* base = s_ < 32 ? ha : hb;                                                           \
+        b0[buf][k] = base[conv2_step_off(s_) + 64 * ((g) / 12)];                                         \
+        b1v[buf][k] = base[conv2_step_off(s_) + 64 * ((g) / 12) + 32];                                   \
+    }
+#define MRCA_CONV2_LOAD(buf, g) _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) MRCA_CONV2_LOAD_K(buf, g, k_)
+// accumulators of a conv2 tile pair -> H1E[c][64 P + ...], registers [r0, r0 + cnt)
+#define MRCA_CONV2_OUT(A0, A1, P, r0, cnt)                                                               \
+    _Pragma("unroll") for (int r = (r0); r < (r0) + (cnt); ++r) {                                        \
+        oe[rowmap(r, 0) * kHPitch + 64 * (P)] = relu(A0[r]);                                             \
+        oe[rowmap(r, 0) * kHPitch + 64 * (P) + 32] = relu(A1[r]);                                        \
+    }
+
+#pragma unroll
+    for (int q = 0; q < 6; ++q) MRCA_STAGE_SCAN(q)
+    MRCA_PIN();
+    MRCA_REQUEST_NEXT()
+    MRCA_PIN();
+    float ba[2][8], bb[2][8];
+    MRCA_CONV1_LOAD(0, 0)
+    MRCA_PIN();
+
+    f32x16 p1a = zero16(), p1b = zero16();     // conv2 pair 1 of the previous robot, still to leave
+    float* out_prev = feat;
+    bool have_prev = false;
+    for (; n < n_robots; n += stride) {
+        float* out = feat + ((size_t)tower * n_robots + n) * (kCh * kL2) + gofs;
+        f32x16 c1a[2], c1b[2];
+        f32x4 row[8];
+        float b0[2][4], b1v[2][4];
+
+        // --- conv1: 8 position tiles of 32 in pairs
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const int cur = tp & 1, nxt = cur ^ 1;
+            if (tp < 3) {
+                MRCA_CONV1_LOAD(nxt, 2 * tp + 2)
+            }
             MRCA_PIN();
+            c1a[cur] = zero16();
+            c1b[cur] = zero16();
 #pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                const int cur = tp & 1, nxt = cur ^ 1, T = 2 * tp;
-                if (tp < 3) {
-                    MRCA_CONV1_LOAD(nxt, T + 2)
+            for (int s = 0; s < 8; ++s) {
+                c1a[cur] = MRCA_MFMA(a1[s], ba[cur][s], c1a[cur]);
+                c1b[cur] = MRCA_MFMA(a1[s], bb[cur][s], c1b[cur]);
+                if (tp > 0) {
+                    MRCA_CONV1_OUT(tp - 1, 2 * s)
+                    MRCA_CONV1_OUT(tp - 1, 2 * s + 1)
                 }
-                MRCA_PIN();
-                f32x16 acca = zero16(), accb = zero16();
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    acca = MRCA_MFMA(a1[s], ba[cur][s], acca);
-                    accb = MRCA_MFMA(a1[s], bb[cur][s], accb);
+                // the previous robot's pair 1 (for the first robot: zeros through the same LDS columns, nothing stored)
+                if (tp == 0) {
+                    MRCA_CONV2_OUT(p1a, p1b, 1, 2 * s, 2)
                 }
-                MRCA_PIN();
-                // ReLU, then to LDS de-interleaved (position 255 does not exist: H1O[c][128] stays conv2's right padding)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hst[16 * T + rowmap(r, 0) * kHPitch] = acca[r] > 0.0f ? acca[r] : 0.0f;
-                if (tp < 3 || col != 31) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        hst[16 * T + 16 + rowmap(r, 0) * kHPitch] = accb[r] > 0.0f ? accb[r] : 0.0f;
+                if (tp == 1) row[s] = *reinterpret_cast<const f32x4*>(orow + 4 * s * kHPitch + 64);
+                if (tp == 2 && have_prev) *reinterpret_cast<f32x4*>(out_prev + 4 * s * kL2 + 64) = row[s];
+                if (tp == 3 && s == 5) {
+                    MRCA_CONV2_LOAD(0, 0)      // conv2's first operands: H1 positions <= 127, written two pairs ago
                 }
                 MRCA_PIN();
             }
-#undef MRCA_CONV1_LOAD
         }
 
-        // --- conv2: two pairs of position tiles (positions 64 P .. 64 P + 63), 48 steps each, operands of four steps
-        //     requested ahead; pair 0's output leaves through H1E[c][0..63] while pair 1 computes
+        // --- conv2: two pairs of position tiles (positions 64 P .. 64 P + 63), 12 chunks of four K steps each
         f32x16 acc0, acc1, done0, done1;
 #pragma unroll
-        for (int P = 0; P < 2; ++P) {
-            acc0 = splat16(bias2);
-            acc1 = splat16(bias2);
-            float b0[2][4], b1v[2][4];
-#define MRCA_CONV2_LOAD(buf, ch)                                                                         \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                      \
-        const int s = 4 * (ch) + k;                                                                      \
-        const float* base = s < 32 ? ha : hb;                                                            \
-        b0[buf][k] = base[conv2_step_off(s) + 64 * P];                                                   \
-        b1v[buf][k] = base[conv2_step_off(s) + 64 * P + 32];                                             \
-    }
-            MRCA_CONV2_LOAD(0, 0)
-            MRCA_PIN();
+        for (int g = 0; g < 24; ++g) {
+            const int P = g / 12, ch = g % 12;
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (ch == 0) {
+                acc0 = splat16(bias2);
+                acc1 = splat16(bias2);
+            }
+            // four K steps; what rides along is dealt out over them so that nothing but an MFMA pair is ever longer than
+            // the 128 cycles the pair keeps the matrix pipe busy
 #pragma unroll
-            for (int ch = 0; ch < 12; ++ch) {
-                const int cur = ch & 1, nxt = cur ^ 1;
-                if (ch < 11) {
-                    MRCA_CONV2_LOAD(nxt, ch + 1)
+            for (int k = 0; k < 4; ++k) {
+                const int s = 4 * ch + k;
+                acc0 = MRCA_MFMA(a2[s], b0[cur][k], acc0);
+                acc1 = MRCA_MFMA(a2[s], b1v[cur][k], acc1);
+                if (g < 23) {
+                    MRCA_CONV2_LOAD_K(nxt, g + 1, k)
                 }
-                if (P == 1) {
-                    // pair 0's epilogue rides along: accumulators -> LDS (after this pair's first MFMAs are queued),
-                    // rows back as float4, out to HBM
-                    if (ch == 1) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            oe[rowmap(r, 0) * kHPitch] = done0[r] > 0.0f ? done0[r] : 0.0f;
-                            oe[rowmap(r, 0) * kHPitch + 32] = done1[r] > 0.0f ? done1[r] : 0.0f;
+                if (P == 0) {
+                    if (ch < 8) {                    // conv1 pair 3 (conv2 pair 0 reads nothing of it)
+                        if (k < 2) {
+                            MRCA_CONV1_OUT(3, 2 * ch + k)
+                        }
+                    } else if (ch < 11) {            // the next robot's scan (its loads were requested a whole robot ago)
+                        if (k < 2 && n + stride < n_robots) {
+                            MRCA_STAGE_SCAN(2 * (ch - 8) + k)
+                        }
+                        if (ch == 8 && k == 2) {
+                            MRCA_H1_PAD()
+                        }
+                    } else if (k == 0) {
+                        MRCA_REQUEST_NEXT_AFTER()
+                    }
+                } else {
+                    // pair 0's output: accumulators -> H1E[c][0..63] (pair 1 reads columns >= 64 only), rows back as
+                    // float4, out
+                    if (ch < 4) {
+                        MRCA_CONV2_OUT(done0, done1, 0, 4 * ch + k, 1)
+                    } else if (ch < 8) {
+                        if (k < 2) row[2 * (ch - 4) + k] = *reinterpret_cast<const f32x4*>(orow + 4 * (2 * (ch - 4) + k) * kHPitch);
+                    } else {
+                        if (k < 2) *reinterpret_cast<f32x4*>(out + 4 * (2 * (ch - 8) + k) * kL2) = row[2 * (ch - 8) + k];
+                        if (ch == 11 && k == 2) {
+                            MRCA_CONV1_LOAD(0, 0)   // the next robot's first conv1 operands (staged during pair 0)
                         }
                     }
-                    if (ch == 3 || ch == 5) {
-#pragma unroll
-                        for (int q = 4 * (ch == 5); q < 4 * (ch == 5) + 4; ++q) {
-                            const float4 v = *reinterpret_cast<const float4*>(orow + 4 * q * kHPitch);
-                            *reinterpret_cast<float4*>(out + 4 * q * kL2) = v;
-                        }
-                    }
-                }
-                MRCA_PIN();
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int s = 4 * ch + k;
-                    acc0 = MRCA_MFMA(a2[s], b0[cur][k], acc0);
-                    acc1 = MRCA_MFMA(a2[s], b1v[cur][k], acc1);
                 }
                 MRCA_PIN();
             }
-#undef MRCA_CONV2_LOAD
-            if (P == 0) {
+            if (g == 11) {
                 done0 = acc0;
                 done1 = acc1;
             }
         }
-        // --- pair 1's epilogue through H1E[c][64..127] (its MFMAs have read it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            oe[rowmap(r, 0) * kHPitch + 64] = acc0[r] > 0.0f ? acc0[r] : 0.0f;
-            oe[rowmap(r, 0) * kHPitch + 96] = acc1[r] > 0.0f ? acc1[r] : 0.0f;
-        }
-        MRCA_PIN();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(orow + 4 * q * kHPitch + 64);
-            *reinterpret_cast<float4*>(out + 4 * q * kL2 + 64) = v;
-        }
-        MRCA_PIN();
+        p1a = acc0;
+        p1b = acc1;
+        out_prev = out;
+        have_prev = true;
     }
+    // --- the last robot's pair 1 leaves
+    MRCA_CONV2_OUT(p1a, p1b, 1, 0, 16)
+    MRCA_PIN();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(orow + 4 * q * kHPitch + 64);
+        *reinterpret_cast<f32x4*>(out_prev + 4 * q * kL2 + 64) = v;
+    }
+#undef MRCA_STAGE_SCAN
+#undef MRCA_REQUEST_NEXT
+#undef MRCA_REQUEST_NEXT_AFTER
+#undef MRCA_CONV1_LOAD
+#undef MRCA_CONV1_OUT
+#undef MRCA_CONV2_LOAD
+#undef MRCA_CONV2_LOAD_K
+#undef MRCA_H1_PAD
+#undef MRCA_CONV2_OUT
 }
 
 }  // namespace mrca_policy
