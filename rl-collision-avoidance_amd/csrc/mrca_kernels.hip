@@ -627,20 +627,16 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
 // no difference.)  Marching the K beams of a thread in LOCK STEP (grid_march_skip_n: K lookups in flight per wait) is
 // implemented and measured too: slower than one after the other (34.7 vs 28.1 us, profiles/r02_c_*), see mrca_abi.hip.
-// ALL: the launch behind a step -- every robot is cast, no early exit, nothing to wait for before the requests are out.
-template <int K, bool BIG, bool SEQ, bool ALL>
+template <int K, bool BIG, bool SEQ>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     MRCA_RSTAMP(0);
     const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
     const int tid = threadIdx.x;
-    // The fresh flag and the ring head are needed by the epilogue only (after a step every robot is cast), so they must
-    // not hold up the requests below: the workgroup's chain used to be kernel arguments -> flag -> head -> robot record ->
-    // neighbour candidate, four dependent round trips, 3 500 of a workgroup's 19 000 ticks before the first request was
-    // out (profiles/r03_k_ablate_raycast_phase_stamps.txt).  Now both are requested behind the candidate (see below).
-    if constexpr (!ALL) {
-        if (only_fresh && e.fresh[n] == 0) return;  // block-uniform
-    }
+    // (A variant of this kernel without the early exit -- so that nothing is waited for before every request of the
+    // workgroup is out -- was measured and changed nothing: 27.96 us either way, profiles/r03_l_bench_env.json.  The
+    // launch is bound by VALU issue with eight waves per SIMD, not by a workgroup's own latency chain.)
+    if (only_fresh && e.fresh[n] == 0) return;  // block-uniform
 
     float4* nb = reinterpret_cast<float4*>(lds);
     int2* nbi = reinterpret_cast<int2*>(nb + kWave);
@@ -1283,27 +1279,25 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
     const bool seq = e.ray_sequential != 0;
-#define MRCA_RAY(K, BIG, SEQ, ALL) \
-    hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, ALL>), grid, dim3(threads), lds, s, e, only_fresh)
+#define MRCA_RAY(K, BIG, SEQ) hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, e, only_fresh)
     if (e.big) {
         switch (e.ray_shift) {
-            case 0: MRCA_RAY(1, true, false, false); break;
-            case 1:
-                if (only_fresh) MRCA_RAY(2, true, false, false);
-                else MRCA_RAY(2, true, false, true);
-                break;
-            default: MRCA_RAY(4, true, false, false); break;
+            case 0: MRCA_RAY(1, true, false); break;
+            case 1: MRCA_RAY(2, true, false); break;
+            default: MRCA_RAY(4, true, false); break;
         }
         return;
     }
     switch (e.ray_shift) {
-        case 0: MRCA_RAY(1, false, false, false); break;
+        case 0: MRCA_RAY(1, false, false); break;
         case 1:
-            if (seq && !only_fresh) MRCA_RAY(2, false, true, true);       // the product's step
-            else if (seq) MRCA_RAY(2, false, true, false);
-            else MRCA_RAY(2, false, false, false);
+            if (seq) MRCA_RAY(2, false, true);
+            else MRCA_RAY(2, false, false);
             break;
-        default: MRCA_RAY(4, false, false, false); break;
+        default:
+            if (seq) MRCA_RAY(4, false, true);      // two waves per workgroup: all 4096 robots resident at once
+            else MRCA_RAY(4, false, false);
+            break;
     }
 #undef MRCA_RAY
 }

@@ -321,12 +321,13 @@ def test_full_batch_bit_exact_vs_c_oracle(hip, name, worlds, R, steps):
 
 @pytest.mark.parametrize("knob,label", [(256, "1 beam per thread"), (512, "2 beams per thread, one after the other"),
                                         (512 + 4096, "2 beams per thread in lock step"),
-                                        (768, "4 beams per thread in lock step"),
+                                        (768, "4 beams per thread, one after the other (2 waves per workgroup)"),
+                                        (768 + 4096, "4 beams per thread in lock step"),
                                         (256 + 2048, "1 beam per thread, dedicated preparation wave"),
                                         (512 + 2048, "2 beams sequential, dedicated preparation wave"),
                                         (512 + 4096 + 2048, "2 beams lock step, dedicated preparation wave"),
-                                        (768 + 2048, "4 beams lock step, dedicated preparation wave"),
-                                        (64, "frame-stack shift as a launch of its own")])
+                                        (768 + 4096 + 2048, "4 beams lock step, dedicated preparation wave"),
+                                        (64, "phase stamps drain the memory queues")])
 def test_raycast_launch_shapes_bit_exact(hip, knob, label):
     """The launch-shape knobs of the PROFILING build (beams per marching thread, with / without the dedicated
     preparation wave) only change how the work is dealt to threads: every shape must match the oracle bit-for-bit."""

@@ -32,10 +32,11 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
                          (8, "move: no outline test"), (16, "move: no collision loop"), (32, "move: no resets"),
                          (56, "move: none of the three"),
                          (256, "1 beam/thread, 512 thr, wave 0 prepares"), (512, "2 beams sequential, wave 0 prepares (product)"),
-                         (512 + 4096, "2 beams lock-step, wave 0 prepares"), (768, "4 beams lock-step, wave 0 prepares"),
+                         (512 + 4096, "2 beams lock-step, wave 0 prepares"), (768 + 4096, "4 beams lock-step, wave 0 prepares"),
+                         (768, "4 beams sequential, wave 0 prepares (2 waves / workgroup)"),
                          (256 + 2048, "1 beam/thread + dedicated prep wave"), (512 + 2048, "2 beams sequential + prep wave"),
                          (512 + 4096 + 2048, "2 beams lock-step + prep wave"),
-                         (768 + 2048, "4 beams lock-step + prep wave"), (0, "full again")):
+                         (768 + 4096 + 2048, "4 beams lock-step + prep wave"), (0, "full again")):
         try:
             env.set_debug_flags(flags)
         except Exception as exc:  # a variant this build / map does not support
