@@ -61,6 +61,23 @@ __device__ inline f32x16 zero16() {
     return z;
 }
 
+#if defined(MRCA_PROFILING)
+// profiling build only: s_memtime ticks a wave spends in each phase of a robot (summed over its robots) + robot count;
+// reading the clock drains the LDS queue, so the stamped kernel runs a few per cent slower than the product
+constexpr int kFwdStamps = 8, kFwdStampWaves = 1024;
+__device__ unsigned long long g_fwd_stamps[kFwdStamps][kFwdStampWaves];
+#define MRCA_FSTAMP(k)                                              \
+    {                                                               \
+        MRCA_PIN();                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        fst[k] += t_ - fprev;                                       \
+        fprev = t_;                                                 \
+        MRCA_PIN();                                                 \
+    }
+#else
+#define MRCA_FSTAMP(k)
+#endif
+
 // the six float4 a lane loads of robot n's scan: float4 q covers logical frame q / 2; with a ring (head != NULL) frame f
 // sits in slot (head[n] + 1 + f) mod 3
 __device__ __forceinline__ void request_scan(float4 (&sx)[6], const float* __restrict__ obs, int n, int hd, int lane) {
@@ -209,6 +226,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     MRCA_CONV1_LOAD(0, 0)
     MRCA_PIN();
 
+#if defined(MRCA_PROFILING)
+    unsigned long long fst[kFwdStamps] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long fprev = __builtin_amdgcn_s_memtime();
+#endif
     f32x16 p1a = zero16(), p1b = zero16();     // conv2 pair 1 of the previous robot, still to leave
     float* out_prev = feat;
     bool have_prev = false;
@@ -247,6 +268,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
                 }
                 MRCA_PIN();
             }
+            MRCA_FSTAMP(tp)
         }
 
         // --- conv2: two pairs of position tiles (positions 64 P .. 64 P + 63), 12 chunks of four K steps each
@@ -303,13 +325,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
             if (g == 11) {
                 done0 = acc0;
                 done1 = acc1;
+                MRCA_FSTAMP(4)
+            }
+            if (g == 23) {
+                MRCA_FSTAMP(5)
             }
         }
         p1a = acc0;
         p1b = acc1;
         out_prev = out;
         have_prev = true;
+#if defined(MRCA_PROFILING)
+        fst[6] += 1;
+#endif
     }
+#if defined(MRCA_PROFILING)
+    if (lane == 0 && gwave < kFwdStampWaves)
+        for (int k = 0; k < kFwdStamps; ++k) g_fwd_stamps[k][gwave] = fst[k];
+#endif
     // --- the last robot's pair 1 leaves
     MRCA_CONV2_OUT(p1a, p1b, 1, 0, 16)
     MRCA_PIN();
@@ -338,6 +371,30 @@ struct DeviceInfo {
 };
 static DeviceInfo g_dev[64];     // per DEVICE: CU count and the dynamic-LDS attribute (a second GPU needs its own)
 }  // namespace mrca_policy
+
+#if defined(MRCA_PROFILING)
+// Profiling build only: where the waves of the LAST mrca_lidar_features launch spent their time.  out[0..3] = conv1 tile
+// pairs 0..3 (pair 0 carries the previous robot's output along), out[4] / out[5] = conv2 tile pairs 0 / 1: s_memtime ticks
+// per robot, averaged over the waves that had work; out[6] = robots per wave.  Synchronises the device.
+extern "C" int mrca_debug_fwd_stamps(double* out /* [7] */) {
+    using namespace mrca_policy;
+    if (!out) return mrca::set_error(MRCA_ERR_INVALID, "mrca_debug_fwd_stamps: NULL");
+    if (hipDeviceSynchronize() != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_debug_fwd_stamps: sync failed");
+    static unsigned long long h[kFwdStamps][kFwdStampWaves];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fwd_stamps), sizeof(h), 0, hipMemcpyDeviceToHost) != hipSuccess)
+        return mrca::set_error(MRCA_ERR_HIP, "mrca_debug_fwd_stamps: copy failed");
+    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    int waves = 0;
+    for (int w = 0; w < kFwdStampWaves; ++w) {
+        if (h[6][w] == 0) continue;
+        ++waves;
+        for (int k = 0; k < 6; ++k) sum[k] += (double)h[k][w] / (double)h[6][w];
+        sum[6] += (double)h[6][w];
+    }
+    for (int k = 0; k < 7; ++k) out[k] = waves ? sum[k] / waves : 0.0;
+    return MRCA_OK;
+}
+#endif
 
 extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t n_robots, int32_t frames,
                                    int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
