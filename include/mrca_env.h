@@ -260,9 +260,9 @@ int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out);
  * last end, out[15] = mean workgroup entry, out[16] = share of workgroups starting in the first tenth of the launch. */
 int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */);
 /* s_memtime ticks per robot a wave of the last mrca_lidar_features launch spent in conv1's tile pairs 0..3 (out[0..3]) and
- * conv2's tile pairs 0 / 1 (out[4], out[5]); out[6] = robots per wave.  192 / 1024 ticks of MFMA work per conv1 pair... see
+ * conv2's tile pairs 0 / 1 (out[4], out[5]); out[6] = robots per wave; out[7] = shader clock during the loop [GHz].  See
  * tools/fwd_phases.py. */
-int mrca_debug_fwd_stamps(double* out /* [7] */);
+int mrca_debug_fwd_stamps(double* out /* [8] */);
 #endif
 
 #ifdef __cplusplus

@@ -103,15 +103,50 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     const int tower = gwave & 1;                 // waves come in (actor, critic) pairs on the same robots
     const int col = lane & 31, hl = lane >> 5;
 
-    // --- the tower's weights as MFMA A fragments A[i = out channel = col][k], in the K orders of mrca_policy_layout.h
+    // --- the tower's weights as MFMA A fragments A[i = out channel = col][k], in the K orders of mrca_policy_layout.h.
+    // Fetched COALESCED (float4 per lane, 12 + 2 instructions) into this wave's still unused H1 area, rows padded to odd
+    // pitches, and picked up from there: as 56 loads with a lane stride of 96 / 15 floats every instruction touched 64 cache
+    // lines -- ~7 us of a launch's ~13 us outside the robot loop, four waves behind one L1 (profiles/r03_n_fwd_phases.txt).
     float a1[8], a2[48];
+    {
+        constexpr int kW2L = kH1E, kW1L = kH1E + 32 * 97;       // [32][97], [32][17]
+        static_assert(kW1L + 32 * 17 <= kWaveFloats, "the weight staging fits the H1 area");
+        const float4* w2v = reinterpret_cast<const float4*>(w2 + tower * 3072);
+        const float4* w1v = reinterpret_cast<const float4*>(w1 + tower * 480);
+        float4 t2[12], t1[2];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int kk = conv1_kk(s, hl);
-        a1[s] = kk < 15 ? w1[tower * 480 + col * 15 + kk] : b1[tower * 32 + col];
+        for (int q = 0; q < 12; ++q) t2[q] = w2v[q * 64 + lane];
+        t1[0] = w1v[lane];
+        t1[1] = w1v[lane < 56 ? 64 + lane : 64];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int f = q * 64 + lane;                          // float4 index: row f / 24, columns 4 (f % 24) ...
+            float* d = lds + kW2L + (f / 24) * 97 + 4 * (f % 24);
+            d[0] = t2[q].x;
+            d[1] = t2[q].y;
+            d[2] = t2[q].z;
+            d[3] = t2[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 0 || lane < 56) {
+                const float v[4] = {t1[q].x, t1[q].y, t1[q].z, t1[q].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * (q * 64 + lane) + j;        // element: row e / 15, column e % 15
+                    lds[kW1L + (e / 15) * 17 + e % 15] = v[j];
+                }
+            }
+        }
+        const float bias1 = b1[tower * 32 + col];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int kk = conv1_kk(s, hl);
+            a1[s] = kk < 15 ? lds[kW1L + col * 17 + kk] : bias1;
+        }
+#pragma unroll
+        for (int s = 0; s < 48; ++s) a2[s] = lds[kW2L + col * 97 + conv2_ci(s, hl) * 3 + conv2_tap(s, hl)];
     }
-#pragma unroll
-    for (int s = 0; s < 48; ++s) a2[s] = w2[tower * 3072 + col * 96 + conv2_ci(s, hl) * 3 + conv2_tap(s, hl)];
     float bias2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias2[r] = b2[tower * 32 + rowmap(r, hl)];
@@ -229,6 +264,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
 #if defined(MRCA_PROFILING)
     unsigned long long fst[kFwdStamps] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long fprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long freal0 = __builtin_amdgcn_s_memrealtime();      // the constant 100 MHz counter
 #endif
     f32x16 p1a = zero16(), p1b = zero16();     // conv2 pair 1 of the previous robot, still to leave
     float* out_prev = feat;
@@ -340,6 +376,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
 #endif
     }
 #if defined(MRCA_PROFILING)
+    fst[7] = __builtin_amdgcn_s_memrealtime() - freal0;
     if (lane == 0 && gwave < kFwdStampWaves)
         for (int k = 0; k < kFwdStamps; ++k) g_fwd_stamps[k][gwave] = fst[k];
 #endif
@@ -375,23 +412,29 @@ static DeviceInfo g_dev[64];     // per DEVICE: CU count and the dynamic-LDS att
 #if defined(MRCA_PROFILING)
 // Profiling build only: where the waves of the LAST mrca_lidar_features launch spent their time.  out[0..3] = conv1 tile
 // pairs 0..3 (pair 0 carries the previous robot's output along), out[4] / out[5] = conv2 tile pairs 0 / 1: s_memtime ticks
-// per robot, averaged over the waves that had work; out[6] = robots per wave.  Synchronises the device.
-extern "C" int mrca_debug_fwd_stamps(double* out /* [7] */) {
+// per robot, averaged over the waves that had work; out[6] = robots per wave; out[7] = the shader clock during the loop
+// [GHz] (s_memtime against the constant 100 MHz s_memrealtime).  Synchronises the device.
+extern "C" int mrca_debug_fwd_stamps(double* out /* [8] */) {
     using namespace mrca_policy;
     if (!out) return mrca::set_error(MRCA_ERR_INVALID, "mrca_debug_fwd_stamps: NULL");
     if (hipDeviceSynchronize() != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_debug_fwd_stamps: sync failed");
     static unsigned long long h[kFwdStamps][kFwdStampWaves];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fwd_stamps), sizeof(h), 0, hipMemcpyDeviceToHost) != hipSuccess)
         return mrca::set_error(MRCA_ERR_HIP, "mrca_debug_fwd_stamps: copy failed");
-    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int waves = 0;
     for (int w = 0; w < kFwdStampWaves; ++w) {
         if (h[6][w] == 0) continue;
         ++waves;
-        for (int k = 0; k < 6; ++k) sum[k] += (double)h[k][w] / (double)h[6][w];
+        double ticks = 0.0;
+        for (int k = 0; k < 6; ++k) {
+            sum[k] += (double)h[k][w] / (double)h[6][w];
+            ticks += (double)h[k][w];
+        }
         sum[6] += (double)h[6][w];
+        sum[7] += ticks / ((double)h[7][w] * 10.0);      // s_memtime ticks per ns of the 100 MHz counter = GHz
     }
-    for (int k = 0; k < 7; ++k) out[k] = waves ? sum[k] / waves : 0.0;
+    for (int k = 0; k < 8; ++k) out[k] = waves ? sum[k] / waves : 0.0;
     return MRCA_OK;
 }
 #endif

@@ -215,3 +215,34 @@ def test_kernel_data_movement_reproduces_conv1d_relu_conv1d_relu():
         assert not np.isnan(out).any()
         # the ReLU goes through fp32 bit patterns here: fp32 rounding of the fp64 emulation
         assert np.abs(out - want).max() < 1e-6, np.abs(out - want).max()
+
+
+def test_weight_staging_reaches_the_same_fragments():
+    """The prologue fetches W2 / W1 with coalesced float4 loads into padded LDS rows ([32][97], [32][17]) and picks the
+    MFMA A fragments up from there: same values as indexing the weight tensors directly."""
+    rng = np.random.default_rng(1)
+    w1 = rng.normal(0, 0.3, (32, 3, 5))
+    w2 = rng.normal(0, 0.1, (32, 32, 3))
+    W2L, W1L = kH1E, kH1E + 32 * 97
+    assert W1L + 32 * 17 <= WAVE_FLOATS and "kW1L = kH1E + 32 * 97" in SRC
+    lds = np.full(WAVE_FLOATS, np.nan)
+    f2, f1 = w2.reshape(-1), w1.reshape(-1)
+    for q in range(12):
+        for lane in range(64):
+            f = q * 64 + lane
+            d = W2L + (f // 24) * 97 + 4 * (f % 24)
+            lds[d: d + 4] = f2[4 * f: 4 * f + 4]
+    for q in range(2):
+        for lane in range(64):
+            if q == 0 or lane < 56:
+                for j in range(4):
+                    e = 4 * (q * 64 + lane) + j
+                    lds[W1L + (e // 15) * 17 + e % 15] = f1[e]
+    for s in range(48):
+        ci = np.array([L.pf_conv2_ci(s, int(h)) for h in HL])
+        tap = np.array([L.pf_conv2_tap(s, int(h)) for h in HL])
+        assert np.array_equal(lds[W2L + COL * 97 + ci * 3 + tap], w2[COL, ci, tap])
+    for s in range(8):
+        kk = np.array([L.pf_conv1_kk(s, int(h)) for h in HL])
+        m = kk < 15
+        assert np.array_equal(lds[W1L + COL[m] * 17 + kk[m]], w1.reshape(32, 15)[COL[m], kk[m]])

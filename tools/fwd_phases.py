@@ -35,13 +35,13 @@ for N in [int(a) for a in sys.argv[1:]] or [4096, 16384]:
         _lib.check(lib.mrca_lidar_features(*args), "mrca_lidar_features")
     e1.record()
     torch.cuda.synchronize()
-    t = (C.c_double * 7)()
+    t = (C.c_double * 8)()
     _lib.check(lib.mrca_debug_fwd_stamps(t), "mrca_debug_fwd_stamps")
     names = ("conv1 pair 0 (+ previous robot's output)", "conv1 pair 1", "conv1 pair 2", "conv1 pair 3", "conv2 pair 0 (+ next robot's scan)",
              "conv2 pair 1 (+ pair 0's output)")
     work = (16, 16, 16, 16, 96, 96)
     total = sum(t[k] for k in range(6))
     print(f"{N} rows: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per launch (stamped build), {t[6]:.1f} robots per wave, {total:.0f} ticks per robot "
-          f"(MFMA work: {256 * 64})")
+          f"(MFMA work: {256 * 64}); shader clock during the loop {t[7]:.3f} GHz")
     for k in range(6):
         print(f"   {names[k]:<44} {t[k]:8.0f} ticks   {work[k]:3d} MFMAs = {work[k] * 64:5d}   x{t[k] / (work[k] * 64):.2f}")

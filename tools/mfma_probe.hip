@@ -19,7 +19,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #define VOP(v) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v) : "v"(lane))
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void probe(float* out, int iters, unsigned long long* ticks) {
+__global__ __launch_bounds__(1024) void probe(float* out, int iters, unsigned long long* ticks, unsigned long long* real) {
     __shared__ float lds[4096];
     const int lane = threadIdx.x & 63;
     f32x16 c0, c1;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(1024) void probe(float* out, int iters, unsigned lo
     float l0 = 0.0f;
     lds[threadIdx.x] = a;
     __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();      // the constant 100 MHz counter
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -62,39 +63,50 @@ __global__ __launch_bounds__(1024) void probe(float* out, int iters, unsigned lo
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float s = l0 + (float)(v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7);
     for (int r = 0; r < 16; ++r) s += c0[r] + c1[r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x] = t1 - t0;
+        real[blockIdx.x] = r1 - r0;
+    }
 }
 
 template <int MODE>
 static void run(const char* label, int waves_per_simd, int cus) {
     const int iters = 20000, threads = 256 * waves_per_simd;      // 4 SIMDs per CU
     float* out;
-    unsigned long long* ticks;
+    unsigned long long *ticks, *real;
     hipMalloc(&out, sizeof(float) * (size_t)cus * threads);
     hipMalloc(&ticks, sizeof(unsigned long long) * cus);
+    hipMalloc(&real, sizeof(unsigned long long) * cus);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(threads), 0, 0, out, 100, ticks);
+    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(threads), 0, 0, out, 100, ticks, real);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(threads), 0, 0, out, iters, ticks);
+    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(threads), 0, 0, out, iters, ticks, real);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.0f;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(cus);
+    std::vector<unsigned long long> h(cus), hr(cus);
     hipMemcpy(h.data(), ticks, sizeof(unsigned long long) * cus, hipMemcpyDeviceToHost);
-    double avg = 0.0;
-    for (auto t : h) avg += (double)t;
+    hipMemcpy(hr.data(), real, sizeof(unsigned long long) * cus, hipMemcpyDeviceToHost);
+    double avg = 0.0, ghz = 0.0;
+    for (int i = 0; i < cus; ++i) {
+        avg += (double)h[i];
+        ghz += (double)h[i] / ((double)hr[i] * 10.0);
+    }
     avg /= cus;
+    ghz /= cus;
     const double mfma_per_simd = 16.0 * iters * waves_per_simd;
     const double flops = mfma_per_simd * 4.0 * cus * 4096.0;
-    printf("%-58s %d wave(s)/SIMD  %7.2f ns per MFMA per SIMD  %7.1f memtime ticks per MFMA  %6.1f TFLOP/s\n", label, waves_per_simd,
-           ms * 1e6 / mfma_per_simd, avg / (16.0 * iters) / waves_per_simd, flops / (ms * 1e-3) / 1e12);
+    printf("%-58s %d wave(s)/SIMD  %7.2f ns per MFMA per SIMD  %7.1f memtime ticks per MFMA  %6.1f TFLOP/s  clock %.3f GHz\n", label, waves_per_simd,
+           ms * 1e6 / mfma_per_simd, avg / (16.0 * iters) / waves_per_simd, flops / (ms * 1e-3) / 1e12, ghz);
+    hipFree(real);
     hipFree(out);
     hipFree(ticks);
 }
