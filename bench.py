@@ -139,10 +139,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--mode", default="env", choices=["env", "rollout", "train"])
     ap.add_argument("--worlds", type=int, default=None,
-                    help="worlds per GPU (default: 128 at 1 GPU = configs[1]; 187 Stage-2 worlds at N > 1 = configs[3])")
+                    help="worlds per GPU (default: 128 Stage-1 rinks = configs[1] at every N; 187 with --scenario stage2)")
     ap.add_argument("--robots-per-world", type=int, default=32)
     ap.add_argument("--scenario", default=None, choices=["stage1", "stage2"],
-                    help="default: stage1 at 1 GPU (BASELINE configs[1]), stage2 at N > 1 (configs[3]: 8192+ robots/GPU)")
+                    help="default: stage1 (BASELINE configs[1]) at every N -- weak scaling of ONE per-GPU workload, so that "
+                         "value(N) / (N x value(1)) is a scaling efficiency; stage2 = configs[2] / configs[3]'s per-GPU "
+                         "workload (8192+ robots per GPU on the Stage-2 map)")
     ap.add_argument("--policy-dtype", default="f32", choices=["f32", "bf16"],
                     help="rollout/train: dtype of the policy INFERENCE pass (update stays fp32); f32 = the reference's")
     ap.add_argument("--update-dtype", default="f32", choices=["f32", "bf16"],
@@ -162,10 +164,12 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # BASELINE.json: configs[1] (4096 robots, Stage-1 rink) is the single-GPU workload; configs[3] (65 536 robots over
-    # 8 GPUs = 8192+ per GPU on the Stage-2 map, ppo_stage2.py:32 / worlds/stage2.world) is the multi-GPU one
+    # BASELINE.json: configs[1] (4096 robots, Stage-1 rink) is the per-GPU workload at EVERY N (weak scaling: rounds 1-2
+    # switched to configs[3]'s Stage-2 workload at N > 1, which made value(N) / value(1) compare two different worlds).
+    # configs[3] (65 536 robots over 8 GPUs = 8192+ per GPU on the Stage-2 map, ppo_stage2.py:32 / worlds/stage2.world)
+    # is `--scenario stage2` (187 worlds x 44 robots per GPU).
     if args.scenario is None:
-        args.scenario = "stage1" if world_size == 1 else "stage2"
+        args.scenario = "stage1"
     if args.worlds is None:
         args.worlds = 128 if args.scenario == "stage1" else 187
     if not torch.cuda.is_available():
@@ -278,25 +282,27 @@ def main():
     # multi-GPU side figure: a few PPO updates with the flat-bucket gradient all-reduce on the measured path
     # (the env tick itself needs no collective, so `value` alone would never touch RCCL)
     if world_size > 1 and args.mode == "env" and not args.no_extra:
-        from mrca import ppo as _ppo
-        from mrca.trainer import HParams, Stage1Trainer
-        hp = HParams(horizon=16, batch_size=16384, epoch=1)
-        tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0, stage2=False)
-        tr.started = True
-        tr.run(hp.horizon)                       # one warm-up update (MIOpen / allocator / RCCL set-up)
-        barrier()
-        tt0 = time.perf_counter()
-        n_upd = 2
-        tr.run(n_upd * hp.horizon)
-        barrier()
-        dt_tr = time.perf_counter() - tt0
-        extra["train_side_figure"] = {
-            "value": N * world_size * n_upd * hp.horizon / dt_tr, "unit": "agent-steps/s",
-            "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                           "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
-                           "optimizer_steps": len(tr.loss_log) - len(tr.loss_log) // (n_upd + 1)},
-            "note": "env + fp32 policy + GAE + PPO update (horizon 16, one epoch, minibatch 16384 per rank), every "
-                    "optimiser step all-reduces the flat gradient bucket; not part of `value`"}
+        try:
+            from mrca.trainer import HParams, Stage1Trainer
+            hp = HParams(horizon=16, batch_size=16384, epoch=1)
+            tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0, stage2=False)
+            tr.started = True
+            tr.run(hp.horizon)                       # one warm-up update (MIOpen / allocator / RCCL set-up)
+            barrier()
+            tt0 = time.perf_counter()
+            n_upd = 2
+            tr.run(n_upd * hp.horizon)
+            barrier()
+            dt_tr = time.perf_counter() - tt0
+            extra["train_side_figure"] = {
+                "value": N * world_size * n_upd * hp.horizon / dt_tr, "unit": "agent-steps/s",
+                "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
+                               "optimizer_steps": len(tr.loss_log) - len(tr.loss_log) // (n_upd + 1)},
+                "note": "env + fp32 policy + GAE + PPO update (horizon 16, one epoch, minibatch 16384 per rank), every "
+                        "optimiser step all-reduces the flat gradient bucket; not part of `value`"}
+        except Exception as exc:      # a failure every rank shares (set-up, memory) must not cost the run its line
+            extra["train_side_figure"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     per_rank = None

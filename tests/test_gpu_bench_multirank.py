@@ -45,18 +45,22 @@ def test_bench_two_ranks_same_gpu():
     assert tr["collective"]["optimizer_steps"] >= 2 and tr["value"] > 0
 
 
-def test_bench_multi_gpu_default_workload_is_configs3():
-    """BASELINE configs[3]: N > 1 defaults to the Stage-2 map with 187 worlds x 44 robots = 8228 robots per GPU."""
+def test_bench_multi_gpu_default_workload_is_the_single_gpu_one():
+    """Weak scaling of ONE per-GPU workload: N > 1 defaults to configs[1] per GPU (128 Stage-1 rinks x 32 robots), like
+    N = 1, so that value(N) / (N x value(1)) is a scaling efficiency; configs[3]'s per-GPU workload (187 Stage-2 worlds x
+    44 robots) is ``--scenario stage2``."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, MRCA_BENCH_SAME_DEVICE="1", MRCA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_port()), os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
-           "--warmup", "5", "--no-cpu-baseline", "--no-extra"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert j["config"]["robots_per_gpu"] == 187 * 44 and j["config"]["workload"].startswith("stage2: 187 worlds")
+    for extra, robots, prefix in (([], 128 * 32, "stage1: 128 worlds"), (["--scenario", "stage2"], 187 * 44, "stage2: 187 worlds")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_port()), os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+               "--warmup", "5", "--no-cpu-baseline", "--no-extra"] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert j["config"]["robots_per_gpu"] == robots and j["config"]["workload"].startswith(prefix)
+        assert j["scaling"] == "weak" and j["n_gpus"] == 2
 
 
 def test_bench_two_ranks_over_rccl():
