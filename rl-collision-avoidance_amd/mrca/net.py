@@ -117,6 +117,20 @@ class CNNPolicy(nn.Module):
                     old[k].copy_(v)
             else:
                 self._rc = new
+            self._rc_stamp = self._param_stamp()
+        return self._rc
+
+    def _param_stamp(self):
+        """What the derived copies were made from: every parameter's in-place version counter (optimiser steps,
+        ``copy_``, broadcasts bump it), storage address and device (``.to()`` / ``.cuda()`` swap the storage)."""
+        return tuple((p._version, p.data_ptr(), p.device) for p in self.parameters())
+
+    def _rollout_cache(self):
+        """The cache, rebuilt first if any parameter changed since it was made -- whoever changed it (the trainer
+        refreshes it itself after an update, so this is one tuple comparison per eager call; a tick replayed as a
+        hipGraph does not come through here, the refresh is in place for its sake)."""
+        if getattr(self, "_rc", None) is None or getattr(self, "_rc_stamp", None) != self._param_stamp():
+            self.refresh_rollout_cache()
         return self._rc
 
     def mean_value_fused(self, x, goal, speed, head=None):
@@ -125,7 +139,7 @@ class CNNPolicy(nn.Module):
         summation order only (tests/test_gpu_policy_ops.py: 1e-5).  No autograd.  ``head``: ``x`` is the env's frame
         ring and head[n] the slot of robot n's newest frame (VecStageWorld.policy_obs())."""
         from . import policy_ops
-        rc = getattr(self, "_rc", None) or self.refresh_rollout_cache()
+        rc = self._rollout_cache()
         with torch.no_grad():
             feat = policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head)   # [2, N, 4096]
             h = torch.relu(torch.baddbmm(rc["fc1_b"], feat, rc["fc1_w"]))                      # [2, N, 256]
@@ -143,7 +157,7 @@ class CNNPolicy(nn.Module):
         -> value [N,1], action [N,2], logprob [N,1], scaled [N,2], mean [N,2].  fp32; differs from the stock path by
         summation order only (tests/test_gpu_policy_ops.py)."""
         from . import policy_ops
-        rc = getattr(self, "_rc", None) or self.refresh_rollout_cache()
+        rc = self._rollout_cache()
         with torch.no_grad():
             feat = policy_ops.lidar_features(x, rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head)   # [2, N, 4096]
             h1 = torch.baddbmm(rc["fc1_b"], feat, rc["fc1_w"])                                        # [2, N, 256], pre-ReLU

@@ -101,3 +101,29 @@ def test_kl_adaptive_lr_and_logstd_floor():
     ppo.ppo_update_stage1(policy=pol, optimizer=big, batch_size=16, memory=mem, epoch=2, coeff_entropy=5e-4,
                           clip_value=0.1, num_step=T, num_env=N, frames=3, obs_size=512, act_size=2, logstd_min=-1.2)
     assert float(pol.logstd.detach().min()) >= -1.2
+
+
+def test_rollout_cache_follows_the_parameters_whoever_changes_them():
+    """The fused rollout path reads tower-major COPIES of the parameters.  They are rebuilt lazily whenever any parameter's
+    in-place version, storage or device differs from what the copies were made from -- an optimiser step outside the
+    trainer, a ``copy_`` (broadcast), ``load_state_dict`` -- and IN PLACE (a captured tick keeps reading the same addresses)."""
+    import torch
+    from mrca.net import CNNPolicy
+    pol = CNNPolicy(3, 2)
+    rc = pol._rollout_cache()
+    addr = rc["fc1_w"].data_ptr()
+    assert torch.equal(rc["w1"][0], pol.act_fea_cv1.weight) and pol._rollout_cache() is rc
+    with torch.no_grad():
+        pol.act_fea_cv1.weight.add_(1.0)                       # e.g. an optimiser step the trainer did not make
+        pol.crt_fc1.bias.copy_(torch.full_like(pol.crt_fc1.bias, 3.0))       # e.g. a parameter broadcast
+    assert not torch.equal(rc["w1"][0], pol.act_fea_cv1.weight)                # stale until somebody asks
+    rc2 = pol._rollout_cache()
+    assert rc2 is rc and rc["fc1_w"].data_ptr() == addr                        # refreshed in place
+    assert torch.equal(rc["w1"][0], pol.act_fea_cv1.weight) and float(rc["fc1_b"][1, 0, 0]) == 3.0
+    sd = {k: v.clone() * 0.5 for k, v in pol.state_dict().items()}
+    pol.load_state_dict(sd)
+    assert torch.equal(pol._rollout_cache()["w2"][1], pol.crt_fea_cv2.weight)
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-2)
+    pol.logstd.grad = torch.ones_like(pol.logstd)
+    opt.step()
+    assert torch.equal(pol._rollout_cache()["logstd"], pol.logstd.detach().reshape(-1))
