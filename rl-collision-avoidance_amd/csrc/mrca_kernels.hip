@@ -654,8 +654,10 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     // the robot's own record: pose, sin / cos and the field entry of its cell.  Block-uniform -- but fetched with VECTOR
     // loads (the index goes through an opaque zero): as scalar loads they shared the out-of-order scalar counter with
     // the kernel arguments, and the neighbour candidate below could not be requested before they were back.
-    int lane_zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    // (Not in big worlds: there the neighbour enumeration hashes the robot's cell per chunk, wave-uniform work that
+    // belongs on the scalar unit -- measured: 513 vs 492 us per 50 000-robot launch, profiles/r03_s_bigworld_shards8.jsonl.)
+    int lane_zero = 0;
+    if constexpr (!BIG) asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     const int nv = n + lane_zero;
     const float x = e.pose[nv * 3 + 0], y = e.pose[nv * 3 + 1];
     const float4 hd = e.head[nv];
