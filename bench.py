@@ -31,6 +31,7 @@ for p in (os.path.join(ROOT, "rl-collision-avoidance_amd"), ROOT):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+SIDE_FIGURE_TIMEOUT_S = 240
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Algorithmic HBM bytes per agent-step.  Since round 3 the frame stack is a ring: a tick writes the scan and
 # ONE observation frame per robot and ~0.1 kB of state -- no shift (rounds 1-2: + 4096 read + 4096 written, B_env_stack).
@@ -279,31 +280,6 @@ def main():
                                                 "GEMMs, tick replayed as a hipGraph), 100 ticks after 10 warm-up ticks; not "
                                                 "part of `value`"}
 
-    # multi-GPU side figure: a few PPO updates with the flat-bucket gradient all-reduce on the measured path
-    # (the env tick itself needs no collective, so `value` alone would never touch RCCL)
-    if world_size > 1 and args.mode == "env" and not args.no_extra:
-        try:
-            from mrca.trainer import HParams, Stage1Trainer
-            hp = HParams(horizon=16, batch_size=16384, epoch=1)
-            tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0, stage2=False)
-            tr.started = True
-            tr.run(hp.horizon)                       # one warm-up update (MIOpen / allocator / RCCL set-up)
-            barrier()
-            tt0 = time.perf_counter()
-            n_upd = 2
-            tr.run(n_upd * hp.horizon)
-            barrier()
-            dt_tr = time.perf_counter() - tt0
-            extra["train_side_figure"] = {
-                "value": N * world_size * n_upd * hp.horizon / dt_tr, "unit": "agent-steps/s",
-                "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                               "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
-                               "optimizer_steps": len(tr.loss_log) - len(tr.loss_log) // (n_upd + 1)},
-                "note": "env + fp32 policy + GAE + PPO update (horizon 16, one epoch, minibatch 16384 per rank), every "
-                        "optimiser step all-reduces the flat gradient bucket; not part of `value`"}
-        except Exception as exc:      # a failure every rank shares (set-up, memory) must not cost the run its line
-            extra["train_side_figure"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
-
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     per_rank = None
     ranks_seen, devices = None, None
@@ -326,7 +302,9 @@ def main():
     total_robots = N * world_size
     value = total_robots * args.steps / elapsed
 
-    if rank == 0:
+
+    def emit():
+        """rank 0: the ONE JSON line (everything it needs is final before the side figure below starts)."""
         ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
         mv_avg_s = (mv_ms / launches) * 1e-3 if launches else float("nan")
         traffic, traffic_note = pmc_traffic(N, args.scenario)
@@ -366,9 +344,10 @@ def main():
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
-                         "note": "HBM is the nominal roof (SURVEY 8d); the ray cast is bound by its per-robot latency chain and the "
-                                 "march, not by traffic or VALU issue (608 VALU instructions per wave, 63 % of the launch's "
-                                 "issue cycles); see DESIGN.md 5"},
+                         "note": "HBM is the nominal roof (SURVEY 8d); the ray cast is bound by VALU issue -- the arithmetic of the exact "
+                                 "march and the slab tests, 608 VALU instructions per wave x 16 384 waves = 63 % of the launch's issue "
+                                 "slots, eight waves per SIMD -- not by traffic and not by a workgroup's latency chain (stamped and "
+                                 "varied in round 3: DESIGN.md 5.2)"},
         }
         if args.mode == "rollout":
             # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2
@@ -390,6 +369,50 @@ def main():
             out["devices"] = devices
         out.update(extra)
         print(json.dumps(out))
+
+    # multi-GPU side figure: a few PPO updates with the flat-bucket gradient all-reduce on the measured path
+    # (the env tick itself needs no collective, so `value` alone would never touch RCCL)
+    if world_size > 1 and args.mode == "env" and not args.no_extra:
+        # (the first time RCCL runs on this code is the driver's SCALE run: a collective that never answers must not cost
+        # the run its line -- after SIDE_FIGURE_TIMEOUT_S rank 0 prints the line without the side figure and every rank
+        # leaves; `value` and the per-rank rates above are final before this starts)
+        import threading
+        side_done = threading.Event()
+
+        def give_up():
+            if side_done.wait(SIDE_FIGURE_TIMEOUT_S):
+                return
+            extra["train_side_figure"] = {"error": f"no answer within {SIDE_FIGURE_TIMEOUT_S} s (a collective that hangs?)"}
+            if rank == 0:
+                emit()
+            sys.stdout.flush()
+            os._exit(0)
+        threading.Thread(target=give_up, daemon=True).start()
+        try:
+            from mrca.trainer import HParams, Stage1Trainer
+            hp = HParams(horizon=16, batch_size=16384, epoch=1)
+            tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0, stage2=False)
+            tr.started = True
+            tr.run(hp.horizon)                       # one warm-up update (MIOpen / allocator / RCCL set-up)
+            barrier()
+            tt0 = time.perf_counter()
+            n_upd = 2
+            tr.run(n_upd * hp.horizon)
+            barrier()
+            dt_tr = time.perf_counter() - tt0
+            extra["train_side_figure"] = {
+                "value": N * world_size * n_upd * hp.horizon / dt_tr, "unit": "agent-steps/s",
+                "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
+                               "optimizer_steps": len(tr.loss_log) - len(tr.loss_log) // (n_upd + 1)},
+                "note": "env + fp32 policy + GAE + PPO update (horizon 16, one epoch, minibatch 16384 per rank), every "
+                        "optimiser step all-reduces the flat gradient bucket; not part of `value`"}
+        except Exception as exc:      # a failure every rank shares (set-up, memory) must not cost the run its line
+            extra["train_side_figure"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        side_done.set()
+
+    if rank == 0:
+        emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
