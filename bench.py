@@ -238,9 +238,9 @@ def main():
     for k in range(args.warmup):
         step_fn(k)
     barrier()
-    # HIP events around the kernels of every 8th step of the timed region -- of EVERY step when the region is short
-    # (the driver's 20-step run used to average 3 launches)
-    every = 8 if args.steps >= 64 else 1
+    # HIP events around the kernels of every 8th step of the timed region (three event records cost a tick ~10 us when
+    # taken every step -- round 3 tried that for short regions and the driver's 20-step run lost 20 % of `value` to it)
+    every = 8
     env.enable_timing(every)
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -249,8 +249,19 @@ def main():
     elapsed = time.perf_counter() - t0
     mv_ms, ray_ms, launches = env.read_timing()
     env.enable_timing(False)
-    kernel_timing_note = ("HIP events around the kernels of every 8th step of the timed region" if every == 8 else
-                          "HIP events around the kernels of every step of the timed region")
+    kernel_timing_note = "HIP events around the kernels of every 8th step of the timed region"
+    if 0 < launches < 16 and args.mode == "env":
+        # a short region (the driver's 20 steps) leaves a handful of samples: add 64 more ticks with the events on EVERY
+        # tick, after the timed region -- `value` does not see them, the kernel averages do
+        env.enable_timing(1)
+        for k in range(64):
+            step_fn(k)
+        torch.cuda.synchronize()
+        mv2, ray2, l2 = env.read_timing()
+        env.enable_timing(False)
+        mv_ms, ray_ms, launches = mv_ms + mv2, ray_ms + ray2, launches + l2
+        kernel_timing_note = ("HIP events around the kernels of every 8th step of the timed region + of each of 64 further "
+                              "ticks right after it (the region alone is too short for an average)")
     if launches == 0:
         # the tick was replayed as a hipGraph (the library's event records are not part of a captured tick): time the
         # two env kernels in a short eager pass AFTER the timed region instead
