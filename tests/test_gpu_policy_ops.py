@@ -77,18 +77,19 @@ def test_mean_value_fused_equals_mean_value(pol):
         m0, v0 = pol.mean_value(x, goal, speed)
     m1, v1 = pol.mean_value_fused(x, goal, speed)
     assert float((m0 - m1).abs().max()) < 1e-5 and float((v0 - v1).abs().max()) < 1e-4 * max(1.0, float(v0.abs().max()))
-    # the cache follows the parameters only when refreshed
+    # the derived copies follow the parameters whoever changes them (stamped with the parameters' versions, rebuilt lazily
+    # and in place): no explicit refresh between the in-place change and the next fused call
+    addr = pol._rc["head_b"].data_ptr()
     with torch.no_grad():
         pol.actor1.bias.add_(0.5)
-    m2, _ = pol.mean_value_fused(x, goal, speed)
-    assert torch.equal(m1, m2)
-    pol.refresh_rollout_cache()
     m3, _ = pol.mean_value_fused(x, goal, speed)
     with torch.no_grad():
         m4, _ = pol.mean_value(x, goal, speed)
         pol.actor1.bias.sub_(0.5)
     assert float((m3 - m4).abs().max()) < 1e-5 and float((m3 - m1).abs().max()) > 1e-3
-    pol.refresh_rollout_cache()
+    assert pol._rc["head_b"].data_ptr() == addr
+    m5, _ = pol.mean_value_fused(x, goal, speed)
+    assert torch.equal(m5, m1)
 
 
 def test_lidar_features_rejects_other_geometries(pol):
