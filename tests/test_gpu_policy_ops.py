@@ -89,7 +89,7 @@ def test_mean_value_fused_equals_mean_value(pol):
     assert float((m3 - m4).abs().max()) < 1e-5 and float((m3 - m1).abs().max()) > 1e-3
     assert pol._rc["head_b"].data_ptr() == addr
     m5, _ = pol.mean_value_fused(x, goal, speed)
-    assert torch.equal(m5, m1)
+    assert float((m5 - m1).abs().max()) < 1e-6          # (b + 0.5) - 0.5 is b up to one rounding
 
 
 def test_lidar_features_rejects_other_geometries(pol):
