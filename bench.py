@@ -355,10 +355,10 @@ def main():
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
                          "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
-                         "note": "HBM is the nominal roof (SURVEY 8d); the ray cast is bound by VALU issue -- the arithmetic of the exact "
-                                 "march and the slab tests, 608 VALU instructions per wave x 16 384 waves = 63 % of the launch's issue "
-                                 "slots, eight waves per SIMD -- not by traffic and not by a workgroup's latency chain (stamped and "
-                                 "varied in round 3: DESIGN.md 5.2)"},
+                         "note": "HBM is the nominal roof (SURVEY 8d); the launch is ~12 us that exist without any march (ramp, tail, two "
+                                 "rounds of request -> prepare -> barrier -> store) + ~13 us of exact march and slab tests bound by VALU "
+                                 "issue at eight waves per SIMD (608 VALU instructions per wave = 63 % of the whole launch's issue "
+                                 "slots); not traffic (stamped and varied in round 3: DESIGN.md 5.2)"},
         }
         if args.mode == "rollout":
             # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2
