@@ -3,14 +3,15 @@
 # DESIGN.md 8 -- Stage-1 from scratch for S1_SECONDS, then Stage-2 worlds mixed with circles of 10-50 robots for
 # S2_SECONDS -- the PPO update running through the HIP forward / backward kernels of the conv front end
 # (--update-path fused, the default; UPDATE_PATH=stock for MIOpen), validation on PERTURBED circles with a held-out seed,
-# then the perturbed circle test of the result on every circle size.   usage: tools/train_recipe.sh <out-dir>
+# then the perturbed circle test of the result on every circle size.   usage: [SEED=k] tools/train_recipe.sh <out-dir>
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 O="${1:-$R/gpurun_out/train}"
 mkdir -p "$O"
 export PYTHONPATH="$R/rl-collision-avoidance_amd"
 S1="${S1_SECONDS:-300}"; S2="${S2_SECONDS:-300}"
 W=/tmp/mrca_train_recipe; rm -rf $W; mkdir -p $W; cd $W
-COMMON="--horizon 16 --batch-size 16384 --kl-target 0.01 --kl-stop 2.0 --lr 1.5e-4 --lr-max 3e-4 --max-grad-norm 1.0 --logstd-min -1.2 --save-every 100000 --log-every 25 --update-path ${UPDATE_PATH:-fused}"
+SEED="${SEED:-0}"
+COMMON="--seed $SEED --horizon 16 --batch-size 16384 --kl-target 0.01 --kl-stop 2.0 --lr 1.5e-4 --lr-max 3e-4 --max-grad-norm 1.0 --logstd-min -1.2 --save-every 100000 --log-every 25 --update-path ${UPDATE_PATH:-fused}"
 timeout $((S1+240)) python -m mrca.train --stage 1 --worlds 128 --robots-per-world 32 --updates 1000000 --max-seconds $S1 --epoch 2 $COMMON 2>&1 \
     | grep -E "^(update|stopping|per-rank|Traceback|.*Error)" > s1.log
 awk 'NR<=3 || NR%6==0' s1.log | cut -c1-150 > "$O/stage1_curve.txt"; tail -1 s1.log | cut -c1-150
