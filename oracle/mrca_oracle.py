@@ -391,7 +391,10 @@ class OracleEnv:
         self.f = f = np.float32 if dtype in (np.float32, "float32") else np.float64
         self.N = N = cfg.W * cfg.R
         self.local = (np.arange(N) % cfg.R).astype(np.int32)
-        self.pose = np.zeros((N, 3), f)
+        # before the first reset the robots stand where the world file puts them (the table's rows ARE the agent lines of
+        # worlds/stage2.world, tools/make_maps.py): stage_world2.py:250-268 keeps a region-sampled start 7 m away from
+        # the robot's CURRENT position, its first one included
+        self.pose = cfg.init_table[self.local].astype(f)
         self.speed = np.zeros((N, 2), f)        # odom velocity = last latched command (stageros.cpp:543-558)
         self.speed_gt = np.zeros((N, 2), f)     # finite-difference GT velocity (stageros.cpp:585-590)
         self.goal = np.zeros((N, 2), f)

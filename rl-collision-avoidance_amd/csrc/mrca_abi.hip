@@ -307,6 +307,15 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_group_id, group.data(), R * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_init_table, init_tab.data(), R * 3 * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_goal_table, goal_tab.data(), R * 2 * 4, hipMemcpyHostToDevice));
+    {
+        // before the first reset the robots stand at their table poses (= the agent lines of the world file): a start
+        // sampled in Stage-2's region keeps 7 m away from the robot's CURRENT position, its first one included
+        // (stage_world2.py:250-268)
+        std::vector<float> pose0((size_t)N * 3);
+        for (size_t n = 0; n < N; ++n)
+            for (int k = 0; k < 3; ++k) pose0[n * 3 + k] = init_tab[(n % (size_t)R) * 3 + k];
+        HIP_TRY_BAIL(hipMemcpy(env->arena + L.field_off[MRCA_F_POSE], pose0.data(), pose0.size() * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_cos, bcos.data(), B * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_beam_sin, bsin.data(), B * 4, hipMemcpyHostToDevice));
     HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_map, cfg->map_bits,

@@ -229,3 +229,20 @@ def test_reset_tables_stage2_and_circle():
     ec.reset()
     assert np.allclose(ec.goal, -ec.pose[:, :2], atol=1e-6)                    # antipodal (model/utils.py:6-38)
     assert np.allclose(np.hypot(ec.pose[:, 0], ec.pose[:, 1]), 25.0, atol=0.01)
+
+
+def test_region_sampled_start_keeps_away_from_the_world_file_pose_in_the_first_episode():
+    """stage_world2.py:250-268: a start sampled in Stage-2's region is re-drawn until it is 7 m from the robot's CURRENT
+    position -- in the first episode that is its world-file pose (worlds/stage2.world; the table's rows 34..43), which
+    lies INSIDE the region.  (Rounds 1-2 started every robot at the origin, 9 m from the region: the first draw always
+    stood.)"""
+    sc = S.stage2(num_worlds=12, seed=3)
+    table = np.asarray(sc.init_table, np.float64)
+    for env in (U.oracle_env(sc, np.float32), U.EmulEnv(sc)):
+        assert np.allclose(np.asarray(env.pose, np.float64).reshape(12, 44, 3)[:, 34:44], table[34:44], atol=1e-6)
+        env.reset()
+        p = np.asarray(env.pose, np.float64).reshape(12, 44, 3)
+        d = np.hypot(p[:, 34:44, 0] - table[34:44, 0], p[:, 34:44, 1] - table[34:44, 1])
+        assert d.min() >= 7.0 - 1e-4
+        # 120 draws, half of the region is within 7 m of such a pose: without the rule some would be closer
+        assert np.allclose(p[:, :34, :2], table[:34, :2], atol=1e-6)

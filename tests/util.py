@@ -97,7 +97,7 @@ class EmulEnv:
         N, R, B, F = sc.num_robots, sc.robots_per_world, sc.beams, sc.frames
         self.N = N
         f32, u8, i32 = np.float32, np.uint8, np.int32
-        self.pose = np.zeros((N, 3), f32)
+        self.pose = np.ascontiguousarray(np.tile(np.asarray(sc.init_table, f32).reshape(-1, 3), (sc.num_worlds, 1)), f32)
         self.speed = np.zeros((N, 2), f32)
         self.speed_gt = np.zeros((N, 2), f32)
         self.goal = np.zeros((N, 2), f32)
