@@ -154,12 +154,15 @@ def test_a_rank_that_stops_commanding(monkeypatch, hold):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ppo_stage2.py")), reason="reference checkout absent")
-def test_unchanged_ppo_stage2_runs(monkeypatch):
+@pytest.mark.parametrize("hold", ["0", "1"])
+def test_unchanged_ppo_stage2_runs(monkeypatch, hold):
     """44 ranks of the UNCHANGED ppo_stage2.py (group-synchronous episodes, liveflag, bcast,
-    get_group_terminal with the py2 `reduce`) on the drop-ins."""
+    get_group_terminal with the py2 `reduce`) on the drop-ins -- with the default idle rule for ranks that stop
+    commanding and with Stage's velocity persistence (MRCA_HOLD_VELOCITY=1)."""
     from mrca import spmd, stage_world
     monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
     monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setenv("MRCA_HOLD_VELOCITY", hold)
     stage_world.set_backend_factory(U.OracleBackend)
     tmp = tempfile.mkdtemp()
     try:
