@@ -30,7 +30,7 @@ def test_c_oracle_stage2_groups():
 
 
 def test_c_oracle_stage2_hold_velocity():
-    _run(S.stage2(num_worlds=1, seed=6, hold_velocity=True), 210, 2, every=7)
+    _run(S.stage2(num_worlds=1, seed=6, hold_velocity=True), 90, 2, every=6)      # first group restart at step 46
 
 
 def test_c_oracle_circle():
