@@ -160,7 +160,31 @@ def main():
                                                              "replaying it as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the rollout/train side figures")
+    ap.add_argument("--graph", action="store_true",
+                    help="env mode: replay the timed ticks as hipGraphs (16 ticks per graph, one per entry of the action pool) "
+                         "instead of launching every kernel from the host")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL, exactly what the
+        # driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` does) -- never a silent 1-GPU run
+        # labelled as one.  A box with fewer GPUs than ranks is an error, not a smaller run.
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < args.gpus and os.environ.get("MRCA_BENCH_SAME_DEVICE") != "1":
+            print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible on this node: refusing to report a "
+                  f"{args.gpus}-GPU figure from fewer devices", file=sys.stderr)
+            raise SystemExit(2)
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +204,10 @@ def main():
     same_device = os.environ.get("MRCA_BENCH_SAME_DEVICE") == "1"
     backend = os.environ.get("MRCA_BENCH_BACKEND", "nccl")
     dev_index = 0 if same_device else local_rank
+    if dev_index >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants cuda:{dev_index} but only {torch.cuda.device_count()} GPU(s) are visible",
+              file=sys.stderr)
+        raise SystemExit(2)
     torch.cuda.set_device(dev_index)
     dist = None
     if world_size > 1:
@@ -217,7 +245,37 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
-    if args.mode == "env":
+    env_graphs = None
+    if args.mode == "env" and args.graph:
+        # The two-launch tick replayed as hipGraphs: ticks k .. k + m - 1 (one per entry of the 16-deep action pool) are
+        # captured once per distinct chunk length and replayed; warm-up and the timed region are cut into chunks of 16
+        # ticks + one remainder, so EXACTLY --steps ticks are timed and the action sequence is the eager run's.
+        side = torch.cuda.Stream(device=dev)
+        env_graphs = {}
+
+        def chunks(first, count):
+            """(start, length) pieces of ticks [first, first + count) that never wrap round the action pool."""
+            k = first
+            while k < first + count:
+                m = min(len(pool) - k % len(pool), first + count - k)
+                yield k, m
+                k += m
+
+        def graph_of(start, count):
+            key = (start % len(pool), count)
+            if key not in env_graphs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for j in range(count):
+                        env.step(pool[(start + j) % len(pool)])
+                env_graphs[key] = g
+            return env_graphs[key]
+
+        def run_ticks(first, count):
+            for k, m in chunks(first, count):
+                graph_of(k, m).replay()
+        step_fn = None
+    elif args.mode == "env":
         step_fn = lambda k: env.step(pool[k % len(pool)])  # noqa: E731
     else:
         from mrca.trainer import make_bench_step
@@ -235,20 +293,37 @@ def main():
         args.warmup = max(hz, (args.warmup + hz - 1) // hz * hz)
         args.steps = max(hz, (args.steps + hz - 1) // hz * hz)
     env.reset()
-    for k in range(args.warmup):
-        step_fn(k)
-    barrier()
-    # HIP events around the kernels of every 8th step of the timed region (three event records cost a tick ~10 us when
-    # taken every step -- round 3 tried that for short regions and the driver's 20-step run lost 20 % of `value` to it)
-    every = 8
-    env.enable_timing(every)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step_fn(k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    mv_ms, ray_ms, launches = env.read_timing()
-    env.enable_timing(False)
+    if env_graphs is not None:
+        for k in range(3):                      # lazy initialisation outside any capture
+            env.step(pool[k])
+        torch.cuda.synchronize()
+        for k, m in list(chunks(0, args.warmup)) + list(chunks(args.warmup, args.steps)):
+            graph_of(k, m)                      # every capture happens here (a capture replays nothing: the env stands still)
+        torch.cuda.synchronize()
+        run_ticks(0, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_ticks(args.warmup, args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        mv_ms, ray_ms, launches = 0.0, 0.0, 0
+    else:
+        for k in range(args.warmup):
+            step_fn(k)
+        barrier()
+        # HIP events around the kernels of every 8th step of the timed region (three event records cost a tick ~10 us when
+        # taken every step -- round 3 tried that for short regions and the driver's 20-step run lost 20 % of `value` to it)
+        every = 8
+        env.enable_timing(every)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step_fn(k)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        mv_ms, ray_ms, launches = env.read_timing()
+        env.enable_timing(False)
+    if step_fn is None:
+        step_fn = lambda k: env.step(pool[k % len(pool)])  # noqa: E731  (the eager passes below)
     kernel_timing_note = "HIP events around the kernels of every 8th step of the timed region"
     if 0 < launches < 16 and args.mode == "env":
         # a short region (the driver's 20 steps) leaves a handful of samples: add 64 more ticks with the events on EVERY
@@ -314,10 +389,26 @@ def main():
     value = total_robots * args.steps / elapsed
 
 
+    import threading
+    emit_lock = threading.RLock()
+    emitted = [False]
+
     def emit():
-        """rank 0: the ONE JSON line (everything it needs is final before the side figure below starts)."""
-        ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
-        mv_avg_s = (mv_ms / launches) * 1e-3 if launches else float("nan")
+        """rank 0: the ONE JSON line (everything it needs is final before the side figure below starts).  Main thread and
+        the side figure's watchdog may both get here: whoever takes the lock first prints, the other returns."""
+        with emit_lock:
+            if emitted[0]:
+                return
+            emitted[0] = True
+            _emit()
+
+    def _emit():
+        # every (event, kernel, event) figure contains one marker's processing time: measured with empty pairs, subtracted
+        ev_us = env.event_pair_overhead(200)
+        ray_raw_us = (ray_ms / launches) * 1e3 if launches else float("nan")
+        mv_raw_us = (mv_ms / launches) * 1e3 if launches else float("nan")
+        ray_avg_s = max(ray_raw_us - ev_us, 0.0) * 1e-6
+        mv_avg_s = max(mv_raw_us - ev_us, 0.0) * 1e-6
         traffic, traffic_note = pmc_traffic(N, args.scenario)
         achieved = RAY_BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
         tick_achieved = BYTES_PER_AGENT_STEP * N / (ray_avg_s + mv_avg_s) / 1e9 if launches else None
@@ -335,7 +426,7 @@ def main():
                        "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
                        "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
                        if args.mode != "env" else None,
-                       "tick_as_hipgraph": (not args.no_graph) if args.mode != "env" else None,
+                       "tick_as_hipgraph": (not args.no_graph) if args.mode != "env" else bool(args.graph),
                        "ppo_update_dtype": args.update_dtype if args.mode == "train" else None,
                        "ppo_update_path": (args.update_path if args.update_dtype == "f32" else "stock")
                        if args.mode == "train" else None},
@@ -343,6 +434,7 @@ def main():
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "bytes_per_agent_step": RAY_BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
+                         "kernel_avg_us_raw_event_pair": ray_raw_us, "event_overhead_us": ev_us,
                          "tick": {"achieved": tick_achieved, "frac": tick_achieved / HBM_PEAK_GBS if tick_achieved else None,
                                   "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
                                   "frac_at_survey_B_env_2140": (tick_achieved * B_ENV_STRICT / BYTES_PER_AGENT_STEP / HBM_PEAK_GBS)
@@ -353,7 +445,8 @@ def main():
                          "move_launch": {"achieved": move_achieved,
                                          "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
-                         "move_kernel_avg_us": (mv_ms / launches) * 1e3 if launches else None,
+                         "move_kernel_avg_us": mv_avg_s * 1e6 if launches else None,
+                         "move_kernel_avg_us_raw_event_pair": mv_raw_us if launches else None,
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
                          "note": "HBM is the nominal roof (SURVEY 8d); the launch is ~12 us that exist without any march (ramp, tail, two "
                                  "rounds of request -> prepare -> barrier -> store) + ~13 us of exact march and slab tests bound by VALU "
@@ -387,17 +480,21 @@ def main():
         # (the first time RCCL runs on this code is the driver's SCALE run: a collective that never answers must not cost
         # the run its line -- after SIDE_FIGURE_TIMEOUT_S rank 0 prints the line without the side figure and every rank
         # leaves; `value` and the per-rank rates above are final before this starts)
-        import threading
         side_done = threading.Event()
+        side_state = ["running"]          # guarded by emit_lock: "running" -> "done" (main thread) | "timed_out" (watchdog)
 
         def give_up():
             if side_done.wait(SIDE_FIGURE_TIMEOUT_S):
                 return
-            extra["train_side_figure"] = {"error": f"no answer within {SIDE_FIGURE_TIMEOUT_S} s (a collective that hangs?)"}
-            if rank == 0:
-                emit()
-            sys.stdout.flush()
-            os._exit(0)
+            with emit_lock:
+                if side_state[0] != "running":       # the side figure finished at the last moment: the main thread prints
+                    return
+                side_state[0] = "timed_out"
+                extra["train_side_figure"] = {"error": f"no answer within {SIDE_FIGURE_TIMEOUT_S} s (a collective that hangs?)"}
+                if rank == 0:
+                    emit()
+                sys.stdout.flush()
+            os._exit(0)      # every rank's own watchdog does the same at the same time: nobody is left in a collective
         threading.Thread(target=give_up, daemon=True).start()
         try:
             from mrca.trainer import HParams, Stage1Trainer
@@ -411,7 +508,7 @@ def main():
             tr.run(n_upd * hp.horizon)
             barrier()
             dt_tr = time.perf_counter() - tt0
-            extra["train_side_figure"] = {
+            side = {
                 "value": N * world_size * n_upd * hp.horizon / dt_tr, "unit": "agent-steps/s",
                 "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
@@ -419,14 +516,24 @@ def main():
                 "note": "env + fp32 policy + GAE + PPO update (horizon 16, one epoch, minibatch 16384 per rank), every "
                         "optimiser step all-reduces the flat gradient bucket; not part of `value`"}
         except Exception as exc:      # a failure every rank shares (set-up, memory) must not cost the run its line
-            extra["train_side_figure"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+            side = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        with emit_lock:               # timeout versus done is decided under the lock the line is printed under
+            if side_state[0] == "running":
+                side_state[0] = "done"
+                extra["train_side_figure"] = side
         side_done.set()
 
     if rank == 0:
         emit()
+        sys.stdout.flush()
     if dist is not None:
+        # tidy shutdown, bounded: a peer that left through its watchdog must not hold this rank in the last barrier
+        t_exit = threading.Timer(60.0, lambda: os._exit(0))
+        t_exit.daemon = True
+        t_exit.start()
         dist.barrier()
         dist.destroy_process_group()
+        t_exit.cancel()
 
 
 if __name__ == "__main__":

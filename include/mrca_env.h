@@ -191,6 +191,9 @@ const char* mrca_last_error(void);
  * recorded launches in milliseconds and clears the ring. */
 int mrca_enable_timing(mrca_env* env, int32_t on); /* on = n > 0: time every n-th step; 0: off */
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches);
+/* Mean microseconds an event pair on `stream` reads with nothing between its two records (`samples` pairs, each
+ * synchronised): the marker time every (event, kernel, event) figure of mrca_read_timing contains once per kernel. */
+int mrca_event_pair_overhead(void* stream, int32_t samples, float* us_out);
 /* Rollout-path front end of the lidar actor-critic (model/net.py:19-25,37-49,57-69: Conv1d(3,32,k5,s2,p1) -> ReLU ->
  * Conv1d(32,32,k3,s2,p1) -> ReLU for the actor and the critic tower), fused into one kernel: fp32 in, fp32 MFMA
  * accumulate, the 32 x 255 intermediate never leaves the CU.

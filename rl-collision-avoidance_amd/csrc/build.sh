@@ -30,6 +30,10 @@ for src in mrca_kernels mrca_abi mrca_policy mrca_policy_bwd mrca_policy_tail; d
     "${HIPCC}" "${FLAGS[@]}" "${per[@]}" -c "${here}/${src}.hip" -o "${obj}/${src}.o" "$@" &
     pids+=($!)
 done
-for pid in "${pids[@]}"; do wait "${pid}"; done      # set -e: the first failed compile ends the build
+# wait for EVERY compile before acting on a failure: leaving at the first one would let the EXIT trap remove the object
+# directory under the compiles still running
+failed=0
+for pid in "${pids[@]}"; do wait "${pid}" || failed=1; done
+if (( failed )); then echo "build.sh: a compile failed" >&2; exit 1; fi
 "${HIPCC}" --offload-arch=gfx950 -fPIC -shared "${obj}"/*.o -o "${out}"
 echo "built ${out}"

@@ -561,6 +561,30 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
     return MRCA_OK;
 }
 
+// What an event pair reads with NOTHING between its two records: the processing time of the second marker, which every
+// (event, kernel, event) measurement of mrca_read_timing contains once per kernel.  bench.py reports its kernel
+// averages net of this figure so that they add up to no more than the tick they are part of.
+int mrca_event_pair_overhead(void* stream, int32_t samples, float* us_out) {
+    if (!us_out || samples < 1 || samples > 4096) return fail(MRCA_ERR_INVALID, "mrca_event_pair_overhead: bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    double sum = 0.0;
+    for (int i = 0; i < samples; ++i) {
+        HIP_TRY(hipEventRecord(a, s));
+        HIP_TRY(hipEventRecord(b, s));
+        HIP_TRY(hipEventSynchronize(b));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        sum += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *us_out = (float)(sum / samples * 1e3);
+    return MRCA_OK;
+}
+
 #if defined(MRCA_PROFILING)
 // Profiling build only (libmrca_env_prof.so): ablation switches (results are WRONG while bits 0-5 are set) and
 // launch-shape knobs (results unchanged): bits 8-10 = k > 0:

@@ -21,6 +21,7 @@ FIELDS = [  # order = enum mrca_field
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
            "mrca_step", "mrca_step_slice", "mrca_materialize_obs", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
+           "mrca_event_pair_overhead",
            "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
            "mrca_policy_tail"]
 
@@ -81,6 +82,7 @@ def load(path=None):
         lib.mrca_debug_move_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.mrca_debug_ray_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.mrca_debug_fwd_stamps.argtypes = [C.POINTER(C.c_double)]
+    lib.mrca_event_pair_overhead.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
     lib.mrca_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.mrca_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{path} ABI {lib.mrca_abi_version()} != binding ABI {ABI_VERSION}")

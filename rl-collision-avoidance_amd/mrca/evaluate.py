@@ -109,6 +109,8 @@ def circle_test(env, policy_fn, max_ticks=1200, perturb=None, seed=0):
         ticks_to_goal += pending.float()
         if k % 25 == 24 and bool((env.first_result != 0).all()):    # one host round trip every 25 ticks
             break
+    if hasattr(env, "check"):
+        env.check()          # mrca_check: raises if a device-side pass flagged an untrusted state (worlds with > 64 robots)
     fr = env.first_result
     reach = fr == 1
     n_reach = int(reach.sum())

@@ -55,6 +55,11 @@ class ConcatEnv:
         self._gather()
         return self
 
+    def check(self):
+        """mrca_check of every part (raises on a device-side failure flagged since the last check)."""
+        for e in self.envs:
+            e.check()
+
     def enable_timing(self, on=True):
         for e in self.envs:
             e.enable_timing(on)

@@ -107,9 +107,11 @@ class CNNPolicy(nn.Module):
                 "fc2_b": st(self.act_fc2.bias, self.crt_fc2.bias).unsqueeze(1),      # [2, 1, 128]
                 "head_w": torch.cat([self.actor1.weight, self.actor2.weight]).detach().t().contiguous(),   # [128, 2]
                 "head_b": torch.cat([self.actor1.bias, self.actor2.bias]).detach(),
-                "critic_w": self.critic.weight.detach().reshape(-1).contiguous(),     # [128]
-                "critic_b": self.critic.bias.detach().reshape(1).contiguous(),
-                "logstd": self.logstd.detach().reshape(-1).contiguous(),
+                # .clone(): reshape / contiguous of an already contiguous parameter is a VIEW of it -- the in-place
+                # refresh below would copy the parameter onto itself and bump its version counter
+                "critic_w": self.critic.weight.detach().reshape(-1).clone(),          # [128]
+                "critic_b": self.critic.bias.detach().reshape(1).clone(),
+                "logstd": self.logstd.detach().reshape(-1).clone(),
             }
             old = getattr(self, "_rc", None)
             if old is not None and all(old[k].shape == v.shape and old[k].device == v.device for k, v in new.items()):
@@ -121,8 +123,11 @@ class CNNPolicy(nn.Module):
         return self._rc
 
     def _param_stamp(self):
-        """What the derived copies were made from: every parameter's in-place version counter (optimiser steps,
-        ``copy_``, broadcasts bump it), storage address and device (``.to()`` / ``.cuda()`` swap the storage)."""
+        """What the derived copies were made from: every parameter's in-place version counter (optimiser steps and
+        ``copy_`` / broadcasts INTO the parameter under no_grad bump it; writes through ``p.data`` do NOT -- ``p.data`` is
+        a detached alias with a counter of its own -- so whoever writes through ``.data`` calls ``refresh_rollout_cache``
+        itself, as trainer.broadcast_parameters does), storage address and device (``.to()`` / ``.cuda()`` swap the
+        storage)."""
         return tuple((p._version, p.data_ptr(), p.device) for p in self.parameters())
 
     def _rollout_cache(self):

@@ -9,7 +9,8 @@ stageros`` (README.md:30-34).  The drop-in modules under ``mrca/dropin`` shadow 
 hand-offs between threads, ROS topics become reads of the device arena.
 
 Tick rule: the simulator advances when EVERY rank is blocked -- in ``rospy.sleep`` (its action is
-latched) or inside an MPI collective -- i.e. once per loop iteration of the scripts.
+latched) or inside an MPI collective -- i.e. once per loop iteration of the scripts.  The ranks run under a deterministic
+cooperative schedule (one at a time, lowest ready rank next: ``Runtime``), so a run is reproducible.
 """
 import argparse
 import os
@@ -20,11 +21,24 @@ import threading
 _tls = threading.local()
 
 
+READY, RUNNING, BLOCKED, DONE = range(4)
+
+
 class Runtime:
+    """Rank threads under a DETERMINISTIC cooperative schedule: exactly one rank runs at a time (it holds the baton); when
+    it blocks -- in ``rospy.sleep`` with a latched command, or inside a collective -- or leaves its script, the baton
+    goes to the lowest-ranked rank that is ready to run.  Every interleaving of the ranks' code between two blocking
+    points is therefore the same in every run: a rank's ``reset_pose`` teleport (which re-casts ITS lidar against the
+    poses the others have at that moment) always sees the same world.  (mpiexec + Stage are racy there; rank threads
+    left to the OS scheduler were too, and two runs of ppo_stage1.py differed from their second tick on.  With the GIL
+    nothing ran in parallel anyway.)"""
+
     def __init__(self, size, max_ticks=None):
         self.size = size
         self.max_ticks = max_ticks
-        self.cv = threading.Condition()
+        lock = threading.RLock()
+        self.cv = threading.Condition(lock)                                     # the runtime's lock
+        self.rank_cv = [threading.Condition(lock) for _ in range(size)]         # one wake-up channel per rank: a baton
         self.blocked = 0            # ranks parked in sleep or in a collective (released ranks are
         self.sleepers = 0           # un-counted by the RELEASER, not when they wake up: a woken-late
         self.coll_waiters = 0       # rank must never make the world look quiescent)
@@ -38,10 +52,36 @@ class Runtime:
         self.coll_result = None
         self.alive = size
         self.errors = []
-        # ranks start one after another: rank r+1 begins when rank r first blocks (or exits), so the
-        # scripts' racy start-up code (os.makedirs, logging handlers) runs serially like it does when
-        # mpiexec staggers process start-up
-        self.first_block = [threading.Event() for _ in range(size)]
+        # the schedule: ranks start one after another too (rank r + 1 begins when rank r first blocks or exits), so the
+        # scripts' racy start-up code (os.makedirs, logging handlers) runs serially like it does when mpiexec staggers
+        # process start-up
+        self.state = [READY] * size
+        self.baton = 0              # the rank that may run (None: everybody is blocked)
+        self.sleeping = set()
+        self.colling = set()
+
+    # ---- the baton (call with self.cv held)
+    def _pass_baton(self):
+        """The caller stopped running: the lowest-ranked READY rank goes next (and only that rank is woken: waking all
+        of 50 threads per hand-over made a tick of circle_test.py six times slower)."""
+        self.baton = next((r for r in range(self.size) if self.state[r] == READY), None)
+        if self.baton is not None:
+            self.rank_cv[self.baton].notify()
+
+    def _take_baton(self, r, released=lambda: True):
+        """Returns once rank r has been released from whatever it blocked on AND holds the baton (or at shutdown)."""
+        while not self.shutdown and not (released() and self.baton == r):
+            self.rank_cv[r].wait(0.5)
+        self.state[r] = RUNNING      # (after a shutdown everybody just leaves: no order to keep)
+
+    def _shut_down(self):
+        self.shutdown = True
+        for c in self.rank_cv:
+            c.notify()
+
+    def begin(self, r):
+        with self.cv:
+            self._take_baton(r)
 
     # ---- quiescence / ticking (call with self.cv held)
     def _maybe_tick(self):
@@ -50,13 +90,15 @@ class Runtime:
             self.sleep_gen += 1
             self.blocked -= self.sleepers
             self.sleepers = 0
+            for q in self.sleeping:
+                self.state[q] = READY
+            self.sleeping.clear()
             if self.max_ticks is not None and self.world.ticks >= self.max_ticks:
-                self.shutdown = True
-            self.cv.notify_all()
+                self._shut_down()
 
     def sleep(self, needs_tick):
         """rospy.sleep: with a latched command, wait for the tick that consumes it."""
-        self.first_block[rank()].set()
+        r = rank()
         with self.cv:
             if self.shutdown:
                 raise KeyboardInterrupt
@@ -65,17 +107,19 @@ class Runtime:
             gen = self.sleep_gen
             self.blocked += 1
             self.sleepers += 1
+            self.state[r] = BLOCKED
+            self.sleeping.add(r)
             self._maybe_tick()
-            while self.sleep_gen == gen and not self.shutdown:
-                self.cv.wait(0.5)
+            self._pass_baton()
+            self._take_baton(r, lambda: self.sleep_gen != gen)
             if self.sleep_gen == gen:          # shut down before the tick: un-count ourselves
                 self.blocked -= 1
                 self.sleepers -= 1
+                self.sleeping.discard(r)
                 raise KeyboardInterrupt
 
     def collective(self, rank, value, combine):
         """All-rank rendezvous; ``combine(list_of_values)`` runs once, every rank gets its result."""
-        self.first_block[rank].set()
         with self.cv:
             if self.shutdown:
                 raise KeyboardInterrupt
@@ -84,16 +128,19 @@ class Runtime:
             self.coll_count += 1
             self.coll_combine = combine
             if self.coll_count == self.alive:
-                self._complete_collective()
+                self._complete_collective()      # the last arriver keeps the baton and carries on
                 return self.coll_result
             self.blocked += 1
             self.coll_waiters += 1
+            self.state[rank] = BLOCKED
+            self.colling.add(rank)
             self._maybe_tick()
-            while self.coll_gen == gen and not self.shutdown:
-                self.cv.wait(0.5)
+            self._pass_baton()
+            self._take_baton(rank, lambda: self.coll_gen != gen)
             if self.coll_gen == gen:
                 self.blocked -= 1
                 self.coll_waiters -= 1
+                self.colling.discard(rank)
                 raise KeyboardInterrupt
             return self.coll_result
 
@@ -104,21 +151,23 @@ class Runtime:
         self.coll_gen += 1
         self.blocked -= self.coll_waiters
         self.coll_waiters = 0
-        self.cv.notify_all()
+        for q in self.colling:
+            self.state[q] = READY
+        self.colling.clear()
 
     def rank_exit(self, err=None):
         """A rank left its script: the remaining ranks' rendezvous / tick conditions shrink."""
-        self.first_block[rank()].set()
         with self.cv:
             self.alive -= 1
+            self.state[rank()] = DONE
             if err is not None:
                 self.errors.append(err)
-                self.shutdown = True
+                self._shut_down()
             elif self.alive > 0:
                 if self.coll_count and self.coll_count == self.alive:
                     self._complete_collective()
                 self._maybe_tick()
-            self.cv.notify_all()
+            self._pass_baton()
 
 
 _runtime = None
@@ -190,8 +239,7 @@ def run_script(path, nprocs, max_ticks=None, extra_argv=(), chdir=None):
     def body(r):
         _tls.rank = r
         err = None
-        if r > 0:
-            rt.first_block[r - 1].wait()
+        rt.begin(r)
         try:
             runpy.run_path(path, run_name="__main__")
         except SystemExit:

@@ -48,9 +48,15 @@ class HParams:
 
 
 def broadcast_parameters(module, dist):
+    """Rank 0's parameters to every rank.  The broadcast writes INTO the parameter under no_grad (not through
+    ``p.data``, whose writes do not bump the parameter's version counter), and the tower-major copies the fused rollout
+    path reads are rebuilt afterwards: a broadcast cannot leave a rank acting on its own initial weights."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        for p in module.parameters():
-            dist.broadcast(p.data, src=0)
+        with torch.no_grad():
+            for p in module.parameters():
+                dist.broadcast(p, src=0)
+        if hasattr(module, "refresh_rollout_cache") and getattr(module, "_rc", None) is not None:
+            module.refresh_rollout_cache()
 
 
 class Stage1Trainer:
@@ -177,6 +183,10 @@ class Stage1Trainer:
             ppo.ppo_update_stage1(**kw)
         if hp.rollout_fused:
             self.policy.refresh_rollout_cache()      # the rollout path reads tower-major copies of the parameters
+        # the env's sticky device status (include/mrca_env.h: mrca_check -- "once per PPO update"): the update has just
+        # synchronised with the host anyway, so the round trip is free; raises instead of training on an untrusted state
+        if hasattr(env, "check"):
+            env.check()
         self.global_update += 1
 
     @property

@@ -162,6 +162,12 @@ class VecStageWorld:
                                "profiling build (csrc/build.sh --profiling, MRCA_ENV_LIB=...)")
         _lib.check(self.lib.mrca_set_debug_flags(self._h, int(flags)), "mrca_set_debug_flags")
 
+    def event_pair_overhead(self, samples=200):
+        """us an empty HIP-event pair reads on the current stream: contained once per kernel in ``read_timing``'s figures."""
+        us = C.c_float()
+        _lib.check(self.lib.mrca_event_pair_overhead(self._stream(), int(samples), C.byref(us)), "mrca_event_pair_overhead")
+        return us.value
+
     def read_timing(self):
         mv, ry, n = C.c_float(), C.c_float(), C.c_int32()
         _lib.check(self.lib.mrca_read_timing(self._h, C.byref(mv), C.byref(ry), C.byref(n)), "mrca_read_timing")

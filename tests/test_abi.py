@@ -3,6 +3,7 @@ every symbol include/mrca_env.h declares, and validates configs without touching
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -107,3 +108,17 @@ def test_committed_pmc_traffic_matches_the_kernel_sources():
     assert bench.code_only(src + "\n// a comment\n/* another\n one */\n") == bench.code_only(src)
     assert bench.code_only(src + "\nstatic const int kNotThere = 1;\n") != bench.code_only(src)
     assert "//" not in bench.code_only(src) and len(bench.code_only(src)) > 1000
+
+
+def test_bench_refuses_a_multi_gpu_run_it_cannot_start():
+    """`python bench.py --gpus N` without torchrun starts its own N ranks -- and where fewer than N GPUs are visible (here:
+    none) it must say so and exit non-zero instead of printing a line labelled with fewer GPUs."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MRCA_BENCH_SAME_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(U.ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    assert out.returncode == 2 and "refusing" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

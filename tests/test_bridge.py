@@ -13,14 +13,21 @@ import pytest
 import util as U
 from util import S
 
-REF = os.environ.get("MRCA_REFERENCE", "/root/reference")
+REF = U.reference_dir() or "/nonexistent"
+
+
+_BACKEND = "oracle"      # "hip": the product backend (the -m gpu leg below re-runs this module's tests on it)
 
 
 def make(R=24, seed=4):
     from mrca import bridge
     sc = S.stage1(num_worlds=1, robots_per_world=R, seed=seed)
     sc.auto_reset = S.AUTO_NONE
-    backend = U.OracleBackend(sc, np.float32)
+    if _BACKEND == "hip":
+        from mrca import stage_world
+        backend = stage_world.HipBackend(sc)
+    else:
+        backend = U.OracleBackend(sc, np.float32)
     backend.reset(np.ones(R, np.uint8), None, None)
     init = S.load_tables()["stage1"]["world_agents"][:R]
     return bridge, bridge.StageBridge(backend, R, init), backend
@@ -151,3 +158,26 @@ def _as_ros_odometry(m):
     o.pose, o.twist = N(), N()
     o.pose.pose, o.twist.twist = m.pose, m.twist
     return o
+
+
+# ------------------------------------------------------------------------------------------------ the product backend
+_ON_ANY_BACKEND = [n for n, f in sorted(globals().items()) if n.startswith("test_") and callable(f)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", _ON_ANY_BACKEND)
+def test_on_the_hip_backend(name, monkeypatch):
+    """SURVEY 8(f4) on the product: every test of this module once more with the bridge fed from HipBackend (the HIP env
+    through the C ABI) instead of the oracle -- the published fields, the inbound topics and the service, Stage's persistent
+    velocity with the global watchdog, and the reference's own subscriber callbacks digesting the messages."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as g
+    g.build()
+    fn = globals()[name]
+    for mark in getattr(fn, "pytestmark", []):
+        if mark.name == "skipif" and mark.args and mark.args[0]:
+            pytest.skip(mark.kwargs.get("reason", "skipif"))
+    monkeypatch.setitem(globals(), "_BACKEND", "hip")
+    fn()

@@ -17,7 +17,7 @@ import torch
 
 import util as U
 
-REF = os.environ.get("MRCA_REFERENCE", "/root/reference")     # wherever a checkout of the reference exists
+REF = U.reference_dir() or "/nonexistent"     # a checkout ($MRCA_REFERENCE) or the staged archive (tools/stage_reference.sh)
 MINI = os.path.join(U.ROOT, "tests", "dropin_script_mini.py")
 
 
@@ -69,25 +69,166 @@ def test_unchanged_ppo_stage1_runs_through_an_update(monkeypatch):
     assert out_logs
 
 
+def _reference_logs(tmp):
+    """The three log streams of a run (ppo_stage1.py:140-161, model/ppo.py:10-19) in an order-free form: the rank threads
+    of one tick write their episode lines in whatever order they are scheduled, so output.log is split per env (each
+    env's own sequence is deterministic) and cal.log -- bare episode returns -- is sorted; ppo.log has one writer."""
+    import re
+
+    def lines(name):
+        hits = glob.glob(os.path.join(tmp, "log", "*", name))
+        return [ln.rstrip("\n") for ln in open(hits[0])] if hits else []
+    per_env = {}
+    other = []
+    for ln in lines("output.log"):
+        msg = ln.split(" - INFO - ", 1)[-1]            # drop "%(asctime)s - %(levelname)s - "
+        m = re.match(r"Env (\d+),", msg)
+        (per_env.setdefault(int(m.group(1)), []) if m else other).append(msg)
+    return {"output_per_env": per_env, "output_other": other, "cal": sorted(lines("cal.log")), "ppo": lines("ppo.log")}
+
+
+def _detach_reference_loggers():
+    """The scripts attach FileHandlers to module-level loggers; a second run in this process must not write into the
+    first run's files."""
+    import logging
+    for name in ("mylogger", "loggercal", "loggerppo"):
+        lg = logging.getLogger(name)
+        for h in list(lg.handlers):
+            h.close()
+            lg.removeHandler(h)
+
+
+class _Recording:
+    """A backend of the SharedWorld protocol that forwards to the real one and keeps (a) a running SHA-256 over what the
+    scripts can see of EVERY tick and (b) a host copy of the world right after tick ``last_tick``.  (The state after the
+    runtime's shutdown is not comparable: ranks whose episode ended at the last tick may or may not get their
+    ``reset_pose`` teleport in before they notice the shutdown.)"""
+    FIELDS = ("pose", "goal", "reward", "done", "result", "first_result", "crashed", "scan", "obs", "speed", "speed_gt",
+              "local_goal")
+
+    def __init__(self, inner, last_tick):
+        import hashlib
+        self.inner, self.last_tick, self.ticks = inner, last_tick, 0
+        self.sha = hashlib.sha256()
+        self.snapshot = None
+
+    def reset(self, mask, poses, goals):
+        self.inner.reset(mask, poses, goals)
+
+    def step(self, actions):
+        self.inner.step(actions)
+        self.ticks += 1
+        if self.ticks <= self.last_tick:
+            state = {k: np.array(self.inner.field(k)) for k in self.FIELDS}
+            self.sha.update(np.ascontiguousarray(actions, np.float32).tobytes())
+            for k in self.FIELDS:
+                self.sha.update(np.ascontiguousarray(state[k]).tobytes())
+            if self.ticks == self.last_tick:
+                self.snapshot = state
+
+    def field(self, name):
+        return self.inner.field(name)
+
+
+def _run_unchanged(script, nprocs, max_ticks, factory, seed, checkpoint=None, hold="0"):
+    """One run of an UNCHANGED reference script as rank threads with its own model/*.py on cuda (real ``.cuda()`` calls).
+    -> (logs, host state of the batched world after the last tick, digest of every tick)."""
+    import shutil
+    from mrca import spmd, stage_world
+    made = []
+
+    def recording(sc):
+        made.append(_Recording(factory(sc), max_ticks))
+        return made[-1]
+    _detach_reference_loggers()
+    os.environ["MRCA_HOLD_VELOCITY"] = hold
+    stage_world.set_seed(seed)
+    stage_world.set_backend_factory(recording)
+    torch.manual_seed(seed)                # policy initialisation, action noise (cuda), minibatch sampler (cpu)
+    np.random.seed(seed)
+    torch.backends.cudnn.benchmark = False        # MIOpen: no per-run algorithm search, deterministic algorithms only --
+    torch.backends.cudnn.deterministic = True     # two runs of the reference's OWN model must agree bit for bit
+    tmp = tempfile.mkdtemp()
+    if checkpoint:
+        os.makedirs(os.path.join(tmp, "policy"))
+        shutil.copy(checkpoint, os.path.join(tmp, "policy", "stage2.pth"))
+    try:
+        errs = spmd.run_script(os.path.join(REF, script), nprocs, max_ticks=max_ticks, chdir=tmp)
+    finally:
+        stage_world.set_backend_factory(None)
+        stage_world.set_seed(0)
+        os.environ.pop("MRCA_HOLD_VELOCITY", None)
+        _detach_reference_loggers()
+    assert not errs, errs
+    assert made[-1].snapshot is not None, f"the run stopped after {made[-1].ticks} of {max_ticks} ticks"
+    return _reference_logs(tmp), made[-1].snapshot, made[-1].sha.hexdigest()
+
+
+_UNCHANGED = {   # script -> (rank threads, ticks: one full PPO update + a few ticks acting on the UPDATED policy)
+    "ppo_stage1.py": (24, 134),       # HORIZON 128 (ppo_stage1.py:25)
+    "ppo_stage2.py": (44, 134),       # HORIZON 128 (ppo_stage2.py:25), group-synchronous episodes, filtered update
+    "circle_test.py": (50, 160),
+}
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ppo_stage1.py")),
-                    reason="reference checkout absent (point MRCA_REFERENCE at one to run the unchanged script on the GPU)")
-def test_unchanged_ppo_stage1_on_the_hip_backend():
-    """The UNCHANGED ppo_stage1.py (24 rank threads, its own model/ppo.py and model/net.py with real .cuda() calls) on the
-    product backend: HipBackend <-> reference script, through one PPO update."""
+                    reason="no reference checkout and no staged archive (tools/stage_reference.sh)")
+@pytest.mark.parametrize("script", sorted(_UNCHANGED))
+def test_unchanged_script_on_the_hip_backend_equals_the_oracle_backend(script):
+    """The literal north-star sentence on the MI355X: the UNCHANGED ppo_stage1.py / ppo_stage2.py / circle_test.py (their own
+    model/ppo.py and model/net.py, real .cuda() policy) run twice with the same seeds -- the batched world behind the
+    StageWorld surface once the C oracle, once HipBackend (libmrca_env.so through the C ABI).  The env is bit-exact, so
+    everything the scripts see is identical: output.log (per env), cal.log and ppo.log must be EQUAL, and so must the
+    final state of the world, field by field, bit by bit."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import __graft_entry__ as g
     g.build()
-    from mrca import spmd, stage_world
-    stage_world.set_backend_factory(None)          # the product default: mrca.stage_world.HipBackend
-    tmp = tempfile.mkdtemp()
-    errs = spmd.run_script(os.path.join(REF, "ppo_stage1.py"), 24, max_ticks=132, chdir=tmp)
-    assert not errs, errs
-    ppo_logs = glob.glob(os.path.join(tmp, "log", "*", "ppo.log"))
-    lines = [ln for ln in open(ppo_logs[0]).read().splitlines() if ln.strip()]
-    assert len(lines) >= 6
-    assert np.isfinite(np.array([[float(x) for x in ln.split(",")] for ln in lines[:6]])).all()
+    from mrca import stage_world
+    nprocs, ticks = _UNCHANGED[script]
+    ckpt = os.path.join(U.ROOT, "rl-collision-avoidance_amd", "mrca", "data", "policy_r02_stage2_circles.pth") \
+        if script == "circle_test.py" else None
+    ref_logs, ref_state, ref_sha = _run_unchanged(script, nprocs, ticks, U.COracleBackend, 11, ckpt)
+    got_logs, got_state, got_sha = _run_unchanged(script, nprocs, ticks, stage_world.HipBackend, 11, ckpt)
+    problems = _compare_runs(ref_logs, ref_state, ref_sha, got_logs, got_state, got_sha)
+    if script != "circle_test.py":         # (circle_test.py writes no log: its evidence is the world's state and digest)
+        assert ref_logs["ppo"], "the run did not reach a PPO update"
+        assert sum(len(v) for v in ref_logs["output_per_env"].values()) >= nprocs // 2, "too few episodes ended"
+    assert not problems, f"{script}: " + "; ".join(problems)
+
+
+def _compare_runs(ref_logs, ref_state, ref_sha, got_logs, got_state, got_sha):
+    """Everything that differs between two runs, in one report.  Episode lines: an episode that ends AT the last tick is
+    logged by its rank thread only if the thread gets there before it notices the shutdown, so per env the shorter
+    sequence must be a PREFIX of the longer one and at most one line shorter; cal.log likewise (a multiset)."""
+    from collections import Counter
+    problems = []
+    for k in ref_state:
+        a, b = ref_state[k], got_state[k]
+        same = (a.view(np.uint32) == b.view(np.uint32)) if a.dtype == np.float32 else (a == b)
+        if not same.all():
+            problems.append(f"{k} after the last tick differs at {int((~same).sum())} of {same.size} entries")
+    if ref_sha != got_sha:
+        problems.append("the digest over actions + state of every tick differs")
+    pa, pb = ref_logs["output_per_env"], got_logs["output_per_env"]
+    for e in sorted(set(pa) | set(pb)):
+        x, y = pa.get(e, []), pb.get(e, [])
+        n = min(len(x), len(y))
+        if x[:n] != y[:n] or abs(len(x) - len(y)) > 1:
+            problems.append(f"output.log of env {e}: {x[max(0, n - 2):n + 1]} vs {y[max(0, n - 2):n + 1]}")
+            break
+    if ref_logs["output_other"] != got_logs["output_other"]:
+        problems.append(f"output.log banner lines: {ref_logs['output_other']} vs {got_logs['output_other']}")
+    ca, cb = Counter(ref_logs["cal"]), Counter(got_logs["cal"])
+    if sum(((ca - cb) + (cb - ca)).values()) > len(pa) or not (ca - cb == Counter() or cb - ca == Counter()):
+        problems.append(f"cal.log: {sum((ca - cb).values())} / {sum((cb - ca).values())} unmatched episode returns")
+    if ref_logs["ppo"] != got_logs["ppo"]:
+        a, b = ref_logs["ppo"], got_logs["ppo"]
+        first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+        problems.append(f"ppo.log: {len(a)} vs {len(b)} lines, first difference at line {first}: {a[first:first + 1]} vs "
+                        f"{b[first:first + 1]}")
+    return problems
 
 
 @pytest.mark.gpu

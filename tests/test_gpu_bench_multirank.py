@@ -45,6 +45,50 @@ def test_bench_two_ranks_same_gpu():
     assert tr["collective"]["optimizer_steps"] >= 2 and tr["value"] > 0
 
 
+def test_plain_python_bench_gpus_2_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun must start two ranks itself (never a 1-GPU figure labelled as one): with
+    the same-device / gloo hook on this 1-GPU box the line must say n_gpus 2 and the collective must have seen 2 ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MRCA_BENCH_SAME_DEVICE="1", MRCA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(U.ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+                          "--worlds", "16", "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and len(j["per_rank_agent_steps_per_s"]) == 2
+
+
+def test_plain_python_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus 8` on a box with fewer GPUs: one clear line on stderr, a non-zero exit code, NO JSON line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    want = torch.cuda.device_count() + 7
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MRCA_BENCH_SAME_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(U.ROOT, "bench.py"), "--gpus", str(want), "--steps", "5",
+                          "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "refusing" in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_env_mode_as_hipgraph_counts_exactly_the_steps_asked_for():
+    """--graph: the two-launch tick replayed as hipGraphs (16 ticks per graph + a remainder graph); the line must account
+    for exactly --steps ticks and say so."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = subprocess.run([sys.executable, os.path.join(U.ROOT, "bench.py"), "--steps", "37", "--warmup", "21", "--worlds", "8",
+                          "--no-cpu-baseline", "--no-extra", "--graph"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["steps"] == 37 and j["config"]["tick_as_hipgraph"] is True
+    assert abs(j["value"] - 8 * 32 * 37 / (j["ms_per_step"] * 1e-3 * 37)) / j["value"] < 1e-6
+    assert j["roofline"]["launches_timed"] == 64          # the kernel averages come from the eager pass after the region
+
+
 def test_bench_multi_gpu_default_workload_is_the_single_gpu_one():
     """Weak scaling of ONE per-GPU workload: N > 1 defaults to configs[1] per GPU (128 Stage-1 rinks x 32 robots), like
     N = 1, so that value(N) / (N x value(1)) is a scaling efficiency; configs[3]'s per-GPU workload (187 Stage-2 worlds x
@@ -91,6 +135,9 @@ def test_bench_single_rank_json_contract():
         assert k in j, k
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the kernel averages are net of the event pair's own time (and say what it was)
+    assert 0.0 < r["event_overhead_us"] < 20.0
+    assert abs(r["kernel_avg_us_raw_event_pair"] - r["kernel_avg_us"] - r["event_overhead_us"]) < 1e-3
     assert j["vs_baseline"] is None and j["data"] == "synthetic" and "workload" in j["config"]
 
 

@@ -41,6 +41,7 @@ def _exact(hip, sc, steps, seed, poses=None, check_every=4, actions=None):
         if k % check_every == check_every - 1 or k == steps - 1:
             torch.cuda.synchronize()
             U.assert_state_equal(U.HostView(env), ora, what=f"{sc.name} step {k}")
+    env.check()          # mrca_check: the ordered collision pass never gave up on a robot
     env.close()
     return ora
 
@@ -63,6 +64,43 @@ def test_single_circle_500_robots_bit_exact(hip):
         return np.stack([np.full(sc.num_robots, 1.0), np.clip(2.0 * bearing, -1, 1)], 1).astype(np.float32)
 
     _exact(hip, sc, 40, 0, actions=act, check_every=8)
+
+
+def _go_to_goal(sc):
+    def act(k, ora):
+        lg = ora.local_goal
+        bearing = np.arctan2(lg[:, 1], lg[:, 0])
+        return np.stack([np.full(sc.num_robots, 1.0), np.clip(2.0 * bearing, -1, 1)], 1).astype(np.float32)
+    return act
+
+
+def _lattice_jam(n, seed):
+    """n robots packed on a jittered 0.8 m lattice with random headings: the centre of the big circle when everybody
+    arrives."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(n)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)[:n]
+    xy = (ij - side / 2) * 0.8 + rng.uniform(-0.12, 0.12, (n, 2))
+    return np.concatenate([xy, rng.uniform(-np.pi, np.pi, (n, 1))], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [5000, 50000])
+def test_single_circle_at_the_quoted_sizes_bit_exact(hip, n):
+    """The sizes the throughput figures are quoted on (one circle of 5 000 and of 50 000 robots, radius
+    proportional to R): the 131 072-bucket hashes, the multi-block scan of the lidar hash, neighbour chunks crossing many
+    buckets.  12 ticks of the go-to-goal controller, EVERY field of EVERY robot bit-exact against the C oracle (its
+    culled passes finish a 50 000-robot tick in well under a second per host thread team), status word clear."""
+    sc = S.circle_big(n)
+    _exact(hip, sc, 12, 0, actions=_go_to_goal(sc), check_every=4)
+
+
+def test_jam_of_50000_robots_bit_exact(hip):
+    """50 000 robots on the 0.8 m lattice (179 m across), random commands: every robot in a dependency chain of the
+    ordered pass, > 150 lidar neighbours each, the collision hash at its working size.  8 ticks, bit-exact."""
+    n = 50000
+    sc = S.circle_big(n)
+    o = _exact(hip, sc, 8, 5, poses=_lattice_jam(n, 13), check_every=4)
+    assert o.crashed.sum() > 2000
 
 
 def test_jam_of_500_robots_bit_exact(hip):

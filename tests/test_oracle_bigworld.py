@@ -75,6 +75,10 @@ class _CpuWorld:
     def reset(self):
         self.env.reset()
 
+    def policy_obs(self):
+        """The oracle keeps the stacks in deque order: that IS a ring whose newest frame sits in the last slot."""
+        return self.obs, torch.full((self.N,), self.obs.shape[1] - 1, dtype=torch.uint8)
+
     def step(self, actions, ray_slice=None):
         lo, cnt = ray_slice if ray_slice is not None else (0, self.N)
         keep = {k: getattr(self.env, k).copy() for k in ("scan", "obs", "local_goal")}
@@ -101,7 +105,8 @@ def _worker(rank, world, port, out, n_robots):
     sw.reset()
     for k in range(6):
         sw.step(_actions(k, n_robots)[sw.lo:sw.hi])          # every rank only knows its own robots' commands
-    torch.save({"lo": sw.lo, "hi": sw.hi, "obs": sw.local("obs").clone(), "pose": sw.env.pose.clone(),
+    assert torch.equal(sw.obs(), sw.local("obs"))            # the slice's stacks gathered from its ring rows only
+    torch.save({"lo": sw.lo, "hi": sw.hi, "obs": sw.obs().clone(), "pose": sw.env.pose.clone(),
                 "reward": sw.env.reward.clone(), "scan": sw.local("scan").clone()}, f"{out}.{rank}")
     dist.destroy_process_group()
 

@@ -15,6 +15,31 @@ for p in (os.path.join(ROOT, "rl-collision-avoidance_amd"), os.path.join(ROOT, "
 import mrca_oracle as O  # noqa: E402
 from mrca import scenario as S  # noqa: E402
 
+_ref_dir = None
+
+
+def reference_dir():
+    """A directory holding the reference's unchanged Python scripts, or None: $MRCA_REFERENCE / /root/reference where a
+    checkout exists (this container), otherwise the git-ignored archive tools/stage_reference.sh packed
+    (tests/_reference.tgz -- it travels to the GPU box with the working tree) unpacked into a temporary directory."""
+    global _ref_dir
+    if _ref_dir is None:
+        cand = os.environ.get("MRCA_REFERENCE", "/root/reference")
+        tgz = os.path.join(ROOT, "tests", "_reference.tgz")
+        if os.path.exists(os.path.join(cand, "ppo_stage1.py")):
+            _ref_dir = cand
+        elif os.path.exists(tgz):
+            import tarfile
+            import tempfile
+            d = tempfile.mkdtemp(prefix="mrca_reference_")
+            with tarfile.open(tgz) as t:
+                t.extractall(d)
+            _ref_dir = d
+        else:
+            _ref_dir = ""
+    return _ref_dir or None
+
+
 STATE_FIELDS = ["pose", "speed", "speed_gt", "goal", "init_pose", "scan", "obs", "local_goal", "reward", "prev_dist",
                 "done", "result", "first_result", "crashed", "live", "t", "episode"]
 

@@ -43,8 +43,7 @@ def traffic_json(root, out, robots, scenario):
          "move_fetch_kib": avg.get(("move_kernel", "FETCH_SIZE")), "move_write_kib": avg.get(("move_kernel", "WRITE_SIZE")),
          "dispatches": {f"{k[0]}:{k[1]}": acc[k][0] for k in acc},
          "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), averages per launch in "
-                 "KiB; FETCH_SIZE is doubled on gfx950 when converted to bytes (MI355X_MICROARCH.md HBM section). "
-                 "move_kernel's launch also carries the frame-stack shift of the tick."}
+                 "KiB; FETCH_SIZE is doubled on gfx950 when converted to bytes (MI355X_MICROARCH.md HBM section)."}
     json.dump(d, open(out, "w"), indent=1)
     print(json.dumps(d))
 
