@@ -17,6 +17,8 @@
 #   prof_bigworld    rocprofv3 --kernel-trace --stats of tools/bigworld_bench.py (BIGWORLD_ARGS: robot counts)
 #   circle           mrca.evaluate of the committed checkpoints (POLICY=... overrides)
 #   train            tools/train_recipe.sh (TRAIN_ARGS / S1_SECONDS / S2_SECONDS)
+#   boundary         tools/launch_boundary (device-side stamps: eager vs hipGraph) + its rocprofv3 kernel trace through
+#                    tools/trace_gaps.py; bench.py env mode eager and --graph; rocprofv3 trace of both with the gaps
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
 TAG="${TAG:-pass}"
@@ -102,6 +104,25 @@ for STAGE in "$@"; do
       done ;;
     train)
       bash tools/train_recipe.sh "$O" ;;
+    boundary)
+      [ -x tools/_build/launch_boundary ] || { mkdir -p tools/_build; hipcc --offload-arch=gfx950 -O3 tools/launch_boundary.hip -o tools/_build/launch_boundary; }
+      timeout 120 tools/_build/launch_boundary > "$O/launch_boundary.txt" 2>&1; echo "rc=$?"; cut -c1-230 "$O/launch_boundary.txt"
+      cd /tmp
+      timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$O/prof_lb" -o trace -- "$R/tools/_build/launch_boundary" > "$O/prof_lb.log" 2>&1; echo "trace rc=$?"
+      cd "$R"
+      python tools/trace_gaps.py "$O/prof_lb" stamp_kernel > "$O/launch_boundary_rocprof_gaps.txt" 2>&1; cut -c1-200 "$O/launch_boundary_rocprof_gaps.txt"
+      rm -rf "$O/prof_lb"
+      timeout 600 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-extra > "$O/bench_env_eager.json" 2>> "$O/bench.err"; echo "eager rc=$?"; cut -c1-330 "$O/bench_env_eager.json"
+      timeout 600 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-extra --graph > "$O/bench_env_graph.json" 2>> "$O/bench.err"; echo "graph rc=$?"; cut -c1-330 "$O/bench_env_graph.json"
+      cd /tmp
+      for M in eager graph; do
+        FL=""; [ $M = graph ] && FL="--graph"
+        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_$M" -o trace -- python "$R/bench.py" --steps 300 --warmup 30 --no-cpu-baseline --no-extra $FL > "$O/prof_$M.log" 2>&1; echo "trace $M rc=$?"
+        python "$R/tools/trace_gaps.py" "$O/prof_$M" raycast_kernel move_kernel > "$O/env_${M}_gaps.txt" 2>&1; cut -c1-200 "$O/env_${M}_gaps.txt"
+        f=$(find "$O/prof_$M" -name "trace_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/env_${M}_kernel_stats.csv"
+        rm -rf "$O/prof_$M"
+      done
+      cd "$R" ;;
     *) echo "unknown stage $STAGE" ;;
   esac
 done
