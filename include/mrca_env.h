@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MRCA_ABI_VERSION 3
+#define MRCA_ABI_VERSION 4
 
 typedef struct mrca_env mrca_env; /* opaque */
 
@@ -69,10 +69,13 @@ enum mrca_field {
     MRCA_F_SPEED_GT,      /* f32 [N,2]   get_self_speedGT   stage_world1.py:119 ; stageros.cpp:585-590                   */
     MRCA_F_GOAL,          /* f32 [N,2]   env.goal_point     stage_world1.py:173                                          */
     MRCA_F_INIT_POSE,     /* f32 [N,3]   env.init_pose      stage_world1.py:263                                          */
-    MRCA_F_SCAN,          /* f32 [N,B]   base_scan ranges   stageros.cpp:479-516                                         */
+    MRCA_F_SCAN,          /* f32 [N,B]   base_scan ranges   stageros.cpp:479-516 : the newest scan, a COPY out of
+                           *             MRCA_F_SCAN_RING -- current after every call with lazy_obs = 0, otherwise after
+                           *             mrca_materialize(MRCA_VIEW_SCAN)                                                    */
     MRCA_F_OBS,           /* f32 [N,F,B] get_laser_observation x frame deque  stage_world1.py:122-140, ppo_stage1.py:59-60,87-89
-                           *             a COPY of MRCA_F_OBS_RING in deque order (oldest frame first): current after every
-                           *             call with lazy_obs = 0, otherwise after mrca_materialize_obs() */
+                           *             x / 6 - 0.5 of the last F scans in deque order (oldest frame first), made from
+                           *             MRCA_F_SCAN_RING: current after every call with lazy_obs = 0, otherwise after
+                           *             mrca_materialize(MRCA_VIEW_OBS) */
     MRCA_F_LOCAL_GOAL,    /* f32 [N,2]   get_local_goal     stage_world1.py:155-160                                      */
     MRCA_F_REWARD,        /* f32 [N]     get_reward_and_terminate[0]  stage_world1.py:180-211                            */
     MRCA_F_DONE,          /* u8  [N]     get_reward_and_terminate[1]                                                     */
@@ -84,9 +87,11 @@ enum mrca_field {
     MRCA_F_T,             /* i32 [N]     the `step` argument of get_reward_and_terminate (ppo_stage1.py:57,118)          */
     MRCA_F_EPISODE,       /* i32 [N]     episode counter (RNG stream position)                                          */
     MRCA_F_PREV_DIST,     /* f32 [N]     self.distance      stage_world1.py:176-177,185-186                              */
-    MRCA_F_OBS_RING,      /* f32 [N,F,B] the same frame deque stored as a ring (ABI 3): a tick writes ONE frame per robot,
-                           *             logical frame f (0 = oldest) of robot n is slot (head[n] + 1 + f) mod F */
-    MRCA_F_OBS_HEAD,      /* u8  [N]     slot of robot n's newest frame in MRCA_F_OBS_RING                                */
+    MRCA_F_SCAN_RING,     /* f32 [N,F,B] the last F scans of every robot (RAW ranges, 0..6 m) as a ring (ABI 4): a tick writes ONE
+                           *             row per robot -- the tick's only per-beam store -- logical frame f (0 = oldest) of
+                           *             robot n is slot (head[n] + 1 + f) mod F.  (ABI 3 kept a ring of NORMALISED frames
+                           *             next to MRCA_F_SCAN: every beam was stored twice.)                                */
+    MRCA_F_RING_HEAD,     /* u8  [N]     slot of robot n's newest scan in MRCA_F_SCAN_RING                                */
     MRCA_F_COUNT
 };
 
@@ -117,9 +122,9 @@ typedef struct mrca_config {
      * res > 0 [m] = Stage's rule on a raster of `res` metres (worlds/stage1.world:3: 0.2): robots collide when their
      * OUTLINES SHARE A RASTER CELL, i.e. up to one cell apart.  res >= 0.1; not with robots_per_world > 64. */
     float collision_raster;
-    /* ABI 3.  0: MRCA_F_OBS (deque order) is brought up to date by every mrca_reset / mrca_step -- one extra copy of the
-     * stack per call, what a caller written against ABI 2 expects.  1: only mrca_materialize_obs() does that; callers
-     * that read MRCA_F_OBS_RING + MRCA_F_OBS_HEAD (mrca_lidar_features does) never pay for it. */
+    /* ABI 3 / 4.  0: MRCA_F_SCAN and MRCA_F_OBS are brought up to date by every mrca_reset / mrca_step -- one extra pass
+     * over the ring per call, what a caller written against ABI 2 expects.  1: only mrca_materialize() does that; callers
+     * that read MRCA_F_SCAN_RING + MRCA_F_RING_HEAD (mrca_lidar_features does) never pay for it. */
     int32_t lazy_obs;
     /* ABI 3, fidelity.  0: a robot that is not acting any more (MRCA_F_LIVE = 0: finished, waiting for its group,
      * ppo_stage2.py:72-107) is commanded (0, 0), and MRCA_F_SPEED restarts at 0 with every episode.  1: what stageros
@@ -162,8 +167,14 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
  * (3.85x measured on one rank's share, profiles/r03_f_bigworld_shards8.jsonl). */
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream);
 
-/* MRCA_F_OBS := the ring in deque order, for all robots (asynchronous on `stream`).  Needed only with lazy_obs = 1. */
-int mrca_materialize_obs(mrca_env* env, void* stream);
+/* The reference-shaped views of the ring, for all robots (asynchronous on `stream`; needed only with lazy_obs = 1):
+ * what & MRCA_VIEW_SCAN: MRCA_F_SCAN := every robot's newest scan; what & MRCA_VIEW_OBS: MRCA_F_OBS := x / 6 - 0.5
+ * (stage_world1.py:140) of the ring in deque order. */
+enum mrca_view { MRCA_VIEW_SCAN = 1, MRCA_VIEW_OBS = 2 };
+int mrca_materialize(mrca_env* env, int32_t what, void* stream);
+/* out_dev f32[N,B] := x / 6 - 0.5 of every robot's newest scan -- the ONE observation row per tick a rollout buffer that
+ * stores single frames keeps (ppo_stage1.py:87-89 appends exactly this row to the deque). */
+int mrca_newest_obs(mrca_env* env, float* out_dev, void* stream);
 
 /* Synchronises `stream` and reports (then clears) the env's sticky device-side status word: MRCA_OK, or MRCA_ERR_HIP with
  * mrca_last_error() saying what went wrong on the device since the last check.  Today one condition: the ordered
@@ -197,15 +208,18 @@ int mrca_event_pair_overhead(void* stream, int32_t samples, float* us_out);
 /* Rollout-path front end of the lidar actor-critic (model/net.py:19-25,37-49,57-69: Conv1d(3,32,k5,s2,p1) -> ReLU ->
  * Conv1d(32,32,k3,s2,p1) -> ReLU for the actor and the critic tower), fused into one kernel: fp32 in, fp32 MFMA
  * accumulate, the 32 x 255 intermediate never leaves the CU.
- *   obs_dev  f32[N,3,512]   the observation stacks: MRCA_F_OBS (deque order) with obs_head_dev = NULL, or
- *                           MRCA_F_OBS_RING with obs_head_dev = MRCA_F_OBS_HEAD (u8[N]): the kernel then reads frame f
- *                           of robot n from slot (head[n] + 1 + f) mod 3 while staging
+ *   obs_dev  f32[N,3,512]   the observation stacks: MRCA_F_OBS (deque order) with obs_head_dev = NULL, or a ring with
+ *                           obs_head_dev = its head slots (u8[N]): the kernel then reads frame f of robot n from slot
+ *                           (head[n] + 1 + f) mod 3 while staging
+ *   raw_scans               0: obs_dev holds normalised observations; 1: it holds RAW ranges (MRCA_F_SCAN_RING with
+ *                           MRCA_F_RING_HEAD) and the kernel applies x / 6 - 0.5 (stage_world1.py:140) while staging --
+ *                           bit-identical to reading the materialised MRCA_F_OBS
  *   w1_dev   f32[2,32,3,5]  b1_dev f32[2,32]    act_fea_cv1 / crt_fea_cv1 weight and bias, tower-major
  *   w2_dev   f32[2,32,32,3] b2_dev f32[2,32]    act_fea_cv2 / crt_fea_cv2
  *   feat_dev f32[2,N,4096]  out: tower-major, each row in the flatten order of [32,128] (what act_fc1 / crt_fc1 eat)
  * frames must be 3 and beams 512 (MRCA_ERR_UNSUPPORTED otherwise). */
-int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t n_robots, int32_t frames, int32_t beams,
-                        const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
+int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t raw_scans, int32_t n_robots,
+                        int32_t frames, int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
                         float* feat_dev, void* stream);
 
 /* The rest of the rollout inference behind fc1 in one kernel (model/net.py:41-55,61-70: ReLU, cat with goal and speed,

@@ -126,8 +126,8 @@ void make_layout(const mrca_config* c, Layout* L) {
     sz[MRCA_F_T] = N * 4;
     sz[MRCA_F_EPISODE] = N * 4;
     sz[MRCA_F_PREV_DIST] = N * 4;
-    sz[MRCA_F_OBS_RING] = N * F * B * 4;
-    sz[MRCA_F_OBS_HEAD] = N;
+    sz[MRCA_F_SCAN_RING] = N * F * B * 4;
+    sz[MRCA_F_RING_HEAD] = N;
     size_t off = 0;
     for (int f = 0; f < MRCA_F_COUNT; ++f) {
         L->field_off[f] = off;
@@ -148,7 +148,7 @@ void make_layout(const mrca_config* c, Layout* L) {
     L->off_beam_sin = take(B * 4);
     L->off_map = take((size_t)c->map_height * c->map_words_per_row * 4);
     L->off_free_rect = take((size_t)(c->map_width + 2 * mrca::kFieldPadX) * (c->map_height + 2 * mrca::kFieldPadY) *
-                            sizeof(uint32_t));
+                            4 * sizeof(uint16_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->off_head = take(N * sizeof(float4));
     L->bw_cmask = L->bw_lmask = 0;
@@ -180,7 +180,7 @@ constexpr int kTimingRing = 1024;
 struct HostField {
     std::vector<uint32_t> bits;
     int32_t width, height, wpr;
-    std::vector<uint32_t> entries;
+    std::vector<uint16_t> entries;      // 4 quadrant entries per cell
     int pitch;
 };
 std::shared_ptr<const HostField> host_field(const mrca_config* c) {
@@ -324,7 +324,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     {
         const std::shared_ptr<const HostField> hf = host_field(cfg);
         free_rect_pitch = hf->pitch;
-        HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_free_rect, hf->entries.data(), hf->entries.size() * sizeof(uint32_t),
+        HIP_TRY_BAIL(hipMemcpy(env->arena + L.off_free_rect, hf->entries.data(), hf->entries.size() * sizeof(uint16_t),
                                hipMemcpyHostToDevice));
     }
     {
@@ -358,8 +358,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.init_pose = reinterpret_cast<float*>(a + L.field_off[MRCA_F_INIT_POSE]);
     v.scan = reinterpret_cast<float*>(a + L.field_off[MRCA_F_SCAN]);
     v.obs = reinterpret_cast<float*>(a + L.field_off[MRCA_F_OBS]);
-    v.obs_ring = reinterpret_cast<float*>(a + L.field_off[MRCA_F_OBS_RING]);
-    v.obs_head = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_OBS_HEAD]);
+    v.scan_ring = reinterpret_cast<float*>(a + L.field_off[MRCA_F_SCAN_RING]);
+    v.ring_head = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_RING_HEAD]);
     v.local_goal = reinterpret_cast<float*>(a + L.field_off[MRCA_F_LOCAL_GOAL]);
     v.reward = reinterpret_cast<float*>(a + L.field_off[MRCA_F_REWARD]);
     v.prev_dist = reinterpret_cast<float*>(a + L.field_off[MRCA_F_PREV_DIST]);
@@ -379,7 +379,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.beam_cos = reinterpret_cast<const float*>(a + L.off_beam_cos);
     v.beam_sin = reinterpret_cast<const float*>(a + L.off_beam_sin);
     v.map_bits = reinterpret_cast<const uint32_t*>(a + L.off_map);
-    v.free_rect = reinterpret_cast<const uint32_t*>(a + L.off_free_rect);
+    v.free_rect = reinterpret_cast<const uint16_t*>(a + L.off_free_rect);
     v.free_rect_pitch = free_rect_pitch;
     v.cellfield = reinterpret_cast<const uint8_t*>(a + L.off_cellfield);
     v.head = reinterpret_cast<float4*>(a + L.off_head);
@@ -473,15 +473,26 @@ int mrca_reset(mrca_env* env, const uint8_t* mask_dev, const float* poses_dev, c
     mrca::launch_reset(env->view, mask_dev, poses_dev, goals_dev, s);
     mrca::launch_lidar_grid(env->view, /*counted=*/0, s);
     mrca::launch_raycast(env->view, /*only_fresh=*/1, s);
-    if (!env->cfg.lazy_obs) mrca::launch_materialize_obs(env->view, s);
+    if (!env->cfg.lazy_obs) mrca::launch_materialize(env->view, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, s);
     HIP_TRY(hipGetLastError());
     return MRCA_OK;
 }
 
-int mrca_materialize_obs(mrca_env* env, void* stream) {
+int mrca_materialize(mrca_env* env, int32_t what, void* stream) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (what & ~(MRCA_VIEW_SCAN | MRCA_VIEW_OBS)) return fail(MRCA_ERR_INVALID, "mrca_materialize: unknown view bits 0x%x", what);
     DeviceGuard guard(env->cfg.device);
-    mrca::launch_materialize_obs(env->view, static_cast<hipStream_t>(stream));
+    mrca::launch_materialize(env->view, what, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
+int mrca_newest_obs(mrca_env* env, float* out_dev, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (!out_dev) return fail(MRCA_ERR_INVALID, "out_dev is NULL");
+    if (reinterpret_cast<uintptr_t>(out_dev) % 16) return fail(MRCA_ERR_INVALID, "out_dev must be 16-byte aligned");
+    DeviceGuard guard(env->cfg.device);
+    mrca::launch_newest_obs(env->view, out_dev, static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return MRCA_OK;
 }
@@ -503,7 +514,7 @@ static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int
     mrca::launch_lidar_grid(v, /*counted=*/1, s);
     if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
     mrca::launch_raycast(v, /*only_fresh=*/0, s);
-    if (!env->cfg.lazy_obs) mrca::launch_materialize_obs(v, s);   // (inside the ray cast's event pair: it is part of the tick then)
+    if (!env->cfg.lazy_obs) mrca::launch_materialize(v, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, s);   // (inside the ray cast's event pair: part of the tick then)
     if (rec) {
         HIP_TRY(hipEventRecord(env->ev[env->ev_used + 2], s));
         env->ev_used += 3;

@@ -174,11 +174,14 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 
 // ------------------------------------------------------------------------------------------
 // Same result as grid_march, far fewer steps: empty-space skipping over a per-cell field of FREE
-// RECTANGLES.  For every empty cell the field stores a rectangle of empty cells around it -- 8-bit
-// extents (left, right, down, up), so the cells [ix-L, ix+R] x [iy-D, iy+U] are all empty -- and
-// kCellOccupied for an occupied cell.  A ray jumps straight to the face where it leaves the rectangle
-// of the cell it is in (in a corridor the rectangle runs the length of the corridor) and looks again:
-// ~2 lookups per lidar ray on the reference maps, and the cell bitmap is never read.
+// RECTANGLES.  A ray only ever needs free space AHEAD of it, so the field stores, for every empty cell, FOUR
+// rectangles of empty cells -- one per quadrant of the direction of travel, each with the cell in the corner the ray
+// enters through: quadrant q = (dx > 0) | (dy > 0) << 1 has the 16-bit entry ex | ey << 8, meaning the cells
+// [ix, ix + sx*ex] x [iy, iy + sy*ey] are all empty -- and 0xFFFF in all four for an occupied cell.  A ray jumps
+// straight to the face where it leaves the rectangle of the cell it is in and looks again: ~1.2 lookups per lidar ray
+// on the Stage-1 rink, and the cell bitmap is never read.  (Rounds 1-3 stored ONE rectangle per cell, grown on all four
+// sides -- the two extents a ray does not use narrowed the two it does: 1.7 lookups per ray, and 3.0 instead of 2.6 loop
+// iterations per 64-beam wavefront; tools/field_probe.cpp)
 //
 // Exactness: grid_march is a 2-way merge of the x-crossing events tx(b) and the y-crossing events
 // ty(b) (both monotone in b), ties -> y first.  Leaving the rectangle through its x face Bx happens
@@ -187,14 +190,15 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 // arithmetic estimate that is always within one boundary of the truth and is settled with the SAME
 // closed-form times, so the walk resumes in precisely the cell, and with precisely the pending
 // boundaries, the cell-by-cell walk would have -- every later comparison, and the returned entry
-// time, are bit-identical.
+// time, are bit-identical.  ANY field of valid empty rectangles gives the same numbers; the field only decides how many
+// jumps a ray takes.
 //
 // Granularity (measured, 4096 / 8228 robots, profiles/r01_u..z_ablation.txt): 4x4-cell blocks with
 // 4-bit extents 48 / 130 us per ray-cast launch on stage-1 / stage-2; 2x2-cell blocks with 8-bit
-// extents 38 / 77 us; per cell 34 / 43 us.  The per-cell field is 0.6 / 2.6 MB for the 20 m / 40 m maps
-// and stays L2-resident.
-constexpr int kFieldMaxExtent = 127;             // cells per side; 6 m of range is 120 cells at 0.05 m
-constexpr uint32_t kCellOccupied = 0xFFFFFFFFu;  // extents are <= 127, so no empty cell packs to this
+// extents 38 / 77 us; per cell 34 / 43 us.  The per-cell field is 8 bytes per cell: 1.3 / 5.1 MB for the 20 m / 40 m
+// maps at 0.05 m.
+constexpr int kFieldMaxExtent = 254;             // cells per side (8-bit; 255 | 255 << 8 marks an occupied cell)
+constexpr uint32_t kCellOccupied = 0xFFFFu;      // a quadrant entry of an occupied cell
 
 // The field is stored with a border of empty cells (kFieldPadX columns left/right, kFieldPadY rows
 // below/above, value 0 = "empty, no extent"): clamping the cell coordinates into the border replaces
@@ -216,6 +220,17 @@ MRCA_HD int med3_i32(int a, int b, int c) {
     return a + b + c - lo - hi;   // no overflow for the operands used here (two of them < 2^20, one < 2^30)
 #endif
 }
+// a * b + c for |a|, |b| < 2^23 in ONE full-rate v_mad_i32_i24 (left to itself the compiler turns the multiply of an
+// operand it knows to be small into v_mad_u64_u32: a quarter-rate 64-bit instruction in the march's inner loop)
+MRCA_HD int mad24(int a, int b, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return a * b + c;
+#endif
+}
 template <int LO>
 MRCA_HD int clamp_from(int x, int hi) {   // clamp(x, LO, hi), LO <= hi
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -227,10 +242,11 @@ MRCA_HD int clamp_from(int x, int hi) {   // clamp(x, LO, hi), LO <= hi
 #endif
 }
 
-struct FreeRectField {   // free-rectangle field straight from global memory (L1/L2-resident)
-    const uint32_t* d;   // base of the padded array
-    int32_t w, h, pitch; // map size in cells, entries per padded row
-    MRCA_HD uint32_t operator()(int ix, int iy) const {
+struct FreeRectField {   // quadrant free-rectangle field straight from global memory (L1/L2-resident)
+    const uint16_t* d;   // base of the padded array: 4 entries (quadrants 0..3) per cell
+    int32_t w, h, pitch; // map size in cells, CELLS per padded row
+    // byte offset of cell (ix, iy)'s record from d (cells outside the map clamp into the zero border)
+    MRCA_HD uint32_t cell_offset(int ix, int iy) const {
         const int x = clamp_from<-kFieldPadX>(ix, w + kFieldPadX - 1);
         const int y = clamp_from<-kFieldPadY>(iy, h + kFieldPadY - 1);
         // |y|, pitch < 2^23: 24-bit multiply-add
@@ -239,7 +255,17 @@ struct FreeRectField {   // free-rectangle field straight from global memory (L1
 #else
         const int idx = y * pitch + x;
 #endif
-        return d[(uint32_t)(idx + (kFieldPadY * pitch + kFieldPadX))];
+        return (uint32_t)(idx + (kFieldPadY * pitch + kFieldPadX)) << 3;
+    }
+    // the entry of quadrant q (qbytes = 2 * q) of a cell
+    MRCA_HD uint32_t operator()(int ix, int iy, uint32_t qbytes) const {
+        return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(d) + (cell_offset(ix, iy) + qbytes));
+    }
+    // all four entries of a cell: .x = quadrants 0 | 1 << 16, .y = quadrants 2 | 3 << 16 (what a `head` record carries)
+    MRCA_HD void cell(int ix, int iy, uint32_t* lo, uint32_t* hi) const {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(d) + cell_offset(ix, iy));
+        *lo = p[0];
+        *hi = p[1];
     }
 };
 
@@ -248,7 +274,7 @@ struct FreeRectField {   // free-rectangle field straight from global memory (L1
 struct MarchOrigin {
     float fx, fy;
     int32_t ix0, iy0;
-    uint32_t v0;
+    uint32_t v_lo, v_hi;     // the four quadrant entries of the origin's cell (FreeRectField::cell)
 };
 template <class Field>
 MRCA_HD MarchOrigin march_origin(const Field& field, const GridGeom& g, float ox, float oy) {
@@ -257,7 +283,7 @@ MRCA_HD MarchOrigin march_origin(const Field& field, const GridGeom& g, float ox
     o.fy = (oy - g.y0) * g.inv_cell;
     o.ix0 = (int)floorf(o.fx);
     o.iy0 = (int)floorf(o.fy);
-    o.v0 = field(o.ix0, o.iy0);
+    field.cell(o.ix0, o.iy0, &o.v_lo, &o.v_hi);
     return o;
 }
 
@@ -271,16 +297,18 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
     const float fx = org.fx, fy = org.fy;
     const int ix0 = org.ix0, iy0 = org.iy0;
     const float tmax_c = tmax * g.inv_cell;
-    uint32_t v = org.v0;  // carried: one field lookup per jump
+    const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
+    const bool xpos = dx > 0.0f, ypos = dy > 0.0f;
+    // the ray's quadrant picks which of the four rectangles of a cell it reads -- from the origin's cell onwards
+    const uint32_t qbytes = (xpos ? 2u : 0u) + (ypos ? 4u : 0u);
+    const uint32_t vq = ypos ? org.v_hi : org.v_lo;
+    uint32_t v = xpos ? vq >> 16 : vq & 0xFFFFu;  // carried: one field lookup per jump
     if (v == kCellOccupied) return 0.0f;
     if (!(tmax_c > 0.0f)) return tmax;
-    const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
     const float inv_dx = xnz ? rcp_exact(dx) : kInf;
     const float inv_dy = ynz ? rcp_exact(dy) : kInf;
-    const bool xpos = dx > 0.0f, ypos = dy > 0.0f;
     const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
     const int ux = xpos ? 1 : 0, uy = ypos ? 1 : 0;      // current cell = pending boundary - u, on each axis
-    const int shx = xpos ? 8 : 0, shy = ypos ? 24 : 16;  // which extent byte faces the direction of travel
     // a pending boundary only ever moves in the direction of travel: clamp(b, from b0) = med3(b, b0, lim)
     const int limx = xpos ? 0x3FFFFFFF : -0x3FFFFFFF, limy = ypos ? 0x3FFFFFFF : -0x3FFFFFFF;
     // An axis-parallel ray never crosses a boundary of its zero axis -- which then is always the secondary
@@ -294,14 +322,9 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
     int guard = kMaxMarchSteps;
     do {
         // faces of the rectangle known to be free: e cells beyond the current cell's own far face
-        const int ex = (int)((v >> shx) & 255u), ey = (int)((v >> shy) & 255u);
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int Bx = __mul24(ex, sx) + bx;
-        const int By = __mul24(ey, sy) + by;
-#else
-        const int Bx = ex * sx + bx;
-        const int By = ey * sy + by;
-#endif
+        const int ex = (int)(v & 255u), ey = (int)((v >> 8) & 255u);   // (both as 8-bit fields: one v_and / v_bfe + a 24-bit mad each)
+        const int Bx = mad24(ex, sx, bx);
+        const int By = mad24(ey, sy, by);
         const float rawx = ((float)Bx - fx) * inv_dx;
         const float rawy = ((float)By - fy) * inv_dy;
         const float tBx = xnz ? rawx : kInf;
@@ -337,7 +360,7 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
         // pending boundaries after the jump: the exit-axis face is crossed, the secondary axis resumes at bS
         bx = xe ? Bx + sx : bS;
         by = xe ? bS : By + sy;
-        v = field(bx - ux, by - uy);  // cells outside the map read as empty (the zero border)
+        v = field(bx - ux, by - uy, qbytes);  // cells outside the map read as empty (the zero border)
         hit = v == kCellOccupied;
     } while (!hit && --guard > 0);
     return hit ? t * g.cell : tmax;
@@ -360,7 +383,7 @@ MRCA_HD void grid_march_skip_n(const Field& field, const GridGeom& g, const Marc
                                const float (&dy)[K], float tmax, float (&out)[K]) {
     const float fx = org.fx, fy = org.fy;
     const float tmax_c = tmax * g.inv_cell;
-    if (org.v0 == kCellOccupied) {
+    if ((org.v_lo & 0xFFFFu) == kCellOccupied) {      // an occupied cell says so in all four quadrants
 #pragma unroll
         for (int k = 0; k < K; ++k) out[k] = 0.0f;
         return;
@@ -372,7 +395,7 @@ MRCA_HD void grid_march_skip_n(const Field& field, const GridGeom& g, const Marc
     }
     float inv_dx[K], inv_dy[K], t[K];
     int bx[K], by[K];
-    uint32_t v[K];
+    uint32_t v[K], qb[K];
     bool act[K], hit[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -380,7 +403,9 @@ MRCA_HD void grid_march_skip_n(const Field& field, const GridGeom& g, const Marc
         inv_dy[k] = dy[k] != 0.0f ? rcp_exact(dy[k]) : kInf;
         bx[k] = org.ix0 + (dx[k] > 0.0f ? 1 : 0);
         by[k] = org.iy0 + (dy[k] > 0.0f ? 1 : 0);
-        v[k] = org.v0;
+        qb[k] = (dx[k] > 0.0f ? 2u : 0u) + (dy[k] > 0.0f ? 4u : 0u);
+        const uint32_t vq = dy[k] > 0.0f ? org.v_hi : org.v_lo;
+        v[k] = dx[k] > 0.0f ? vq >> 16 : vq & 0xFFFFu;
         t[k] = 0.0f;
         act[k] = true;
         hit[k] = false;
@@ -397,16 +422,10 @@ MRCA_HD void grid_march_skip_n(const Field& field, const GridGeom& g, const Marc
             const bool xpos = dx[k] > 0.0f, ypos = dy[k] > 0.0f;
             const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
             const int ux = xpos ? 1 : 0, uy = ypos ? 1 : 0;
-            const int shx = xpos ? 8 : 0, shy = ypos ? 24 : 16;
             const int limx = xpos ? 0x3FFFFFFF : -0x3FFFFFFF, limy = ypos ? 0x3FFFFFFF : -0x3FFFFFFF;
-            const int ex = (int)((v[k] >> shx) & 255u), ey = (int)((v[k] >> shy) & 255u);
-#if defined(__HIP_DEVICE_COMPILE__)
-            const int Bx = __mul24(ex, sx) + bx[k];
-            const int By = __mul24(ey, sy) + by[k];
-#else
-            const int Bx = ex * sx + bx[k];
-            const int By = ey * sy + by[k];
-#endif
+            const int ex = (int)(v[k] & 255u), ey = (int)((v[k] >> 8) & 255u);
+            const int Bx = mad24(ex, sx, bx[k]);
+            const int By = mad24(ey, sy, by[k]);
             const float rawx = ((float)Bx - fx) * inv_dx[k];
             const float rawy = ((float)By - fy) * inv_dy[k];
             const float tBx = xnz ? rawx : kInf;
@@ -438,7 +457,7 @@ MRCA_HD void grid_march_skip_n(const Field& field, const GridGeom& g, const Marc
         }
         uint32_t nv[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) nv[k] = field(cx[k], cy[k]);   // K independent lookups in flight
+        for (int k = 0; k < K; ++k) nv[k] = field(cx[k], cy[k], qb[k]);   // K independent lookups in flight
         --guard;
         any = false;
 #pragma unroll

@@ -10,15 +10,16 @@
 
 namespace mrca {
 
-// Free-rectangle field for grid_march_skip, one entry per cell.  For an EMPTY cell the entry packs four
-// 8-bit extents L | R<<8 | D<<16 | U<<24 of a rectangle of empty cells [x-L, x+R] x [y-D, y+U] around it
-// (cells outside the map are empty); an occupied cell gets kCellOccupied.  The rectangle is grown
-// greedily, one side at a time in the order left, right, down, up, while the strip added is entirely
-// empty (up to kFieldMaxExtent cells per side) -- any empty rectangle containing the cell is valid for
-// the march, larger ones just save jumps.
-// Storage: (height + 2*kFieldPadY) rows of `pitch` entries, cell (0,0) at [kFieldPadY][kFieldPadX], the
+// Quadrant free-rectangle field for grid_march_skip: FOUR 16-bit entries per cell, one per quadrant of the direction of
+// travel, q = (dx > 0) | (dy > 0) << 1 with sx = +-1, sy = +-1 accordingly.  For an EMPTY cell entry q packs the extents
+// ex | ey << 8 of a rectangle of empty cells [x, x + sx*ex] x [y, y + sy*ey] that has the cell in the corner a ray of
+// that quadrant enters through (cells outside the map are empty); an occupied cell gets kCellOccupied in all four.  Each
+// rectangle is grown greedily, alternately in x and in y, while the strip added is entirely empty (up to
+// kFieldMaxExtent cells per side) -- any empty rectangle is valid for the march, larger ones just save jumps; measured
+// against the alternatives (one 4-sided rectangle per cell, largest square, largest area) in tools/field_probe.cpp.
+// Storage: (height + 2*kFieldPadY) rows of `pitch` CELLS (4 x uint16 each), cell (0,0) at [kFieldPadY][kFieldPadX], the
 // border filled with 0 (see FreeRectField).  Rows are independent and are built by a few host threads.
-inline void build_free_rect_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint32_t>* out,
+inline void build_free_rect_field(const uint32_t* bits, int width, int height, int wpr, std::vector<uint16_t>* out,
                                   int* pitch_out) {
     // summed-area table of occupied cells for O(1) strip tests
     const size_t sw = (size_t)width + 1;
@@ -28,33 +29,36 @@ inline void build_free_rect_field(const uint32_t* bits, int width, int height, i
         for (int x = 0; x < width; ++x)
             sat[(size_t)(y + 1) * sw + x + 1] =
                 occupied(x, y) + sat[(size_t)y * sw + x + 1] + sat[(size_t)(y + 1) * sw + x] - sat[(size_t)y * sw + x];
-    auto count = [&](int x0, int y0, int x1, int y1) -> int {  // inclusive cell rectangle, clipped to the map
+    auto count = [&](int x0, int y0, int x1, int y1) -> int {  // inclusive cell rectangle (either order), clipped to the map
+        if (x0 > x1) std::swap(x0, x1);
+        if (y0 > y1) std::swap(y0, y1);
         x0 = std::max(x0, 0); y0 = std::max(y0, 0); x1 = std::min(x1, width - 1); y1 = std::min(y1, height - 1);
         if (x0 > x1 || y0 > y1) return 0;
         return sat[(size_t)(y1 + 1) * sw + x1 + 1] - sat[(size_t)y0 * sw + x1 + 1] - sat[(size_t)(y1 + 1) * sw + x0] +
                sat[(size_t)y0 * sw + x0];
     };
     const int pitch = width + 2 * kFieldPadX;
-    out->assign((size_t)pitch * (height + 2 * kFieldPadY), 0);
-    uint32_t* field = out->data();
+    out->assign((size_t)pitch * (height + 2 * kFieldPadY) * 4, 0);
+    uint16_t* field = out->data();
     auto rows = [&](int y_begin, int y_end) {
         const int M = kFieldMaxExtent;   // < 255, so a packed entry can never equal kCellOccupied
         for (int y = y_begin; y < y_end; ++y)
             for (int x = 0; x < width; ++x) {
-                uint32_t& e = field[(size_t)(y + kFieldPadY) * pitch + x + kFieldPadX];
+                uint16_t* e = field + ((size_t)(y + kFieldPadY) * pitch + x + kFieldPadX) * 4;
                 if (occupied(x, y)) {
-                    e = kCellOccupied;
+                    e[0] = e[1] = e[2] = e[3] = (uint16_t)kCellOccupied;
                     continue;
                 }
-                int l = 0, r = 0, d = 0, u = 0;
-                for (bool grew = true; grew;) {
-                    grew = false;
-                    if (l < M && count(x - l - 1, y - d, x - l - 1, y + u) == 0) { ++l; grew = true; }
-                    if (r < M && count(x + r + 1, y - d, x + r + 1, y + u) == 0) { ++r; grew = true; }
-                    if (d < M && count(x - l, y - d - 1, x + r, y - d - 1) == 0) { ++d; grew = true; }
-                    if (u < M && count(x - l, y + u + 1, x + r, y + u + 1) == 0) { ++u; grew = true; }
+                for (int q = 0; q < 4; ++q) {
+                    const int sx = (q & 1) ? 1 : -1, sy = (q & 2) ? 1 : -1;
+                    int ex = 0, ey = 0;
+                    for (bool grew = true; grew;) {
+                        grew = false;
+                        if (ex < M && count(x + sx * (ex + 1), y, x + sx * (ex + 1), y + sy * ey) == 0) { ++ex; grew = true; }
+                        if (ey < M && count(x, y + sy * (ey + 1), x + sx * ex, y + sy * (ey + 1)) == 0) { ++ey; grew = true; }
+                    }
+                    e[q] = (uint16_t)(ex | (ey << 8));
                 }
-                e = (uint32_t)l | ((uint32_t)r << 8) | ((uint32_t)d << 16) | ((uint32_t)u << 24);
             }
     };
     const int nthreads = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, height / 64}));

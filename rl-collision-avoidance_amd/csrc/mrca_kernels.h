@@ -17,10 +17,10 @@ struct EnvView {
     float* speed_gt;    // [N,2]
     float* goal;        // [N,2]
     float* init_pose;   // [N,3]
-    float* scan;        // [N,B]
-    float* obs;         // [N,F,B] the frame stack in deque order -- a COPY of obs_ring, made by materialize_obs_kernel
-    float* obs_ring;    // [N,F,B] the frame stack as a ring: slot obs_head[n] holds robot n's newest frame
-    uint8_t* obs_head;  // [N]
+    float* scan;        // [N,B]   the newest scan -- a COPY out of scan_ring, made by materialize_kernel
+    float* obs;         // [N,F,B] the normalised frame stack in deque order -- made from scan_ring by materialize_kernel
+    float* scan_ring;   // [N,F,B] the last F scans (RAW ranges) as a ring: slot ring_head[n] holds robot n's newest one
+    uint8_t* ring_head; // [N]
     float* local_goal;  // [N,2]
     float* reward;      // [N]
     float* prev_dist;   // [N]
@@ -33,9 +33,9 @@ struct EnvView {
     int32_t* t;
     int32_t* episode;
     // internal, one 16-byte record per robot, rewritten by whoever changes a pose (move / reset kernels): sin and
-    // cos of the heading (deterministic sincos_det) and the free-rectangle field entry of the cell the robot
-    // stands in (as float bits).  The ray cast starts from it instead of recomputing all three per wave.
-    float4* head;       // [N] (sin, cos, bits(v0), 0)
+    // cos of the heading (deterministic sincos_det) and the four quadrant entries of the free-rectangle field for the
+    // cell the robot stands in (as float bits).  The ray cast starts from it instead of recomputing all three per wave.
+    float4* head;       // [N] (sin, cos, bits(quadrants 0 | 1 << 16), bits(quadrants 2 | 3 << 16))
     // worlds with more than 64 robots ("big" worlds: one wavefront no longer holds a world): scratch of the
     // per-tick broad phase, see the bw_* kernels.  All NULL / 0 otherwise.
     int32_t big;            // 1: robots_per_world > 64
@@ -62,8 +62,8 @@ struct EnvView {
     const float* beam_sin;
     // occupancy grid (move kernel) + per-cell free-rectangle field (grid_march_skip, ray-cast kernel)
     const uint32_t* map_bits;
-    const uint32_t* free_rect;   // [map_h + 2*kFieldPadY][free_rect_pitch], see FreeRectField
-    int32_t free_rect_pitch;     // padded row length in entries
+    const uint16_t* free_rect;   // [map_h + 2*kFieldPadY][free_rect_pitch][4 quadrants], see FreeRectField
+    int32_t free_rect_pitch;     // padded row length in CELLS
     const uint8_t* cellfield;  // per-cell Chebyshev distance to the nearest occupied cell [map_h][map_w]
     GridGeom g;
     // rules
@@ -107,7 +107,10 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
 void read_ray_stamps(unsigned long long* host, int blocks);     // profiling build: [2 waves][7 stamps][blocks] of raycast_kernel
 void read_move_stamps(unsigned long long* host, int worlds);   // profiling build: s_memtime stamps of move_kernel's phases
 #endif
-void launch_materialize_obs(const EnvView& e, hipStream_t s);   // obs_ring -> obs for robots [ray_first, ray_first + ray_count)
+// scan_ring -> scan (what & 1) and / or obs (what & 2: normalised, deque order) for robots [ray_first, ray_first + ray_count)
+void launch_materialize(const EnvView& e, int what, hipStream_t s);
+// the newest frame of every robot, normalised, into out[N,B] (the row a one-frame rollout buffer stores per tick)
+void launch_newest_obs(const EnvView& e, float* out, hipStream_t s);
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
                 float lam, int T, int N, float* targets, float* advs, hipStream_t s);
 

@@ -16,9 +16,10 @@
 //                  the others: the exact skipping march over the per-cell free-rectangle field (~2 dependent
 //                  L2 lookups per ray).  The robot's own sin/cos and the field entry of its cell come from the
 //                  16-byte `head` record the move kernel published (scalar loads), so no wave recomputes them.
-//                  Each thread slab-tests its own beams against the flagged neighbours and stores their scan
-//                  value and newest observation frame itself -- the frame stack is a ring (one slot per tick, no shift).
-//   materialize_obs_kernel  the ring in deque order (MRCA_F_OBS), on demand.
+//                  Each thread slab-tests its own beams against the flagged neighbours and stores their range itself,
+//                  into the robot's ring of raw scans (one slot per tick, no shift, no second copy).
+//   materialize_kernel  the newest scan (MRCA_F_SCAN) / the normalised stack in deque order (MRCA_F_OBS) out of the ring of
+//                  raw scans, on demand; newest_obs_kernel: the rollout buffer's row.
 //   bw_*           the move kernel's tick for worlds with more than 64 robots (per-robot threads, spatial
 //                  hashes, ordered collision pass as dependency rounds); raycast_kernel<K, true> is its ray cast.
 //   reset_kernel   explicit reset_pose / control_pose / generate_goal_point.
@@ -132,34 +133,60 @@ struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
     }
 };
 
-// The observation stack (ppo_stage1.py:59-60,87-89: a deque of the last F normalised scans) is stored as a RING per
-// robot: obs_ring[n][slot][beam] with obs_head[n] = the slot of the NEWEST frame; logical frame f (0 = oldest) sits in
-// slot (head + 1 + f) mod F.  A tick writes ONE frame per robot (the ray cast's epilogue) and bumps the head; rounds 1-2
-// shifted the whole stack down every tick instead -- 33.6 of the tick's 56.6 MB of HBM traffic at 4096 robots.
-// Consumers that want the deque order (MRCA_F_OBS) get it from this copy kernel, on demand (mrca_materialize_obs) or
-// after every call when the env was created with lazy_obs = 0; the policy's front end reads the ring directly.
-// A thread owns float4 columns of robots [ray_first, ray_first + ray_count).
-__global__ void materialize_obs_kernel(EnvView e) {
+// The observation stack (ppo_stage1.py:59-60,87-89: a deque of the last F normalised scans) is stored as a RING of RAW
+// scans per robot: scan_ring[n][slot][beam] with ring_head[n] = the slot of the NEWEST scan; logical frame f (0 = oldest)
+// sits in slot (head + 1 + f) mod F.  A tick writes ONE row per robot (the ray cast's epilogue) and bumps the head --
+// rounds 1-2 shifted the whole stack down every tick (33.6 of the tick's 56.6 MB of HBM traffic at 4096 robots), round 3
+// still stored every beam twice (the scan and its affine image x / 6 - 0.5: 16.8 MB of the tick's 22.9).  The affine map
+// (stage_world1.py:140) is applied by whoever READS: the policy's front end while it stages a scan (mrca_policy.hip),
+// newest_obs_kernel for the rollout buffer's row, and this kernel, which makes the two views a reference-shaped caller
+// wants -- MRCA_F_SCAN (the newest scan, contiguous) and MRCA_F_OBS (the normalised stack in deque order, what
+// CNNPolicy.forward eats) -- on demand (mrca_materialize) or after every call when the env was created with
+// lazy_obs = 0.  A thread owns float4 columns of robots [ray_first, ray_first + ray_count).
+__device__ __forceinline__ float4 norm_obs4(float4 v) {
+    return make_float4(norm_obs(v.x), norm_obs(v.y), norm_obs(v.z), norm_obs(v.w));
+}
+
+__global__ void materialize_kernel(EnvView e, int what) {
     const int fstride = e.B >> 2;
     const long long total = (long long)e.ray_count * fstride;
-    const float4* ring = reinterpret_cast<const float4*>(e.obs_ring) + (size_t)e.ray_first * e.F * fstride;
+    const float4* ring = reinterpret_cast<const float4*>(e.scan_ring) + (size_t)e.ray_first * e.F * fstride;
     float4* out = reinterpret_cast<float4*>(e.obs) + (size_t)e.ray_first * e.F * fstride;
+    float4* scan = reinterpret_cast<float4*>(e.scan) + (size_t)e.ray_first * fstride;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
         const long long r = k / fstride;
         const int col = (int)(k - r * fstride);
-        const int hd = e.obs_head[e.ray_first + r];
+        const int hd = e.ring_head[e.ray_first + r];
         const float4* src = ring + r * e.F * fstride + col;
-        float4* dst = out + r * e.F * fstride + col;
-        if (e.F == 3) {
-            const int s0 = hd == 2 ? 0 : hd + 1, s1 = s0 == 2 ? 0 : s0 + 1;
-            const float4 a = src[s0 * fstride], b = src[s1 * fstride], c = src[hd * fstride];
-            dst[0] = a;
-            dst[fstride] = b;
-            dst[2 * fstride] = c;
-        } else {
-            for (int f = 0; f < e.F; ++f) dst[f * fstride] = src[((hd + 1 + f) % e.F) * fstride];
+        const float4 newest = src[hd * fstride];
+        if (what & 1) scan[r * fstride + col] = newest;
+        if (what & 2) {
+            float4* dst = out + r * e.F * fstride + col;
+            if (e.F == 3) {
+                const int s0 = hd == 2 ? 0 : hd + 1, s1 = s0 == 2 ? 0 : s0 + 1;
+                const float4 a = src[s0 * fstride], b = src[s1 * fstride];
+                dst[0] = norm_obs4(a);
+                dst[fstride] = norm_obs4(b);
+                dst[2 * fstride] = norm_obs4(newest);
+            } else {
+                for (int f = 0; f < e.F; ++f) dst[f * fstride] = norm_obs4(src[((hd + 1 + f) % e.F) * fstride]);
+            }
         }
+    }
+}
+
+// out[n][:] = x / 6 - 0.5 of robot n's newest scan: the one row per tick a single-frame rollout buffer keeps
+__global__ void newest_obs_kernel(EnvView e, float* __restrict__ out) {
+    const int fstride = e.B >> 2;
+    const long long total = (long long)e.N * fstride;
+    const float4* ring = reinterpret_cast<const float4*>(e.scan_ring);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        const long long r = k / fstride;
+        const int col = (int)(k - r * fstride);
+        const int hd = e.ring_head[r];
+        reinterpret_cast<float4*>(out)[k] = norm_obs4(ring[(r * e.F + hd) * fstride + col]);
     }
 }
 
@@ -239,7 +266,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
 
     // integrate: explicit Euler with the heading at tick start
     float s = hd.x, c = hd.y;
-    uint32_t cellv = __float_as_uint(hd.z);
+    uint32_t cellv = __float_as_uint(hd.z), cellw = __float_as_uint(hd.w);
     const float d = v * kDt;
     const float nx = x + d * c;
     const float ny = y + d * s;
@@ -270,7 +297,8 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
     // the field entry of the provisional cell rides in the same round trip: it becomes the `head` entry if the
     // move is committed
     const FreeRectField rect_field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
-    const uint32_t cellv_new = rect_field(pix, piy);
+    uint32_t cellv_new, cellw_new;
+    rect_field.cell(pix, piy, &cellv_new, &cellw_new);
 
     // --- broad phase of the robot-robot collision pass (the pass itself follows the outline test): robot i
     //     can only touch robot j if its provisional centre comes within 2 x circumradius of j's old or
@@ -391,6 +419,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
         s = ns;
         c = nc;
         cellv = cellv_new;
+        cellw = cellw_new;
     }
     {
         unsigned long long turn = __ballot(involved);
@@ -423,6 +452,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
                     s = ns;
                     c = nc;
                     cellv = cellv_new;
+                    cellw = cellw_new;
                     moved = true;
                     if (raster) {
                         const int tn = *turn_n;
@@ -508,8 +538,8 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
         // head record of the new pose (wave-uniform values; only lane src keeps them)
         float rs_, rc_;
         sincos_det(pth, &rs_, &rc_);
-        const uint32_t rv_ = rect_field((int)floorf((px - e.g.x0) * e.g.inv_cell),
-                                        (int)floorf((py - e.g.y0) * e.g.inv_cell));
+        uint32_t rv_, rw_;
+        rect_field.cell((int)floorf((px - e.g.x0) * e.g.inv_cell), (int)floorf((py - e.g.y0) * e.g.inv_cell), &rv_, &rw_);
         if (lane == src) {
             ep = (int)eps;
             x = px;
@@ -518,6 +548,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
             s = rs_;
             c = rc_;
             cellv = rv_;
+            cellw = rw_;
             gx = qx;
             gy = qy;
             const float ex = qx - px, ey = qy - py;
@@ -555,7 +586,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
         e.live[n] = lv;
         e.episode[n] = ep;
         e.fresh[n] = fresh ? 1 : 0;
-        e.head[n] = make_float4(s, c, __uint_as_float(cellv), 0.0f);
+        e.head[n] = make_float4(s, c, __uint_as_float(cellv), __uint_as_float(cellw));
     }
     MRCA_STAMP(8);      // stores drained
 }
@@ -564,8 +595,9 @@ __device__ __forceinline__ void write_head(const EnvView& e, int n, float x, flo
     float s, c;
     sincos_det(th, &s, &c);
     const FreeRectField rect_field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
-    const uint32_t v0 = rect_field((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell));
-    e.head[n] = make_float4(s, c, __uint_as_float(v0), 0.0f);
+    uint32_t v0, v1;
+    rect_field.cell((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell), &v0, &v1);
+    e.head[n] = make_float4(s, c, __uint_as_float(v0), __uint_as_float(v1));
 }
 
 // head records from the poses as they are (mrca_create: before the first reset every robot sits at the origin)
@@ -684,9 +716,9 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     // slot of the newest frame so far (read by every thread BEFORE the first barrier, advanced by thread 0 after it) and
     // the fresh flag: requested last, used last
     const uint8_t fresh_byte = e.fresh[n];
-    const int obs_slot = e.obs_head[n];
-    // (The frame stack -- ppo_stage1.py:87-89: popleft / append -- is a ring: only the newest frame is written, into
-    // the slot behind the previous newest one; see materialize_obs_kernel.)
+    const int ring_slot = e.ring_head[n];
+    // (The frame stack -- ppo_stage1.py:87-89: popleft / append -- is a ring of raw scans: only the newest one is written,
+    // into the slot behind the previous newest one; see materialize_kernel.)
     // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
     // exceed the 64 a chunk holds: the preparation wave walks the nine bucket ranges 64 entries at a time and hands
     // the marching threads one chunk of <= 64 neighbours per barrier pair (see the chunk loop below)
@@ -791,7 +823,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         org.fy = (y - e.g.y0) * e.g.inv_cell;
         org.ix0 = (int)floorf(org.fx);
         org.iy0 = (int)floorf(org.fy);
-        org.v0 = __float_as_uint(hd.z);
+        org.v_lo = __float_as_uint(hd.z);
+        org.v_hi = __float_as_uint(hd.w);
         if constexpr (K == 1 || SEQ) {   // one ray at a time: the hand-tuned single-ray loop (54 VALU per jump)
 #pragma unroll
             for (int k = 0; k < K; ++k) rng[k] = grid_march_skip(field, e.g, org, dx[k], dy[k], kRangeMax);
@@ -831,28 +864,25 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     }
     if (!marches) return;
     MRCA_RSTAMP(5);     // neighbour slab tests done
-    // --- scan, normalised observation (stage_world1.py:140), newest frame of the stack (ppo_stage1.py:59-60,87-89):
-    //     every thread stores its own beams -- lane l of a wave holds beam base + l, so each store instruction of a
-    //     wave covers 256 contiguous bytes.  (Round 1 went through LDS so that a quarter of the threads could move 16
-    //     bytes each: one more barrier and an LDS round trip for the same two cache lines per wave.)
+    // --- the scan (stageros.cpp:479-516) goes into the ring slot behind the newest one -- ONE store stream: the
+    //     observation x / 6 - 0.5 (stage_world1.py:140) and the deque order (ppo_stage1.py:59-60,87-89) are the readers'
+    //     business (materialize_kernel).  Every thread stores its own beams -- lane l of a wave holds beam base + l, so
+    //     each store instruction of a wave covers 256 contiguous bytes.
     {
-        float* scan_row = e.scan + (size_t)n * e.B;
-        float* obs_row = e.obs_ring + (size_t)n * e.F * e.B;
-        const int new_slot = obs_slot + 1 == e.F ? 0 : obs_slot + 1;
+        float* ring_row = e.scan_ring + (size_t)n * e.F * e.B;
+        const int new_slot = ring_slot + 1 == e.F ? 0 : ring_slot + 1;
         const bool fresh = __builtin_amdgcn_readfirstlane((int)fresh_byte) != 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int b = tid + k * T;
             const float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
-            const float o = norm_obs(r);
-            scan_row[b] = r;
             if (fresh) {     // deque([obs] * F), ppo_stage1.py:59-60: every slot, the head stays where it is
-                for (int f = 0; f < e.F; ++f) obs_row[f * e.B + b] = o;
+                for (int f = 0; f < e.F; ++f) ring_row[f * e.B + b] = r;
             } else {
-                obs_row[new_slot * e.B + b] = o;
+                ring_row[new_slot * e.B + b] = r;
             }
         }
-        if (tid == 0 && !fresh) e.obs_head[n] = (uint8_t)new_slot;
+        if (tid == 0 && !fresh) e.ring_head[n] = (uint8_t)new_slot;
     }
     if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
         const float gx = e.goal[n * 2 + 0] - x, gy = e.goal[n * 2 + 1] - y;
@@ -1080,7 +1110,8 @@ __global__ void bw_finish_kernel(EnvView e) {
         if (!e.hold_velocity) spv = spw = 0.0f;
     }
     const FreeRectField rect_field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
-    const uint32_t cellv = rect_field((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell));
+    uint32_t cellv, cellw;
+    rect_field.cell((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell), &cellv, &cellw);
     e.pose[n * 3 + 0] = x;
     e.pose[n * 3 + 1] = y;
     e.pose[n * 3 + 2] = th;
@@ -1100,7 +1131,7 @@ __global__ void bw_finish_kernel(EnvView e) {
     e.live[n] = lv;
     e.episode[n] = ep;
     e.fresh[n] = fresh ? 1 : 0;
-    e.head[n] = make_float4(s, c, __uint_as_float(cellv), 0.0f);
+    e.head[n] = make_float4(s, c, __uint_as_float(cellv), __uint_as_float(cellw));
     // the collision hash is per tick: every robot empties the (at most two) buckets it filled, so the next tick needs
     // no 4N-entry memset; and the lidar hash's population count of the FINAL pose rides here as well
     const int world = n / e.R;
@@ -1232,7 +1263,6 @@ size_t move_lds_bytes(const EnvView& e) {
     return b;
 }
 
-// blocks of 64 threads x 4 float4 columns per pass for the frame-stack shift that rides behind the move kernel
 void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
     if (!e.big) {
         hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e, actions);
@@ -1246,12 +1276,19 @@ void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
     hipLaunchKernelGGL(bw_finish_kernel, dim3(nb), dim3(bs), 0, s, e);      // + the lidar hash's counts
 }
 
-void launch_materialize_obs(const EnvView& e, hipStream_t s) {
-    if (e.ray_count <= 0) return;
+void launch_materialize(const EnvView& e, int what, hipStream_t s) {
+    if (e.ray_count <= 0 || !(what & 3)) return;
     const long long cols = (long long)e.ray_count * (e.B >> 2);
     long long nb = (cols + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(materialize_obs_kernel, dim3((int)nb), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(materialize_kernel, dim3((int)nb), dim3(256), 0, s, e, what);
+}
+
+void launch_newest_obs(const EnvView& e, float* out, hipStream_t s) {
+    const long long cols = (long long)e.N * (e.B >> 2);
+    long long nb = (cols + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(newest_obs_kernel, dim3((int)nb), dim3(256), 0, s, e, out);
 }
 
 // the lidar hash of the current poses.  counted = 1: the populations are in bw_lcount already (a tick: bw_finish_kernel)

@@ -90,6 +90,17 @@ __device__ __forceinline__ void request_scan(float4 (&sx)[6], const float* __res
     }
 }
 
+// x / 6 - 0.5 (stage_world1.py:140) exactly as the env's own views compute it (mrca_device.h:norm_obs -- restated here
+// because this translation unit does not see the env's headers; tests/test_gpu_policy_ops.py holds the two bit-identical)
+__device__ __forceinline__ float norm_scan(float x) {
+    const float inv6 = 1.0f / 6.0f;
+    const float q = x * inv6;
+    const float r = __builtin_fmaf(-q, 6.0f, x);
+    return __builtin_fmaf(r, inv6, q) - 0.5f;
+}
+
+// RAW: `obs` holds raw ranges (the env's ring of scans); the observation is formed while the scan is staged
+template <bool RAW>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     const float* __restrict__ obs, const uint8_t* __restrict__ head, int n_robots, const float* __restrict__ w1,
     const float* __restrict__ b1,
@@ -200,7 +211,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
 #define MRCA_STAGE_SCAN(q)                                                                               \
     {                                                                                                    \
         const int idx = (q) * 64 + lane; /* float4 index: ci = idx / 128, m = idx % 128 -> x[ci][4m .. 4m+3] */ \
-        const float4 v = sx[q];                                                                          \
+        float4 v = sx[q];                                                                                \
+        if (RAW) v = make_float4(norm_scan(v.x), norm_scan(v.y), norm_scan(v.z), norm_scan(v.w));        \
         const int ci = idx >> 7, m = idx & 127;                                                          \
         float* xe = lds + kXE + ci * kXPitch + 2 * m;                                                    \
         float* xo = lds + kXO + ci * kXPitch + 2 * m + 1;                                                \
@@ -439,8 +451,8 @@ extern "C" int mrca_debug_fwd_stamps(double* out /* [8] */) {
 }
 #endif
 
-extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t n_robots, int32_t frames,
-                                   int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
+extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t raw_scans, int32_t n_robots,
+                                   int32_t frames, int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
                                    float* feat_dev, void* stream) {
     using namespace mrca_policy;
     if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !feat_dev)
@@ -460,8 +472,11 @@ extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head
         d.cus = cus;
     }
     if (!d.attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_features_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_features_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(lidar_features_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features: %zu B of dynamic LDS refused: %s", lds,
                                    hipGetErrorString(e));
@@ -471,8 +486,12 @@ extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head
     int blocks = d.cus;
     const int pairs_needed = (n_robots + 1) / 2;          // a block holds two (actor, critic) pairs
     if (blocks > pairs_needed) blocks = pairs_needed;
-    hipLaunchKernelGGL(lidar_features_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), lds,
-                       static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
+    if (raw_scans)
+        hipLaunchKernelGGL(lidar_features_kernel<true>, dim3(blocks), dim3(64 * kWavesPerBlock), lds,
+                           static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
+    else
+        hipLaunchKernelGGL(lidar_features_kernel<false>, dim3(blocks), dim3(64 * kWavesPerBlock), lds,
+                           static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features launch: %s", hipGetErrorString(e));
     return MRCA_OK;

@@ -9,18 +9,19 @@ PROFILING_LIB_PATH = os.path.join(_HERE, "libmrca_env_prof.so")
 # libmrca_env_prof.so); whichever it is, it must exist -- there is no fallback
 LIB_PATH = os.environ.get("MRCA_ENV_LIB") or os.path.join(_HERE, "libmrca_env.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+VIEW_SCAN, VIEW_OBS = 1, 2        # enum mrca_view
 
 FIELDS = [  # order = enum mrca_field
     ("pose", "f32", 3), ("speed", "f32", 2), ("speed_gt", "f32", 2), ("goal", "f32", 2), ("init_pose", "f32", 3),
     ("scan", "f32", "B"), ("obs", "f32", "FB"), ("local_goal", "f32", 2), ("reward", "f32", 1), ("done", "u8", 1),
     ("result", "u8", 1), ("first_result", "u8", 1), ("crashed", "u8", 1), ("live", "u8", 1), ("fresh", "u8", 1),
     ("t", "i32", 1), ("episode", "i32", 1), ("prev_dist", "f32", 1),
-    ("obs_ring", "f32", "FB"), ("obs_head", "u8", 1),
+    ("scan_ring", "f32", "FB"), ("ring_head", "u8", 1),
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
-           "mrca_step", "mrca_step_slice", "mrca_materialize_obs", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
+           "mrca_step", "mrca_step_slice", "mrca_materialize", "mrca_newest_obs", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
            "mrca_event_pair_overhead",
            "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
            "mrca_policy_tail"]
@@ -65,12 +66,13 @@ def load(path=None):
     lib.mrca_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_step_slice.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.mrca_check.argtypes = [C.c_void_p, C.c_void_p]
-    lib.mrca_materialize_obs.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mrca_materialize.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.mrca_newest_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_get_field.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_size_t)]
     lib.mrca_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.mrca_lidar_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+    lib.mrca_lidar_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_lidar_features_backward_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + \

@@ -3,7 +3,7 @@ scenarios under one policy (e.g. Stage-2 worlds + circle worlds).  The envs step
 stream; the per-robot fields the learner reads are concatenated into preallocated tensors after every tick."""
 import torch
 
-_FIELDS = ("obs_ring", "obs_head", "local_goal", "speed", "reward", "done", "result", "live", "fresh", "first_result")
+_FIELDS = ("scan_ring", "ring_head", "local_goal", "speed", "reward", "done", "result", "live", "fresh", "first_result")
 
 
 class ConcatEnv:
@@ -20,22 +20,31 @@ class ConcatEnv:
             ref = getattr(self.envs[0], k)
             setattr(self, k, torch.empty((self.N,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=self.device))
         self._ar = torch.arange(self.N, device=self.device)
-        self._order = torch.arange(self.obs_ring.shape[1], device=self.device).view(1, -1)
+        self._order = torch.arange(self.scan_ring.shape[1], device=self.device).view(1, -1)
+        # VecStageWorld keeps RAW ranges in its ring; a part may say otherwise (ring_is_raw = False: normalised frames)
+        raw = {bool(getattr(e, "ring_is_raw", True)) for e in self.envs}
+        if len(raw) != 1:
+            raise ValueError("ConcatEnv: the parts disagree on what their rings hold")
+        self.ring_is_raw = raw.pop()
         self._gather()
 
-    # the observation stacks are kept the way the parts keep them: as rings (see VecStageWorld.obs)
+    # the scans are kept the way the parts keep them: as rings of raw ranges (see VecStageWorld.obs).  x / 6.0 - 0.5 in
+    # torch is the correctly rounded quotient minus one half: bit-identical to the library's norm_obs
     @property
     def obs(self):
-        """f32[N,F,B] in deque order (oldest frame first), gathered from the concatenated rings."""
-        F = self.obs_ring.shape[1]
-        slots = (self.obs_head.long().view(-1, 1) + 1 + self._order) % F
-        return self.obs_ring[self._ar.view(-1, 1), slots]
+        """f32[N,F,B] x / 6 - 0.5 in deque order (oldest frame first), gathered from the concatenated rings."""
+        F = self.scan_ring.shape[1]
+        slots = (self.ring_head.long().view(-1, 1) + 1 + self._order) % F
+        stacks = self.scan_ring[self._ar.view(-1, 1), slots]
+        return stacks / 6.0 - 0.5 if self.ring_is_raw else stacks
 
     def policy_obs(self):
-        return self.obs_ring, self.obs_head
+        from .policy_ops import RingHead
+        return self.scan_ring, RingHead(self.ring_head, raw=self.ring_is_raw)
 
     def newest_frame(self):
-        return self.obs_ring[self._ar, self.obs_head.long()]
+        rows = self.scan_ring[self._ar, self.ring_head.long()]
+        return rows / 6.0 - 0.5 if self.ring_is_raw else rows
 
     def _gather(self):
         for k in _FIELDS:

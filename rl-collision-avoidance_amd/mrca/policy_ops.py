@@ -10,13 +10,35 @@ import torch
 from . import _lib
 
 
+class RingHead:
+    """The head slots of a frame ring plus what the ring holds: ``raw`` = raw lidar ranges (the env's MRCA_F_SCAN_RING;
+    the front end applies x / 6 - 0.5 while it stages) or normalised observations.  Travels opaquely through
+    ppo.generate_action / CNNPolicy.act_fused as their ``head`` argument; a plain u8 tensor means "normalised"."""
+    __slots__ = ("slots", "raw")
+
+    def __init__(self, slots, raw):
+        self.slots, self.raw = slots, bool(raw)
+
+    def __getitem__(self, idx):
+        return RingHead(self.slots[idx], self.raw)
+
+
+def unwrap_head(head):
+    """-> (u8 tensor or None, raw)"""
+    if isinstance(head, RingHead):
+        return head.slots, head.raw
+    return head, False
+
+
 def lidar_features(obs, w1, b1, w2, b2, out=None, head=None):
     """relu(conv2(relu(conv1(obs)))) of the actor and the critic tower in one launch.
     obs f32[N,3,512]; w1 f32[2,32,3,5], b1 f32[2,32], w2 f32[2,32,32,3], b2 f32[2,32] (tower-major: actor, critic)
     -> f32[2,N,4096], rows in the flatten order of [32,128].
-    ``head`` u8[N]: ``obs`` is the env's frame RING (VecStageWorld.policy_obs()) and head[n] the slot of robot n's
-    newest frame; the kernel reads the frames in deque order while staging.  None: ``obs`` is in deque order."""
+    ``head`` u8[N] or a ``RingHead``: ``obs`` is a frame RING (VecStageWorld.policy_obs()) and head[n] the slot of
+    robot n's newest frame; the kernel reads the frames in deque order while staging -- and, for a ring of RAW scans,
+    forms the observation x / 6 - 0.5 on the way.  None: ``obs`` is in deque order."""
     lib = _lib.load()
+    head, raw = unwrap_head(head)
     N, F, B = obs.shape
     for t, shape in ((obs, (N, 3, 512)), (w1, (2, 32, 3, 5)), (b1, (2, 32)), (w2, (2, 32, 32, 3)), (b2, (2, 32))):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
@@ -28,7 +50,7 @@ def lidar_features(obs, w1, b1, w2, b2, out=None, head=None):
         out = torch.empty(2, N, 4096, dtype=torch.float32, device=obs.device)
     with torch.cuda.device(obs.device):
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-        _lib.check(lib.mrca_lidar_features(obs.data_ptr(), None if head is None else head.data_ptr(), N, F, B,
+        _lib.check(lib.mrca_lidar_features(obs.data_ptr(), None if head is None else head.data_ptr(), int(raw), N, F, B,
                                            w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(),
                                            stream), "mrca_lidar_features")
     return out

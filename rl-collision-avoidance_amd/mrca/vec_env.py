@@ -74,29 +74,52 @@ class VecStageWorld:
                 t = flat.view(self.N)
             else:
                 t = flat.view(self.N, shape)
-            setattr(self, "_obs" if name == "obs" else name, t)
-        self._obs_current = False
-        self._ar = torch.arange(self.N, device=self.device)
+            setattr(self, "_" + name if name in ("obs", "scan") else name, t)
+        self._views_current = 0          # bits of _lib.VIEW_*: which of MRCA_F_SCAN / MRCA_F_OBS follow the ring right now
 
-    # ------------------------------------------------------------------ the observation stack
+    # ------------------------------------------------------------------ the scans and the observation stack
+    # The env keeps the last F scans of every robot as a RING of raw ranges (``scan_ring`` + ``ring_head``: a tick writes
+    # ONE row per robot -- no shift, no second normalised copy) and makes the two reference-shaped views when somebody
+    # reads them after a tick (mrca_materialize: one kernel on the current stream).  The fused policy path reads the ring.
+    def _view(self, bit, what):
+        if not self._views_current & bit:
+            _lib.check(self.lib.mrca_materialize(self._h, bit, self._stream()), "mrca_materialize")
+            self._views_current |= bit
+        return what
+
+    @property
+    def scan(self):
+        """f32[N,B] the newest scan of every robot (base_scan ranges, stageros.cpp:479-516)."""
+        return self._view(_lib.VIEW_SCAN, self._scan)
+
     @property
     def obs(self):
-        """f32[N,F,B] the frame stacks in deque order (oldest frame first; what ``CNNPolicy.forward`` eats,
-        ppo_stage1.py:59-60,87-89).  The env keeps the stacks as a RING (``obs_ring`` + ``obs_head``: a tick writes one
-        frame per robot instead of shifting three) and brings this copy up to date when it is read after a tick
-        (mrca_materialize_obs: one copy kernel on the current stream).  The fused policy path reads the ring itself."""
-        if not self._obs_current:
-            _lib.check(self.lib.mrca_materialize_obs(self._h, self._stream()), "mrca_materialize_obs")
-            self._obs_current = True
-        return self._obs
+        """f32[N,F,B] the observation stacks x / 6 - 0.5 in deque order (oldest frame first; what ``CNNPolicy.forward``
+        eats: stage_world1.py:140, ppo_stage1.py:59-60,87-89)."""
+        return self._view(_lib.VIEW_OBS, self._obs)
+
+    @property
+    def _obs_current(self):
+        return bool(self._views_current)
+
+    @_obs_current.setter
+    def _obs_current(self, value):      # (a tick replayed as a hipGraph advances the ring behind the binding's back)
+        if not value:
+            self._views_current = 0
 
     def policy_obs(self):
-        """-> (stacks, heads) for consumers that understand the ring: (obs_ring f32[N,F,B], obs_head u8[N])."""
-        return self.obs_ring, self.obs_head
+        """-> (ring, heads) for consumers that understand the ring: (scan_ring f32[N,F,B] of RAW ranges, RingHead)."""
+        from .policy_ops import RingHead
+        return self.scan_ring, RingHead(self.ring_head, raw=True)
 
-    def newest_frame(self):
-        """f32[N,B]: every robot's newest normalised scan (the frame a tick appended), gathered from the ring."""
-        return self.obs_ring[self._ar, self.obs_head.long()]
+    def newest_frame(self, out=None):
+        """f32[N,B]: every robot's newest observation row x / 6 - 0.5 (the frame a tick appended), from the ring."""
+        if out is None:
+            out = torch.empty(self.N, self.B, dtype=torch.float32, device=self.device)
+        elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.N * self.B):
+            raise ValueError("newest_frame: out must be a contiguous cuda float32 tensor of N x B elements")
+        _lib.check(self.lib.mrca_newest_obs(self._h, out.data_ptr(), self._stream()), "mrca_newest_obs")
+        return out
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -129,7 +152,7 @@ class VecStageWorld:
         _lib.check(self.lib.mrca_reset(self._h, self._ptr(mask, torch.uint8, self.N),
                                        self._ptr(poses, torch.float32, self.N * 3),
                                        self._ptr(goals, torch.float32, self.N * 2), self._stream()), "mrca_reset")
-        self._obs_current = False
+        self._views_current = 0
         return self
 
     def step(self, actions, ray_slice=None):
@@ -143,7 +166,7 @@ class VecStageWorld:
         else:
             _lib.check(self.lib.mrca_step_slice(self._h, a, int(ray_slice[0]), int(ray_slice[1]), self._stream()),
                        "mrca_step_slice")
-        self._obs_current = False
+        self._views_current = 0
         return self
 
     def check(self):

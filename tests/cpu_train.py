@@ -36,8 +36,9 @@ class CpuEnv:
             setattr(self, k, torch.from_numpy(getattr(self.env, k)))
         # the VecStageWorld surface keeps the stacks as a ring; the oracle's deque-ordered stacks ARE a ring whose newest
         # frame sits in the last slot
-        self.obs_ring = self.obs
-        self.obs_head = torch.full((self.N,), sc.frames - 1, dtype=torch.uint8)
+        self.scan_ring = self.obs                 # (normalised frames, not raw ranges:)
+        self.ring_is_raw = False
+        self.ring_head = torch.full((self.N,), sc.frames - 1, dtype=torch.uint8)
 
     def reset(self, mask=None, poses=None, goals=None):
         self.env.reset(None if mask is None else mask.numpy(), None if poses is None else poses.numpy(),

@@ -41,7 +41,7 @@ struct EmulEnv {
 
 // the free-rectangle field of a map, built once per distinct map (keyed by a hash of the bitmap)
 struct CachedField {
-    std::vector<uint32_t> f;
+    std::vector<uint16_t> f;
     int pitch = 0;
 };
 static const CachedField& field_of(const EmulEnv* e) {
@@ -280,13 +280,13 @@ void emul_step(const EmulEnv* e, const float* actions) {
     emul_raycast(e, 0);
 }
 
-// the product's free-rectangle field, un-padded [height][width], for the soundness test
-int emul_free_rect_field(const EmulEnv* e, uint32_t* out, int cap) {
+// the product's quadrant free-rectangle field, un-padded [height][width][4] uint16, for the soundness test
+int emul_free_rect_field(const EmulEnv* e, uint16_t* out, int cap) {
     const CachedField& cf = field_of(e);
-    if (e->width * e->height > cap) return -1;
+    if (e->width * e->height * 4 > cap) return -1;
     for (int y = 0; y < e->height; ++y)
-        memcpy(out + (size_t)y * e->width, cf.f.data() + (size_t)(y + kFieldPadY) * cf.pitch + kFieldPadX,
-               (size_t)e->width * 4);
+        memcpy(out + (size_t)y * e->width * 4, cf.f.data() + ((size_t)(y + kFieldPadY) * cf.pitch + kFieldPadX) * 4,
+               (size_t)e->width * 8);
     return 0;
 }
 

@@ -31,7 +31,7 @@ def test_header_symbols_exported(built_lib):
 
 
 def test_abi_version(built_lib):
-    assert built_lib.mrca_abi_version() == 3
+    assert built_lib.mrca_abi_version() == 4
 
 
 def _cfg(sc):
@@ -52,8 +52,8 @@ def test_arena_bytes_and_layout(built_lib):
     n = C.c_size_t()
     assert built_lib.mrca_arena_bytes(C.byref(cfg), C.byref(n)) == 0
     N = sc.num_robots
-    need = N * 512 * 4 * (1 + 3 + 3)  # scan + the frame ring + its deque-ordered copy
-    assert need < n.value < need + 2 * 1024 * 1024
+    need = N * 512 * 4 * (1 + 3 + 3)  # the ring of raw scans + the two materialised views (newest scan, normalised stack)
+    assert need < n.value < need + 3 * 1024 * 1024      # + the quadrant free-rectangle field: 8 B per cell of the map
     assert n.value % 256 == 0
 
 

@@ -122,7 +122,9 @@ def test_the_references_own_callbacks_digest_the_bridge_messages():
     import make_golden_env as G
     G.install_stubs()
     sys.path.insert(0, REF)
+    sys.modules.pop("stage_world1", None)     # (an earlier spmd run of this session may have left the drop-in of that name)
     import stage_world1
+    assert os.path.dirname(os.path.abspath(stage_world1.__file__)) == os.path.abspath(REF)
     bridge, br, backend = make()
     rng = np.random.default_rng(0)
     worlds = [G.make(stage_world1.StageWorld, r) for r in range(24)]

@@ -147,9 +147,10 @@ def test_bf16_inference_is_bounded_against_fp32():
 
 
 def test_front_end_reads_the_envs_frame_ring_in_place(pol):
-    """The env keeps the observation stacks as a ring (one frame written per tick); the kernel must see exactly the
-    stacks the deque-ordered copy (env.obs, mrca_materialize_obs) holds -- bit for bit, at every phase of the ring and
-    across restarts (a restarted robot has all its slots rewritten)."""
+    """The env keeps the last three scans of every robot as a ring of RAW ranges (one row written per tick); the kernel
+    forms x / 6 - 0.5 and the deque order while it stages and must see exactly the stacks the materialised copy
+    (env.obs, mrca_materialize) holds -- bit for bit, at every phase of the ring and across restarts (a restarted robot
+    has all its slots rewritten).  The rollout buffer's row (mrca_newest_obs) and the newest-scan view likewise."""
     from mrca import policy_ops
     from mrca.vec_env import VecStageWorld
     from util import S
@@ -162,11 +163,19 @@ def test_front_end_reads_the_envs_frame_ring_in_place(pol):
         a = torch.stack([torch.rand(env.N, generator=g, device="cuda"), torch.rand(env.N, generator=g, device="cuda") * 2 - 1], 1)
         env.step(a.contiguous())
         ring, head = env.policy_obs()
-        seen_heads |= set(head.unique().tolist())
+        assert head.raw and ring.data_ptr() == env.scan_ring.data_ptr()
+        seen_heads |= set(head.slots.unique().tolist())
         via_ring = policy_ops.lidar_features(ring, rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head)
         via_copy = policy_ops.lidar_features(env.obs, rc["w1"], rc["b1"], rc["w2"], rc["b2"])
         assert torch.equal(via_ring, via_copy), k
         assert torch.equal(env.newest_frame(), env.obs[:, -1])
+        # the views against the ring itself: newest scan, and torch's own x / 6 - 0.5 (the IEEE quotient minus one half)
+        ar = torch.arange(env.N, device="cuda")
+        assert torch.equal(env.scan, ring[ar, head.slots.long()])
+        assert torch.equal(env.obs[:, -1], env.scan / 6.0 - 0.5)
+        # a ring of NORMALISED frames (what a caller of ABI 3 hands over) still works: plain u8 heads
+        via_norm = policy_ops.lidar_features((ring / 6.0 - 0.5).contiguous(), rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head.slots)
+        assert torch.equal(via_norm, via_copy), k
         m0, v0 = pol.mean_value_fused(ring, env.local_goal, env.speed, head=head)
         m1, v1 = pol.mean_value_fused(env.obs, env.local_goal, env.speed)
         assert torch.equal(m0, m1) and torch.equal(v0, v1)

@@ -41,13 +41,21 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
     anchors = [i for i, l in enumerate(device_asm)
                if re.match(r"\s+v_(div_scale|div_fmas|div_fixup|rsq|sqrt|rcp|rcp_iflag)_f32", l)]
     assert fused and anchors
-    # norm_obs: v_mul x, RN(1/6); v_fmamk .., -6.0, ..; v_fmac .., RN(1/6), ..   (explicit __builtin_fmaf)
-    norm = [i for i in fused if "0xc0c00000" in device_asm[i] or "0x3e2aaaab" in device_asm[i]]
-    # two per beam of every raycast_kernel variant: <1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential>,
-    # big worlds <1 | 2 | 4>
-    assert len(norm) == 2 * ((1 + 2 + 2 + 4 + 4) + (1 + 2 + 4)), len(norm)
-    for i in norm:
-        assert any("0x3e2aaaab" in device_asm[j] and "v_mul_f32" in device_asm[j] for j in range(i - 8, i)), i
+    # norm_obs (x / 6 - 0.5, two explicit __builtin_fmaf): since ABI 4 only the READERS of the scan ring form it --
+    # materialize_kernel and newest_obs_kernel, four floats at a time, which the compiler packs (v_pk_mul / v_pk_fma with
+    # RN(1/6) and 6.0 in scalar registers).  Every fused operation inside those two kernels is one of these; no ray-cast
+    # variant holds any (it stores raw ranges).
+    starts = [(i, m.group(1)) for i, l in enumerate(device_asm) for m in [re.match(r"(_Z\w+):\s*(;.*)?$", l)] if m]
+    ends = [i for i, l in enumerate(device_asm) if re.match(r"\.Lfunc_end\d+:", l)]
+
+    def owner(i):
+        k = bisect.bisect_right([a for a, _ in starts], i) - 1
+        return starts[k][1] if k >= 0 and any(starts[k][0] < e and i < e for e in ends) else ""
+    norm = [i for i in fused if "materialize_kernel" in owner(i) or "newest_obs_kernel" in owner(i)]
+    assert norm and all(re.match(r"\s+v_(pk_fma|fma|fmac|fmamk|fmaak)_f32", device_asm[i]) for i in norm), len(norm)
+    assert {o for o in map(owner, norm)} == {o for _, o in starts if "materialize_kernel" in o or "newest_obs_kernel" in o}
+    assert not any("raycast_kernel" in owner(i) and ("0xc0c00000" in device_asm[i] or "0x3e2aaaab" in device_asm[i])
+                   for i in fused)
     fused = [i for i in fused if i not in set(norm)]
     for i in fused:
         k = bisect.bisect_left(anchors, i)
@@ -58,9 +66,9 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
 def test_register_budget_and_no_scratch(device_asm):
     text = "\n".join(device_asm)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
-    # move, materialize_obs, head_init, reset, gae, 7 x bw_* (integrate, collide, finish, lidar count / scan x 2 / fill),
-    # raycast<1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential> + big-world <1|2|4>
-    assert len(kernels) == 20, [k for k, _ in kernels]
+    # move, materialize, newest_obs, head_init, reset, gae, 7 x bw_* (integrate, collide, finish, lidar count / scan x 2 /
+    # fill), raycast<1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential> + big-world <1|2|4>
+    assert len(kernels) == 21, [k for k, _ in kernels]
     for name, body in kernels:
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))

@@ -62,24 +62,32 @@ def test_skipping_march_equals_plain_walk_and_oracle(name):
 
 
 def test_free_rectangle_field_is_sound():
-    """Every rectangle stored for an empty cell must contain no occupied cell (the march's only
-    assumption about the field), and occupied cells must be flagged."""
+    """Every rectangle stored for an empty cell -- four per cell, one per quadrant of the direction of travel, the cell
+    in the corner the ray enters through -- must contain no occupied cell (the march's only assumption about the field),
+    and occupied cells must be flagged in all four."""
     for sc in (S.stage1(1, 2), S.stage2(1), S.circle(1)):
         e = U.EmulEnv(sc)
         g = sc.grid
-        buf = np.zeros(g.width * g.height, np.uint32)
+        buf = np.zeros(g.width * g.height * 4, np.uint16)
         assert e.lib.emul_free_rect_field(C.byref(e._st), C.c_void_p(buf.ctypes.data), buf.size) == 0
-        f = buf.reshape(g.height, g.width)
+        f = buf.reshape(g.height, g.width, 4)
         occ = g.dense()
-        assert ((f == 0xFFFFFFFF) == occ).all()
+        assert ((f == 0xFFFF).all(axis=2) == occ).all() and ((f == 0xFFFF).any(axis=2) == occ).all()
         sat = np.pad(occ.astype(np.int64).cumsum(0).cumsum(1), ((1, 0), (1, 0)))
         ys, xs = np.nonzero(~occ)
-        v = f[ys, xs].astype(np.int64)
-        assert (v & 0xFF).max() <= 127 and (v >> 24).max() <= 127
-        x0 = np.clip(xs - (v & 255), 0, g.width - 1)
-        x1 = np.clip(xs + ((v >> 8) & 255), 0, g.width - 1)
-        y0 = np.clip(ys - ((v >> 16) & 255), 0, g.height - 1)
-        y1 = np.clip(ys + (v >> 24), 0, g.height - 1)
-        cnt = sat[y1 + 1, x1 + 1] - sat[y0, x1 + 1] - sat[y1 + 1, x0] + sat[y0, x0]
-        assert (cnt == 0).all()
-        assert ((v & 255) + ((v >> 8) & 255)).mean() > 4    # the rectangles are not trivial
+        total = 0.0
+        for q in range(4):
+            sx, sy = (1 if q & 1 else -1), (1 if q & 2 else -1)
+            v = f[ys, xs, q].astype(np.int64)
+            ex, ey = v & 255, v >> 8
+            assert ex.max() <= 254 and ey.max() <= 254
+            xa, xb = xs, xs + sx * ex
+            ya, yb = ys, ys + sy * ey
+            x0 = np.clip(np.minimum(xa, xb), 0, g.width - 1)
+            x1 = np.clip(np.maximum(xa, xb), 0, g.width - 1)
+            y0 = np.clip(np.minimum(ya, yb), 0, g.height - 1)
+            y1 = np.clip(np.maximum(ya, yb), 0, g.height - 1)
+            cnt = sat[y1 + 1, x1 + 1] - sat[y0, x1 + 1] - sat[y1 + 1, x0] + sat[y0, x0]
+            assert (cnt == 0).all(), q
+            total += (ex + ey).mean()
+        assert total / 4 > 4                             # the rectangles are not trivial
