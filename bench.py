@@ -33,12 +33,13 @@ import torch  # noqa: E402
 
 SIDE_FIGURE_TIMEOUT_S = 240
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Algorithmic HBM bytes per agent-step.  Since round 3 the frame stack is a ring: a tick writes the scan and
-# ONE observation frame per robot and ~0.1 kB of state -- no shift (rounds 1-2: + 4096 read + 4096 written, B_env_stack).
-B_ENV_STRICT = 4 * 512 + 92                    # SURVEY 8(d) B_env: ONE 2 kB row (scan or frame) + 92 B of state = 2140
-BYTES_PER_AGENT_STEP = 2 * 4 * 512 + 92        # what the tick really owes: scan + newest frame + state = 4188, per TICK
-RAY_BYTES_PER_AGENT_STEP = 2 * 4 * 512 + 48    # per LAUNCH: scan + newest obs frame written, pose / head / goal / flag read, local goal
+# Algorithmic HBM bytes per agent-step.  Since round 4 (ABI 4) the frame history is a ring of RAW scans: a tick
+# writes ONE 2 kB row per robot and ~0.1 kB of state -- SURVEY's strict B_env.  (Round 3 stored every beam twice, scan +
+# normalised frame: 4188 B; rounds 1-2 shifted the stack as well: B_env_stack = 10 332 B.)
+B_ENV_STRICT = 4 * 512 + 92                    # SURVEY 8(d) B_env: ONE 2 kB row + 92 B of state = 2140
+RAY_BYTES_PER_AGENT_STEP = 4 * 512 + 48        # per LAUNCH: the scan row written; pose / head / goal / flags read, local goal
 MOVE_BYTES_PER_AGENT_STEP = 140                # per LAUNCH: pose, speeds, goal, counters, flags, head record read + written
+BYTES_PER_AGENT_STEP = RAY_BYTES_PER_AGENT_STEP + MOVE_BYTES_PER_AGENT_STEP    # both launches of the tick = 2236
 
 
 def code_only(src):
@@ -439,9 +440,10 @@ def main():
                                   "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
                                   "frac_at_survey_B_env_2140": (tick_achieved * B_ENV_STRICT / BYTES_PER_AGENT_STEP / HBM_PEAK_GBS)
                                   if tick_achieved else None,
-                                  "note": "both launches of the tick (move, ray cast) against scan + newest frame + state "
-                                          "= 4188 B per agent-step; the frame stack is a ring since round 3 (no shift: "
-                                          "rounds 1-2 owed SURVEY's B_env_stack = 10 332 B)"},
+                                  "note": "both launches of the tick (move, ray cast) against ONE scan row + state = 2236 B per "
+                                          "agent-step (SURVEY's strict B_env = 2140): since ABI 4 the frame history is a ring of "
+                                          "raw scans, the observation x/6 - 0.5 is formed by its readers (round 3: 4188 B, every "
+                                          "beam stored twice; rounds 1-2: 10 332 B with the shift)"},
                          "move_launch": {"achieved": move_achieved,
                                          "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
