@@ -312,8 +312,9 @@ def main():
         for k in range(args.warmup):
             step_fn(k)
         barrier()
-        # HIP events around the kernels of every 8th step of the timed region (three event records cost a tick ~10 us when
-        # taken every step -- round 3 tried that for short regions and the driver's 20-step run lost 20 % of `value` to it)
+        # begin / end stamps on the two launches of every 8th step of the timed region (stamped launches go through
+        # hipExtLaunchKernel with four events: a few us of host time each -- taken on every step they cost a 20-step run a
+        # fifth of `value`, round 3 measured)
         every = 8
         env.enable_timing(every)
         t0 = time.perf_counter()
@@ -325,7 +326,7 @@ def main():
         env.enable_timing(False)
     if step_fn is None:
         step_fn = lambda k: env.step(pool[k % len(pool)])  # noqa: E731  (the eager passes below)
-    kernel_timing_note = "HIP events around the kernels of every 8th step of the timed region"
+    kernel_timing_note = "begin / end stamps of the launches (hipExtLaunchKernel) of every 8th step of the timed region"
     if 0 < launches < 16 and args.mode == "env":
         # a short region (the driver's 20 steps) leaves a handful of samples: add 64 more ticks with the events on EVERY
         # tick, after the timed region -- `value` does not see them, the kernel averages do
@@ -336,8 +337,8 @@ def main():
         mv2, ray2, l2 = env.read_timing()
         env.enable_timing(False)
         mv_ms, ray_ms, launches = mv_ms + mv2, ray_ms + ray2, launches + l2
-        kernel_timing_note = ("HIP events around the kernels of every 8th step of the timed region + of each of 64 further "
-                              "ticks right after it (the region alone is too short for an average)")
+        kernel_timing_note = ("begin / end stamps of the launches (hipExtLaunchKernel) of every 8th step of the timed region + "
+                              "of each of 64 further ticks right after it (the region alone is too short for an average)")
     if launches == 0:
         # the tick was replayed as a hipGraph (the library's event records are not part of a captured tick): time the
         # two env kernels in a short eager pass AFTER the timed region instead
@@ -347,7 +348,8 @@ def main():
         torch.cuda.synchronize()
         mv_ms, ray_ms, launches = env.read_timing()
         env.enable_timing(False)
-        kernel_timing_note = "HIP events around the env kernels in a separate eager pass of 64 ticks after the timed region"
+        kernel_timing_note = ("begin / end stamps of the env kernels' launches (hipExtLaunchKernel) in a separate eager pass of "
+                              "64 ticks after the timed region")
 
     # side figure (single GPU, env mode only, outside the timed region above): the same world driven by the
     # fp32 policy instead of the action pool -- SURVEY 8d (ii).  `--mode rollout|train` time these properly.
@@ -404,12 +406,10 @@ def main():
             _emit()
 
     def _emit():
-        # every (event, kernel, event) figure contains one marker's processing time: measured with empty pairs, subtracted
-        ev_us = env.event_pair_overhead(200)
-        ray_raw_us = (ray_ms / launches) * 1e3 if launches else float("nan")
-        mv_raw_us = (mv_ms / launches) * 1e3 if launches else float("nan")
-        ray_avg_s = max(ray_raw_us - ev_us, 0.0) * 1e-6
-        mv_avg_s = max(mv_raw_us - ev_us, 0.0) * 1e-6
+        # the launches' own begin / end stamps (hipExtLaunchKernel start / stop events: what rocprofv3 reports); rounds 1-3
+        # recorded events AROUND each launch, which read ~2.5 us longer per kernel -- their sum exceeded ms_per_step
+        ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
+        mv_avg_s = (mv_ms / launches) * 1e-3 if launches else float("nan")
         traffic, traffic_note = pmc_traffic(N, args.scenario)
         achieved = RAY_BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
         tick_achieved = BYTES_PER_AGENT_STEP * N / (ray_avg_s + mv_avg_s) / 1e9 if launches else None
@@ -435,7 +435,6 @@ def main():
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "bytes_per_agent_step": RAY_BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
-                         "kernel_avg_us_raw_event_pair": ray_raw_us, "event_overhead_us": ev_us,
                          "tick": {"achieved": tick_achieved, "frac": tick_achieved / HBM_PEAK_GBS if tick_achieved else None,
                                   "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
                                   "frac_at_survey_B_env_2140": (tick_achieved * B_ENV_STRICT / BYTES_PER_AGENT_STEP / HBM_PEAK_GBS)
@@ -448,12 +447,10 @@ def main():
                                          "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
                          "move_kernel_avg_us": mv_avg_s * 1e6 if launches else None,
-                         "move_kernel_avg_us_raw_event_pair": mv_raw_us if launches else None,
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
-                         "note": "HBM is the nominal roof (SURVEY 8d); the launch is ~12 us that exist without any march (ramp, tail, two "
-                                 "rounds of request -> prepare -> barrier -> store) + ~13 us of exact march and slab tests bound by VALU "
-                                 "issue at eight waves per SIMD (608 VALU instructions per wave = 63 % of the whole launch's issue "
-                                 "slots); not traffic (stamped and varied in round 3: DESIGN.md 5.2)"},
+                         "note": "HBM is the nominal roof (SURVEY 8d); the launch is bound by VALU issue at eight waves per SIMD: "
+                                 "553 VALU instructions per wave (608 in round 3), two residency rounds of 2048 workgroups whose "
+                                 "lifetime is what eight waves per SIMD x ~550 instructions x 4 cycles come to; DESIGN.md 5.2"},
         }
         if args.mode == "rollout":
             # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2

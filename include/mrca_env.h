@@ -176,6 +176,18 @@ int mrca_materialize(mrca_env* env, int32_t what, void* stream);
  * stores single frames keeps (ppo_stage1.py:87-89 appends exactly this row to the deque). */
 int mrca_newest_obs(mrca_env* env, float* out_dev, void* stream);
 
+/* out_dev[i] := in_dev[i] / 6 - 0.5 (stage_world1.py:140) for `count` floats, rounded exactly as MRCA_F_OBS is -- for a caller
+ * that holds rows of MRCA_F_SCAN_RING (several envs concatenated, a slice of a sharded world) and wants observations.
+ * count % 4 == 0, both buffers 16-byte aligned; in place allowed. */
+int mrca_normalize_scans(const float* in_dev, float* out_dev, size_t count, void* stream);
+
+/* get_laser_observation for a StageWorld constructed with beam_num != the lidar's sample count (stage_world1.py:126-139:
+ * the sparse scan is a left half picked ascending and a right half picked descending from the raw one):
+ * out_dev f32[N,F,beam_num] := x / 6 - 0.5 of beams index_dev[0..beam_num) of every frame of the stack, deque order.
+ * index_dev i32[beam_num], each in [0, beams): the caller's table (the reference advances a float64 index by
+ * raw / beam_num per pick and truncates; mrca/vec_env.py:sparse_beam_index restates that loop). */
+int mrca_sparse_obs(mrca_env* env, const int32_t* index_dev, int32_t beam_num, float* out_dev, void* stream);
+
 /* Synchronises `stream` and reports (then clears) the env's sticky device-side status word: MRCA_OK, or MRCA_ERR_HIP with
  * mrca_last_error() saying what went wrong on the device since the last check.  Today one condition: the ordered
  * collision pass of a world with more than 64 robots ran out of its (very long) bounded wait and left a robot
@@ -196,8 +208,9 @@ int mrca_gae(const float* rewards_dev, const float* values_dev, const float* las
 /* Diagnostics */
 int mrca_abi_version(void);
 const char* mrca_last_error(void);
-/* Per-kernel timing with HIP events recorded on the stream each mrca_step launches on
- * (event, move kernel, event, ray-cast kernel, event), up to 1024 steps between reads.
+/* Per-kernel timing: the move launch and the ray-cast launch of a timed step are stamped with their own BEGIN and END
+ * (hipExtLaunchKernel's start / stop events: the dispatch's timestamps, what rocprofv3 reports -- event records AROUND a
+ * launch read ~2.5 us longer per kernel), up to 1024 steps between reads.
  * mrca_read_timing synchronises on the last recorded event, returns the summed durations of the
  * recorded launches in milliseconds and clears the ring. */
 int mrca_enable_timing(mrca_env* env, int32_t on); /* on = n > 0: time every n-th step; 0: off */
@@ -257,6 +270,21 @@ int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t
                                  const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* feat_dev,
                                  const float* gfeat_act_dev, const float* gfeat_crt_dev, float* dw1_dev, float* db1_dev,
                                  float* dw2_dev, float* db2_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
+
+/* The loss tail of the PPO update, values AND gradients, in one launch (model/ppo.py:172-185 / :238-251: importance ratio,
+ * clipped surrogate, value loss x value_coef, entropy bonus; log-density of model/utils.py:90-97) -- what PyTorch runs as
+ * ~30 element-wise launches forward and as many backward per minibatch.
+ *   mean_dev f32[n,2]  value_dev f32[n]  logstd_dev f32[2]      the network's outputs for the minibatch
+ *   action_dev f32[n,2]  old_logprob_dev f32[n]  adv_dev f32[n]  target_dev f32[n]      the minibatch's stored rows
+ *   out_dev f32[8]:  loss, policy loss, value loss, entropy, k3 estimate of KL(old || new), dloss/dlogstd[0], [1], 0
+ *   gmean_dev f32[n,2] = dloss/dmean,  gvalue_dev f32[n] = dloss/dvalue      (autograd's tie rules for min / clamp)
+ *   scratch_dev: caller-owned, at least mrca_ppo_loss_scratch() bytes, ZEROED ONCE before its first use (a launch leaves
+ *   it ready for the next); sums are combined in a fixed order: bit-identical from run to run. */
+int mrca_ppo_loss_scratch(size_t* bytes_out);
+int mrca_ppo_loss(const float* mean_dev, const float* value_dev, const float* logstd_dev, const float* action_dev,
+                  const float* old_logprob_dev, const float* adv_dev, const float* target_dev, int32_t n, float clip_value,
+                  float value_coef, float coeff_entropy, float* out_dev, float* gmean_dev, float* gvalue_dev,
+                  void* scratch_dev, size_t scratch_bytes, void* stream);
 
 #ifdef MRCA_PROFILING
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product

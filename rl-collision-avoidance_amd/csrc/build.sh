@@ -24,7 +24,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC
 pids=()
 obj="$(mktemp -d)"
 trap 'rm -rf "${obj}"' EXIT
-for src in mrca_kernels mrca_abi mrca_policy mrca_policy_bwd mrca_policy_tail; do
+for src in mrca_kernels mrca_abi mrca_policy mrca_policy_bwd mrca_policy_tail mrca_ppo_loss; do
     per=()
     [[ "${src}" == "mrca_policy" ]] && per=(-mllvm --amdgpu-mfma-vgpr-form)
     "${HIPCC}" "${FLAGS[@]}" "${per[@]}" -c "${here}/${src}.hip" -o "${obj}/${src}.o" "$@" &

@@ -50,7 +50,7 @@ struct Layout {
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
     size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield, off_head;
     // big worlds (robots_per_world > 64) only
-    size_t off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted, off_bw_lblock, off_bw_lcursor;
+    size_t off_bw_ticket, off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted, off_bw_lblock, off_bw_lcursor;
     size_t off_status;
     int32_t bw_cmask, bw_lmask;
     size_t total;
@@ -158,6 +158,7 @@ void make_layout(const mrca_config* c, Layout* L) {
         while (ml < 2 * N) ml <<= 1;
         L->bw_cmask = (int32_t)(mc - 1);
         L->bw_lmask = (int32_t)(ml - 1);
+        L->off_bw_ticket = take(4);
         L->off_bw_prov = take(N * 2 * sizeof(float4));
         L->off_bw_state = take(N * 4);
         L->off_bw_chead = take(mc * 4);
@@ -215,7 +216,7 @@ struct mrca_env {
     // timing
     int timing = 0;      // 0 off, n > 0: record events on every n-th step
     int step_count = 0;
-    std::vector<hipEvent_t> ev;  // 3 per recorded step: before move, before ray, after ray
+    std::vector<hipEvent_t> ev;  // 4 per recorded step: begin / end of the move launch, begin / end of the ray cast
     int ev_used = 0;
 };
 
@@ -378,6 +379,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.goal_table = reinterpret_cast<const float*>(a + L.off_goal_table);
     v.beam_cos = reinterpret_cast<const float*>(a + L.off_beam_cos);
     v.beam_sin = reinterpret_cast<const float*>(a + L.off_beam_sin);
+    v.beam_step = mrca::kPi / (float)(B - 1);
+    v.beam_inv_step = (float)(B - 1) / mrca::kPi;
     v.map_bits = reinterpret_cast<const uint32_t*>(a + L.off_map);
     v.free_rect = reinterpret_cast<const uint16_t*>(a + L.off_free_rect);
     v.free_rect_pitch = free_rect_pitch;
@@ -385,6 +388,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.head = reinterpret_cast<float4*>(a + L.off_head);
     v.big = R > 64 ? 1 : 0;
     if (v.big) {
+        v.bw_ticket = reinterpret_cast<uint32_t*>(a + L.off_bw_ticket);
         v.bw_prov = reinterpret_cast<float4*>(a + L.off_bw_prov);
         v.bw_state = reinterpret_cast<int32_t*>(a + L.off_bw_state);
         v.bw_chead = reinterpret_cast<int32_t*>(a + L.off_bw_chead);
@@ -505,20 +509,17 @@ static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int
     DeviceGuard guard(env->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool rec = env->timing > 0 && (env->step_count++ % env->timing) == 0 &&
-                     env->ev_used + 3 <= (int)env->ev.size();
+                     env->ev_used + 4 <= (int)env->ev.size();
     mrca::EnvView v = env->view;
     v.ray_first = first;      // the robots whose lidar outputs (scan, frame stack, local goal) this call produces
     v.ray_count = count;
-    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 0], s));
-    mrca::launch_move(v, actions_dev, s);
+    // timing: the launches' own begin / end stamps (hipExtLaunchKernel), not event records around them
+    hipEvent_t* ev = rec ? &env->ev[env->ev_used] : nullptr;
+    mrca::launch_move(v, actions_dev, s, rec ? ev[0] : nullptr, rec ? ev[1] : nullptr);
     mrca::launch_lidar_grid(v, /*counted=*/1, s);
-    if (rec) HIP_TRY(hipEventRecord(env->ev[env->ev_used + 1], s));
-    mrca::launch_raycast(v, /*only_fresh=*/0, s);
-    if (!env->cfg.lazy_obs) mrca::launch_materialize(v, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, s);   // (inside the ray cast's event pair: part of the tick then)
-    if (rec) {
-        HIP_TRY(hipEventRecord(env->ev[env->ev_used + 2], s));
-        env->ev_used += 3;
-    }
+    mrca::launch_raycast(v, /*only_fresh=*/0, s, rec ? ev[2] : nullptr, rec ? ev[3] : nullptr);
+    if (!env->cfg.lazy_obs) mrca::launch_materialize(v, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, s);
+    if (rec) env->ev_used += 4;
     HIP_TRY(hipGetLastError());
     return MRCA_OK;
 }
@@ -542,9 +543,29 @@ int mrca_check(mrca_env* env, void* stream) {
     HIP_TRY(hipMemsetAsync(env->view.status, 0, sizeof(bits), s));
     if (bits & mrca::kStatusCollideUndecided)
         return fail(MRCA_ERR_HIP, "collision pass of a world with more than 64 robots gave up waiting for a lower-indexed "
-                                  "robot (workgroups not dispatched in index order?): at least one robot was left "
-                                  "undecided since the last check; the env's state is not to be trusted");
+                                  "robot (its bounded wait ran out): at least one robot was left undecided since the last "
+                                  "check; the env's state is not to be trusted");
     return fail(MRCA_ERR_HIP, "device status word 0x%x", bits);
+}
+
+int mrca_normalize_scans(const float* in_dev, float* out_dev, size_t count, void* stream) {
+    if (!in_dev || !out_dev) return fail(MRCA_ERR_INVALID, "mrca_normalize_scans: NULL pointer");
+    if (count % 4 || reinterpret_cast<uintptr_t>(in_dev) % 16 || reinterpret_cast<uintptr_t>(out_dev) % 16)
+        return fail(MRCA_ERR_INVALID, "mrca_normalize_scans: count must be a multiple of 4 and the buffers 16-byte aligned");
+    DeviceGuard guard(mrca::device_of(in_dev));
+    mrca::launch_normalize(in_dev, out_dev, (long long)count, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
+int mrca_sparse_obs(mrca_env* env, const int32_t* index_dev, int32_t beam_num, float* out_dev, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (!index_dev || !out_dev) return fail(MRCA_ERR_INVALID, "mrca_sparse_obs: NULL pointer");
+    if (beam_num < 1 || beam_num > env->view.B) return fail(MRCA_ERR_INVALID, "mrca_sparse_obs: beam_num %d not in [1, %d]", beam_num, env->view.B);
+    DeviceGuard guard(env->cfg.device);
+    mrca::launch_sparse_obs(env->view, index_dev, beam_num, out_dev, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
 }
 
 int mrca_gae(const float* rewards_dev, const float* values_dev, const float* last_value_dev,
@@ -563,7 +584,7 @@ int mrca_gae(const float* rewards_dev, const float* values_dev, const float* las
 int mrca_enable_timing(mrca_env* env, int32_t on) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     if (on && env->ev.empty()) {
-        env->ev.resize(3 * kTimingRing);
+        env->ev.resize(4 * kTimingRing);
         for (auto& e : env->ev) HIP_TRY(hipEventCreate(&e));
     }
     env->timing = on > 0 ? on : 0;
@@ -682,12 +703,12 @@ int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */) {
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
     float mv = 0.0f, ry = 0.0f;
-    const int n = env->ev_used / 3;
+    const int n = env->ev_used / 4;
     if (n > 0) HIP_TRY(hipEventSynchronize(env->ev[env->ev_used - 1]));
     for (int i = 0; i < n; ++i) {
         float a = 0.0f, b = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&a, env->ev[3 * i], env->ev[3 * i + 1]));
-        HIP_TRY(hipEventElapsedTime(&b, env->ev[3 * i + 1], env->ev[3 * i + 2]));
+        HIP_TRY(hipEventElapsedTime(&a, env->ev[4 * i], env->ev[4 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, env->ev[4 * i + 2], env->ev[4 * i + 3]));
         mv += a;
         ry += b;
     }

@@ -44,6 +44,7 @@ struct EnvView {
     int32_t* bw_chead;      // [bw_cmask+1] collision hash (0.7 m cells): bucket -> first entry, -1 = empty
     int32_t* bw_cnext;      // [2N] entry e = 2*robot + (0: pose at tick start | 1: provisional pose) -> next entry
     int32_t bw_cmask;
+    uint32_t* bw_ticket;    // [1] the collision pass hands its robot blocks to workgroups in the order they START
     int32_t* bw_lstart;     // [bw_lmask+2] lidar hash (6.5 m cells) over the FINAL poses: bucket -> first slot
     int32_t* bw_lcount;     // [bw_lmask+1] bucket population (counted by bw_finish_kernel, zeroed again by the scan)
     int32_t* bw_lcursor;    // [bw_lmask+1] fill cursor of the counting sort
@@ -60,6 +61,7 @@ struct EnvView {
     // lidar beam directions in the robot frame (stageros.cpp:495-497), fp64-computed, fp32-rounded
     const float* beam_cos;
     const float* beam_sin;
+    float beam_step, beam_inv_step;   // pi / (B - 1) and (B - 1) / pi as fp32 quotients (mrca_device.h:beam_interval)
     // occupancy grid (move kernel) + per-cell free-rectangle field (grid_march_skip, ray-cast kernel)
     const uint32_t* map_bits;
     const uint16_t* free_rect;   // [map_h + 2*kFieldPadY][free_rect_pitch][4 quadrants], see FreeRectField
@@ -98,11 +100,14 @@ constexpr uint32_t kStatusCollideUndecided = 1u;   // bw_collide_kernel gave up 
 size_t ray_lds_bytes(const EnvView& e);
 size_t move_lds_bytes(const EnvView& e);
 
-void launch_move(const EnvView& e, const float* actions, hipStream_t s);
+// `start` / `stop` (both or neither): events stamped with the BEGIN of the first and the END of the last kernel of the launch
+// (hipExtLaunchKernel: the dispatch's own timestamps -- what rocprofv3 reports -- instead of event records around it, which
+// read 2.5 us longer per kernel; bench.py)
+void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s);
 void launch_head_init(const EnvView& e, hipStream_t s);
 void launch_lidar_grid(const EnvView& e, int counted, hipStream_t s);   // big worlds: hash of the current poses for the ray cast
-void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s);
+void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 #if defined(MRCA_PROFILING)
 void read_ray_stamps(unsigned long long* host, int blocks);     // profiling build: [2 waves][7 stamps][blocks] of raycast_kernel
 void read_move_stamps(unsigned long long* host, int worlds);   // profiling build: s_memtime stamps of move_kernel's phases
@@ -111,6 +116,10 @@ void read_move_stamps(unsigned long long* host, int worlds);   // profiling buil
 void launch_materialize(const EnvView& e, int what, hipStream_t s);
 // the newest frame of every robot, normalised, into out[N,B] (the row a one-frame rollout buffer stores per tick)
 void launch_newest_obs(const EnvView& e, float* out, hipStream_t s);
+// out[N,F,nb] = x / 6 - 0.5 of beams index[0..nb) of every frame in deque order (get_laser_observation with beam_num != raw)
+// out[i] = in[i] / 6 - 0.5 exactly as the env's own views form it (norm_obs), for `count` floats (count % 4 == 0)
+void launch_normalize(const float* in, float* out, long long count, hipStream_t s);
+void launch_sparse_obs(const EnvView& e, const int32_t* index, int nb, float* out, hipStream_t s);
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,
                 float lam, int T, int N, float* targets, float* advs, hipStream_t s);
 

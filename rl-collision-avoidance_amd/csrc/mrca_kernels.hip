@@ -29,6 +29,8 @@
 // policy's conv front end (mrca_policy.hip) is where it is used.
 #include "mrca_kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace mrca {
 
 namespace {
@@ -187,6 +189,29 @@ __global__ void newest_obs_kernel(EnvView e, float* __restrict__ out) {
         const int col = (int)(k - r * fstride);
         const int hd = e.ring_head[r];
         reinterpret_cast<float4*>(out)[k] = norm_obs4(ring[(r * e.F + hd) * fstride + col]);
+    }
+}
+
+__global__ void normalize_kernel(const float4* __restrict__ in, float4* __restrict__ out, long long count4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < count4; k += stride) out[k] = norm_obs4(in[k]);
+}
+
+// get_laser_observation for beam_num != the raw sample count (stage_world1.py:126-139: a left half picked ascending and a
+// right half picked descending from the raw scan): out[n][f][k] = x / 6 - 0.5 of beam index[k] of robot n's logical frame f.
+// The index table is the caller's (the reference builds it by repeated float64 addition; mrca/vec_env.py restates that).
+__global__ void sparse_obs_kernel(EnvView e, const int32_t* __restrict__ index, int nb, float* __restrict__ out) {
+    const long long total = (long long)e.N * e.F * nb;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        const long long rf = k / nb;
+        const int j = (int)(k - rf * nb);
+        const long long r = rf / e.F;
+        const int f = (int)(rf - r * e.F);
+        const int hd = e.ring_head[r];
+        int slot = hd + 1 + f;
+        slot -= slot >= e.F ? e.F : 0;
+        out[k] = norm_obs(e.scan_ring[((size_t)r * e.F + slot) * e.B + index[j]]);
     }
 }
 
@@ -535,20 +560,11 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
         } else {
             wave_sample_goal(lane, gm, (uint32_t)nsrc, eps, e.key0, e.key1, px, py, &qx, &qy);
         }
-        // head record of the new pose (wave-uniform values; only lane src keeps them)
-        float rs_, rc_;
-        sincos_det(pth, &rs_, &rc_);
-        uint32_t rv_, rw_;
-        rect_field.cell((int)floorf((px - e.g.x0) * e.g.inv_cell), (int)floorf((py - e.g.y0) * e.g.inv_cell), &rv_, &rw_);
         if (lane == src) {
             ep = (int)eps;
             x = px;
             y = py;
             th = pth;
-            s = rs_;
-            c = rc_;
-            cellv = rv_;
-            cellw = rw_;
             gx = qx;
             gy = qy;
             const float ex = qx - px, ey = qy - py;
@@ -563,6 +579,13 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
             ovgt = owgt = 0.0f;
             if (!e.hold_velocity) spv = spw = 0.0f;   // hold_velocity: the odom twist survives the teleport
         }
+    }
+    // head records of the new poses, for every restarted robot AT ONCE: inside the loop above the field entry of each new
+    // cell was a dependent global load per restart -- a world with three restarts in a tick waited three round trips,
+    // and the launch lasts as long as its slowest world
+    if (fresh) {
+        sincos_det(th, &s, &c);
+        rect_field.cell((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell), &cellv, &cellw);
     }
 
     MRCA_STAMP(7);      // restarts done
@@ -750,7 +773,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
                 if (hash_cell_coord(cxj, kLidarCell) == qx && hash_cell_coord(cyj, kLidarCell) == qy) {
                     const float ddx = cxj - x, ddy = cyj - y;
                     if (ddx * ddx + ddy * ddy <= kLidarReach2) {
-                        beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, &lo, &hi);
+                        beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, e.beam_step, e.beam_inv_step, &lo, &hi);
                         keep = lo <= hi;
                         if (keep) chj = e.head[j];
                     }
@@ -787,7 +810,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         bool keep = cand && (ddx * ddx + ddy * ddy <= 39.69f);
         int lo = 0, hi = -1;
         if (keep) {
-            beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, &lo, &hi);
+            beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, e.beam_step, e.beam_inv_step, &lo, &hi);
             keep = lo <= hi;
         }
         const unsigned long long m = __ballot(keep);
@@ -876,10 +899,12 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         for (int k = 0; k < K; ++k) {
             const int b = tid + k * T;
             const float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
+            // (nontemporal: the 8.4 MB of rows a launch writes are not read again by it -- they should not push the
+            // free-rectangle field, which every workgroup reads, out of the XCD's L2)
             if (fresh) {     // deque([obs] * F), ppo_stage1.py:59-60: every slot, the head stays where it is
-                for (int f = 0; f < e.F; ++f) ring_row[f * e.B + b] = r;
+                for (int f = 0; f < e.F; ++f) __builtin_nontemporal_store(r, &ring_row[f * e.B + b]);
             } else {
-                ring_row[new_slot * e.B + b] = r;
+                __builtin_nontemporal_store(r, &ring_row[new_slot * e.B + b]);
             }
         }
         if (tid == 0 && !fresh) e.ring_head[n] = (uint8_t)new_slot;
@@ -904,9 +929,10 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
 //                 its provisional centre; anybody listed there within 2 x circumradius can matter.  i is decided once
 //                 every such lower-indexed moving robot is (their outcome tells which of their two poses counts);
 //                 then it runs the SAT tests and publishes its own outcome (release / acquire on bw_state).  The
-//                 lowest undecided robot never waits, so the loop terminates as long as lower workgroups get to run
-//                 (see the kernel: in-order dispatch is observed, not guaranteed; a bounded wait that ends in a status
-//                 word, never in a silent wrong state).  Robots with nobody in reach decide in their first round.
+//                 lowest undecided robot never waits, and robot blocks are handed to workgroups by TICKET in the order
+//                 they start, so every lower-indexed robot is held by a workgroup that is already running or done: the
+//                 loop terminates whatever order the hardware dispatches workgroups in (a bounded wait + status word
+//                 stay as a belt).  Robots with nobody in reach decide in their first round.
 //   bw_finish     thread per robot: commit, GT velocity, reward / terminal, episode bookkeeping (per-robot resets),
 //                 head record.
 //   bw_lidar_*    counting sort of the FINAL poses into the lidar hash (6.5 m cells) the ray cast enumerates.
@@ -915,6 +941,7 @@ constexpr int kFlagMoving = 1, kFlagStaticHit = 2, kFlagLive = 4;
 
 __global__ void bw_integrate_kernel(EnvView e, const float* __restrict__ actions) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) *e.bw_ticket = 0;          // the collision pass that follows hands out its robot blocks by ticket
     if (n >= e.N) return;
     const float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
     const float4 hd = e.head[n];
@@ -959,7 +986,14 @@ __global__ void bw_integrate_kernel(EnvView e, const float* __restrict__ actions
 }
 
 __global__ void bw_collide_kernel(EnvView e) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    // A workgroup takes the next block of robots when it STARTS (a ticket), not by its blockIdx: the robots below any
+    // robot of this workgroup then belong to workgroups that have already started -- they are resident or finished,
+    // never waiting to be dispatched -- so a robot only ever waits for waves that are running.  (Rounds 2-3 mapped
+    // blockIdx -> robots and relied on gfx950 dispatching workgroups in index order: observed, not guaranteed.)
+    __shared__ int block_ticket;
+    if (threadIdx.x == 0) block_ticket = (int)atomicAdd(e.bw_ticket, 1u);
+    __syncthreads();
+    const int n = block_ticket * blockDim.x + threadIdx.x;
     if (n >= e.N) return;
     const float4 p0 = e.bw_prov[2 * n], p1 = e.bw_prov[2 * n + 1];
     const int flags = __float_as_int(p0.w);
@@ -973,13 +1007,12 @@ __global__ void bw_collide_kernel(EnvView e) {
     for (int q = 0; q < 9; ++q)
         head9[q] = e.bw_chead[hash_cell(icx + q % 3 - 1, icy + q / 3 - 1, world) & (uint32_t)e.bw_cmask];
     // Dependency rounds.  A robot only ever waits for LOWER-indexed robots, and the lowest undecided robot of the
-    // launch never waits, so somebody can always make progress -- PROVIDED the waves holding those lower indices are
-    // resident or will become resident.  Workgroups are dispatched in index order on gfx950 (observed, not an
-    // architectural guarantee: MI355X_MICROARCH.md "Dispatch order ... undefined"), and a waiting wave sleeps, so in
-    // practice a lower workgroup is never starved.  Should that ever fail, the guard below ends the launch instead of
-    // hanging the GPU, the robot stays undecided (treated as not moved) and bit 0 of the env's status word is raised:
-    // mrca_check() turns it into MRCA_ERR_HIP -- never a silent wrong state.  The release store of the outcome sits
-    // inside the loop by construction (done-flag form), not by grace of the optimiser.
+    // launch never waits, so somebody can always make progress: every lower-indexed robot sits in a workgroup that took
+    // its ticket earlier, i.e. one that is resident (its waves are scheduled: a waiting wave sleeps, it does not starve
+    // the others) or already done.  The guard below stays as a belt: should a wait ever run out, the launch ends
+    // instead of hanging the GPU, the robot stays undecided (treated as not moved) and bit 0 of the env's status word
+    // is raised -- mrca_check() turns it into MRCA_ERR_HIP, never a silent wrong state.  The release store of the
+    // outcome sits inside the loop by construction (done-flag form), not by grace of the optimiser.
     bool done = false;
     for (int guard = 0; !done && guard < (1 << 22); ++guard) {
         bool ready = true;
@@ -1263,14 +1296,24 @@ size_t move_lds_bytes(const EnvView& e) {
     return b;
 }
 
-void launch_move(const EnvView& e, const float* actions, hipStream_t s) {
+void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     if (!e.big) {
-        hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e, actions);
+        if (start || stop)
+            hipExtLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), (uint32_t)move_lds_bytes(e), s, start, stop, 0,
+                                  e, actions);
+        else
+            hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e, actions);
         return;
     }
     // (the collision hash's heads and the lidar hash's counts are left clean by the tick before: bw_finish_kernel /
     // bw_lidar_scan_local_kernel; mrca_create clears them once)
     const int bs = 256, nb = (e.N + bs - 1) / bs;
+    if (start || stop) {     // the move phase's span: begin of its first kernel .. end of its last
+        hipExtLaunchKernelGGL(bw_integrate_kernel, dim3(nb), dim3(bs), 0, s, start, nullptr, 0, e, actions);
+        hipLaunchKernelGGL(bw_collide_kernel, dim3(nb), dim3(bs), 0, s, e);
+        hipExtLaunchKernelGGL(bw_finish_kernel, dim3(nb), dim3(bs), 0, s, nullptr, stop, 0, e);
+        return;
+    }
     hipLaunchKernelGGL(bw_integrate_kernel, dim3(nb), dim3(bs), 0, s, e, actions);
     hipLaunchKernelGGL(bw_collide_kernel, dim3(nb), dim3(bs), 0, s, e);
     hipLaunchKernelGGL(bw_finish_kernel, dim3(nb), dim3(bs), 0, s, e);      // + the lidar hash's counts
@@ -1282,6 +1325,22 @@ void launch_materialize(const EnvView& e, int what, hipStream_t s) {
     long long nb = (cols + 255) / 256;
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(materialize_kernel, dim3((int)nb), dim3(256), 0, s, e, what);
+}
+
+void launch_normalize(const float* in, float* out, long long count, hipStream_t s) {
+    const long long c4 = count / 4;
+    long long blocks = (c4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) return;
+    hipLaunchKernelGGL(normalize_kernel, dim3((int)blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(in),
+                       reinterpret_cast<float4*>(out), c4);
+}
+
+void launch_sparse_obs(const EnvView& e, const int32_t* index, int nb, float* out, hipStream_t s) {
+    const long long total = (long long)e.N * e.F * nb;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sparse_obs_kernel, dim3((int)blocks), dim3(256), 0, s, e, index, nb, out);
 }
 
 void launch_newest_obs(const EnvView& e, float* out, hipStream_t s) {
@@ -1312,13 +1371,20 @@ void launch_head_init(const EnvView& e, hipStream_t s) {
     hipLaunchKernelGGL(head_init_kernel, dim3((e.N + bs - 1) / bs), dim3(bs), 0, s, e);
 }
 
-void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s) {
+void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     const int threads = (e.B >> e.ray_shift) + (e.ray_prep_wave ? kWave : 0);
     const size_t lds = ray_lds_bytes(e);
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
     const bool seq = e.ray_sequential != 0;
-#define MRCA_RAY(K, BIG, SEQ) hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, e, only_fresh)
+#define MRCA_RAY(K, BIG, SEQ)                                                                                          \
+    do {                                                                                                               \
+        if (start || stop)                                                                                             \
+            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0, e,  \
+                                  only_fresh);                                                                         \
+        else                                                                                                           \
+            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, e, only_fresh);             \
+    } while (0)
     if (e.big) {
         switch (e.ray_shift) {
             case 0: MRCA_RAY(1, true, false); break;

@@ -25,7 +25,7 @@
 #include "../../include/mrca_env.h"
 #include "mrca_hostutil.h"
 
-namespace mrca_ppo_loss {
+namespace mrca_ppoloss {
 
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 256;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kThreads) void ppo_loss_kernel(
     const float* __restrict__ action, const float* __restrict__ old_logprob, const float* __restrict__ adv,
     const float* __restrict__ target, int n, float clip, float value_coef, float coeff_entropy,
     float* __restrict__ out /* [8]: loss, L_pi, L_v, H, kl, dls_0, dls_1, - */, float* __restrict__ gmean /* [n,2] */,
-    float* __restrict__ gvalue /* [n] */, double* __restrict__ partial, unsigned int* __restrict__ ticket) {
+    float* __restrict__ gvalue /* [n] */, double* partial, unsigned int* ticket) {
     __shared__ double red[kSums][kThreads / 64];
     __shared__ bool is_last;
     const float ls0 = logstd[0], ls1 = logstd[1];
@@ -88,16 +88,19 @@ __global__ __launch_bounds__(kThreads) void ppo_loss_kernel(
         for (int w = 0; w < kThreads / 64; ++w) v += red[threadIdx.x][w];
         partial[(size_t)blockIdx.x * kSums + threadIdx.x] = v;
     }
+    // release (agent scope: the workgroups of a launch sit on eight XCDs with an L2 each), the write-back waited for in so
+    // many words (MI355X_MICROARCH.md, "compiler hazard": the s_waitcnt behind buffer_wbl2 can be dropped), THEN the ticket
     __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
+    __threadfence();      // acquire: the other workgroups' partial sums, whichever XCD wrote them
     if (threadIdx.x < kSums) {
         double v = 0.0;
         for (unsigned b = 0; b < gridDim.x; ++b)
-            v += __builtin_nontemporal_load(&partial[(size_t)b * kSums + threadIdx.x]);     // fixed order over workgroups
+            v += partial[(size_t)b * kSums + threadIdx.x];     // fixed order over workgroups
         red[threadIdx.x][0] = v;
     }
     __syncthreads();
@@ -112,15 +115,15 @@ __global__ __launch_bounds__(kThreads) void ppo_loss_kernel(
         out[5] = (float)(red[3][0] - (double)coeff_entropy);
         out[6] = (float)(red[4][0] - (double)coeff_entropy);
         out[7] = 0.0f;
-        *ticket = 0u;                                            // ready for the next launch on this stream
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
     }
 }
 
-}  // namespace mrca_ppo_loss
+}  // namespace mrca_ppoloss
 
 extern "C" int mrca_ppo_loss_scratch(size_t* bytes_out) {
     if (!bytes_out) return mrca::set_error(MRCA_ERR_INVALID, "mrca_ppo_loss_scratch: bytes_out is NULL");
-    *bytes_out = mrca_ppo_loss::kScratchBytes;
+    *bytes_out = mrca_ppoloss::kScratchBytes;
     return MRCA_OK;
 }
 
@@ -128,7 +131,7 @@ extern "C" int mrca_ppo_loss(const float* mean_dev, const float* value_dev, cons
                              const float* old_logprob_dev, const float* adv_dev, const float* target_dev, int32_t n,
                              float clip_value, float value_coef, float coeff_entropy, float* out_dev, float* gmean_dev,
                              float* gvalue_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
-    using namespace mrca_ppo_loss;
+    using namespace mrca_ppoloss;
     if (!mean_dev || !value_dev || !logstd_dev || !action_dev || !old_logprob_dev || !adv_dev || !target_dev || !out_dev ||
         !gmean_dev || !gvalue_dev || !scratch_dev)
         return mrca::set_error(MRCA_ERR_INVALID, "mrca_ppo_loss: NULL pointer");

@@ -21,10 +21,10 @@ FIELDS = [  # order = enum mrca_field
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
-           "mrca_step", "mrca_step_slice", "mrca_materialize", "mrca_newest_obs", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
+           "mrca_step", "mrca_step_slice", "mrca_materialize", "mrca_newest_obs", "mrca_sparse_obs", "mrca_normalize_scans", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
            "mrca_event_pair_overhead",
            "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
-           "mrca_policy_tail"]
+           "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch"]
 
 
 class MrcaConfig(C.Structure):
@@ -68,6 +68,8 @@ def load(path=None):
     lib.mrca_check.argtypes = [C.c_void_p, C.c_void_p]
     lib.mrca_materialize.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.mrca_newest_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_normalize_scans.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mrca_sparse_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mrca_get_field.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_size_t)]
     lib.mrca_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32,
@@ -78,6 +80,9 @@ def load(path=None):
     lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + \
         [C.c_size_t, C.c_void_p]
     lib.mrca_policy_tail.argtypes = [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 16
+    lib.mrca_ppo_loss_scratch.argtypes = [C.POINTER(C.c_size_t)]
+    lib.mrca_ppo_loss.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4 + \
+        [C.c_size_t, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only
         lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]

@@ -28,23 +28,25 @@ class ConcatEnv:
         self.ring_is_raw = raw.pop()
         self._gather()
 
-    # the scans are kept the way the parts keep them: as rings of raw ranges (see VecStageWorld.obs).  x / 6.0 - 0.5 in
-    # torch is the correctly rounded quotient minus one half: bit-identical to the library's norm_obs
+    # the scans are kept the way the parts keep them: as rings of raw ranges (see VecStageWorld.obs); observations are
+    # formed by the library's own x / 6 - 0.5 (policy_ops.normalize_scans), never by torch's scalar division
     @property
     def obs(self):
         """f32[N,F,B] x / 6 - 0.5 in deque order (oldest frame first), gathered from the concatenated rings."""
+        from .policy_ops import normalize_scans
         F = self.scan_ring.shape[1]
         slots = (self.ring_head.long().view(-1, 1) + 1 + self._order) % F
         stacks = self.scan_ring[self._ar.view(-1, 1), slots]
-        return stacks / 6.0 - 0.5 if self.ring_is_raw else stacks
+        return normalize_scans(stacks) if self.ring_is_raw else stacks
 
     def policy_obs(self):
         from .policy_ops import RingHead
         return self.scan_ring, RingHead(self.ring_head, raw=self.ring_is_raw)
 
     def newest_frame(self):
+        from .policy_ops import normalize_scans
         rows = self.scan_ring[self._ar, self.ring_head.long()]
-        return rows / 6.0 - 0.5 if self.ring_is_raw else rows
+        return normalize_scans(rows) if self.ring_is_raw else rows
 
     def _gather(self):
         for k in _FIELDS:

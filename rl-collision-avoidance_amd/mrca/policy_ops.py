@@ -30,6 +30,23 @@ def unwrap_head(head):
     return head, False
 
 
+def normalize_scans(scans):
+    """x / 6 - 0.5 (stage_world1.py:140) of raw lidar ranges, rounded exactly as the env's own MRCA_F_OBS view is
+    (mrca_normalize_scans).  torch's ``x / 6.0`` is NOT that on the GPU: a scalar divisor becomes a multiplication by
+    RN(1/6).  CPU tensors (the tests' stand-ins) take numpy's correctly rounded quotient, which equals the kernel's
+    result."""
+    if not scans.is_cuda:
+        return torch.from_numpy(scans.numpy() / scans.numpy().dtype.type(6.0) - scans.numpy().dtype.type(0.5))
+    x = scans.contiguous()
+    if x.dtype != torch.float32 or x.numel() % 4:
+        raise ValueError("normalize_scans: expected a float32 tensor with a multiple of 4 elements")
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(_lib.load().mrca_normalize_scans(x.data_ptr(), out.data_ptr(), x.numel(), stream), "mrca_normalize_scans")
+    return out
+
+
 def lidar_features(obs, w1, b1, w2, b2, out=None, head=None):
     """relu(conv2(relu(conv1(obs)))) of the actor and the critic tower in one launch.
     obs f32[N,3,512]; w1 f32[2,32,3,5], b1 f32[2,32], w2 f32[2,32,32,3], b2 f32[2,32] (tower-major: actor, critic)
@@ -151,3 +168,59 @@ def lidar_features_fn(obs, w1, b1, w2, b2):
     """Differentiable lidar_features: same arguments, returns (actor features, critic features), gradients flow to
     w1 / b1 / w2 / b2 (the scan is data)."""
     return _LidarFeatures.apply(obs, w1, b1, w2, b2)
+
+
+# ------------------------------------------------------------------------------------------------ the PPO loss tail
+_loss_scratch = {}
+
+
+def _ppo_loss_scratch(device):
+    key = (device.type, device.index)
+    if key not in _loss_scratch:
+        lib = _lib.load()
+        n = C.c_size_t()
+        _lib.check(lib.mrca_ppo_loss_scratch(C.byref(n)), "mrca_ppo_loss_scratch")
+        _loss_scratch[key] = torch.zeros(n.value, dtype=torch.uint8, device=device)      # zeroed once: the ticket counter
+    return _loss_scratch[key]
+
+
+class _PPOLoss(torch.autograd.Function):
+    """loss = L_pi + value_coef * L_v - coeff_entropy * H of model/ppo.py:172-185 with its gradients with respect to the
+    network's outputs (mean, value, logstd) from ONE launch (csrc/mrca_ppo_loss.hip); backward scales them by the incoming
+    gradient (1 for ``loss.backward()``)."""
+
+    @staticmethod
+    def forward(ctx, mean, value, logstd, action, old_logprob, adv, target, clip_value, value_coef, coeff_entropy):
+        lib = _lib.load()
+        n = mean.shape[0]
+        args = [t.detach().contiguous().view(-1) for t in (mean, value, logstd, action, old_logprob, adv, target)]
+        for t, numel in zip(args, (2 * n, n, 2, 2 * n, n, n, n)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.numel() == numel):
+                raise ValueError("ppo_loss: expected cuda float32 tensors mean [n,2], value [n,1], logstd [2], action [n,2], "
+                                 "old_logprob / adv / target [n,1]")
+        dev = mean.device
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        gmean = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        gvalue = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        scratch = _ppo_loss_scratch(dev)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.mrca_ppo_loss(*[t.data_ptr() for t in args], n, float(clip_value), float(value_coef),
+                                         float(coeff_entropy), out.data_ptr(), gmean.data_ptr(), gvalue.data_ptr(),
+                                         scratch.data_ptr(), scratch.numel(), stream), "mrca_ppo_loss")
+        ctx.save_for_backward(gmean, gvalue, out)
+        ctx.value_shape, ctx.logstd_shape = value.shape, logstd.shape
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        gmean, gvalue, out = ctx.saved_tensors
+        return (gmean * g_loss, (gvalue * g_loss).view(ctx.value_shape), (out[5:7] * g_loss).view(ctx.logstd_shape),
+                None, None, None, None, None, None, None)
+
+
+def ppo_loss(mean, value, logstd, action, old_logprob, adv, target, clip_value, value_coef, coeff_entropy):
+    """-> (loss, stats): ``loss`` differentiable with respect to mean [n,2], value [n,1] and logstd [2]; ``stats`` f32[8] =
+    loss, policy loss, value loss, entropy, k3 KL(old || new), dloss/dlogstd[0], dloss/dlogstd[1], 0."""
+    return _PPOLoss.apply(mean, value, logstd, action, old_logprob, adv, target, clip_value, value_coef, coeff_entropy)

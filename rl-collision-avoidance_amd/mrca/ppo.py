@@ -260,14 +260,6 @@ def _global_mean_std(x, dist):
     return mean.to(x.dtype), torch.sqrt(var).to(x.dtype)
 
 
-def _minibatches(n, batch_size, drop_last, generator=None, device=None):
-    perm = torch.randperm(n, device=device, generator=generator)
-    out = list(torch.split(perm, batch_size))
-    if drop_last and out and out[-1].numel() < batch_size:
-        out = out[:-1]
-    return out
-
-
 def _world_size(dist):
     return dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
 
@@ -320,9 +312,22 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
     if multi and flat_grads is None:
         raise ValueError("ppo update with a multi-rank process group needs flat_grads (ppo.FlatGrads): without it "
                          "the replicas would train unsynchronised")
+    # the loss tail (ratio, clipped surrogate, value loss, entropy and their gradients) as ONE launch where the policy's
+    # front end already runs through the HIP kernels (policy_ops.ppo_loss); the stock expression otherwise
+    fused_loss = bool(getattr(policy, "fused_train", False)) and advs.is_cuda and autocast_dtype is None
+    small = (goals, speeds, actions, logprobs, targets, advs)
     for _ in range(epoch):
-        batches = index_batches(n) if index_batches is not None else \
-            _minibatches(n, batch_size, drop_last, device=advs.device)
+        if index_batches is not None:
+            batches = index_batches(n)
+            rows = None
+        else:
+            # ONE permutation per epoch: the six small per-sample tensors are permuted once, their minibatches are then
+            # contiguous slices (views); only the observation stacks -- three frame rows per sample -- are gathered per
+            # minibatch.  (Seven index kernels per minibatch before: 1 152 of them per 64-minibatch update.)
+            perm = torch.randperm(n, device=advs.device)
+            n_mb = n // batch_size if drop_last else -(-n // batch_size)
+            batches = [perm[k * batch_size: min((k + 1) * batch_size, n)] for k in range(n_mb)]
+            rows = tuple(x[perm] for x in small)
         if multi:
             # every rank must take the same number of optimiser steps (one gradient all-reduce each): Stage-2
             # filtering leaves a different row count on every rank, so agree on the minimum for this epoch
@@ -334,19 +339,30 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
             batches = batches[:int(s.item())]
         kl_sum = torch.zeros((), device=advs.device)
         n_done, stop = 0, False
-        for index in batches:
-            with torch.autocast(advs.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
-                new_value, new_logprob, dist_entropy = policy.evaluate_actions(obss[index], goals[index],
-                                                                               speeds[index], actions[index])
-            new_value, new_logprob = new_value.float(), new_logprob.float()
-            log_ratio = new_logprob - logprobs[index]
-            ratio = torch.exp(log_ratio)
-            adv = advs[index]
-            surrogate1 = ratio * adv
-            surrogate2 = torch.clamp(ratio, 1 - clip_value, 1 + clip_value) * adv
-            policy_loss = -torch.min(surrogate1, surrogate2).mean()
-            value_loss = F.mse_loss(new_value, targets[index])
-            loss = policy_loss + value_coef * value_loss - coeff_entropy * dist_entropy
+        for k, index in enumerate(batches):
+            if rows is None:
+                mb_goal, mb_speed, mb_action, mb_logprob, mb_target, adv = (x[index] for x in small)
+            else:
+                lo_, hi_ = k * batch_size, k * batch_size + index.numel()
+                mb_goal, mb_speed, mb_action, mb_logprob, mb_target, adv = (x[lo_:hi_] for x in rows)
+            if fused_loss:
+                from . import policy_ops
+                mean, new_value = policy.mean_value(obss[index], mb_goal, mb_speed)
+                loss, stats = policy_ops.ppo_loss(mean, new_value, policy.logstd, mb_action, mb_logprob, adv, mb_target,
+                                                  clip_value, value_coef, coeff_entropy)
+                policy_loss, value_loss, dist_entropy, kl_mb = stats[1], stats[2], stats[3], stats[4]
+            else:
+                with torch.autocast(advs.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+                    new_value, new_logprob, dist_entropy = policy.evaluate_actions(obss[index], mb_goal, mb_speed, mb_action)
+                new_value, new_logprob = new_value.float(), new_logprob.float()
+                log_ratio = new_logprob - mb_logprob
+                ratio = torch.exp(log_ratio)
+                surrogate1 = ratio * adv
+                surrogate2 = torch.clamp(ratio, 1 - clip_value, 1 + clip_value) * adv
+                policy_loss = -torch.min(surrogate1, surrogate2).mean()
+                value_loss = F.mse_loss(new_value, mb_target)
+                loss = policy_loss + value_coef * value_loss - coeff_entropy * dist_entropy
+                kl_mb = None
             if flat_grads is not None:
                 flat_grads.zero()
             else:
@@ -366,7 +382,8 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
             stop = False
             if kl_ctl is not None:
                 with torch.no_grad():
-                    kl_mb = ((ratio - 1.0) - log_ratio).mean()        # k3 estimator of KL(old || new), >= 0
+                    if kl_mb is None:
+                        kl_mb = ((ratio - 1.0) - log_ratio).mean()        # k3 estimator of KL(old || new), >= 0
                     kl_sum += kl_mb
                 n_done += 1
                 stop = kl_ctl.should_stop(kl_mb, dist)

@@ -48,13 +48,13 @@ class ShardedWorld:
 
     def obs(self):
         """f32[count,F,B] this rank's stacks in deque order, gathered from the ring rows of the slice only."""
-        from .policy_ops import unwrap_head
+        from .policy_ops import normalize_scans, unwrap_head
         ring, head = self.policy_obs()
         head, raw = unwrap_head(head)
         F = ring.shape[1]
         slots = (head.long().view(-1, 1) + 1 + torch.arange(F, device=ring.device).view(1, -1)) % F
         stacks = ring[torch.arange(ring.shape[0], device=ring.device).view(-1, 1), slots]
-        return stacks / 6.0 - 0.5 if raw else stacks      # (a ring of raw scans: stage_world1.py:140 applied on read)
+        return normalize_scans(stacks) if raw else stacks      # (a ring of raw scans: stage_world1.py:140 applied on read)
 
     def check(self):
         self.env.check()

@@ -71,7 +71,10 @@ class Stage1Trainer:
         if self.hp.update_fused:
             self.policy.fused_train = True
         broadcast_parameters(self.policy, dist)
-        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate)
+        # the reference's optimiser (ppo_stage1.py:176: Adam, lr 5e-5); on the GPU as ONE multi-tensor launch per step
+        # (fused=True: the same update rule; the default "foreach" form is a dozen launches per step)
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate,
+                                          **({"fused": True} if dev.type == "cuda" else {}))
         self.flat_grads = ppo.FlatGrads(self.policy.parameters())
         self.kl_ctl = ppo.KLAdaptiveLR(self.hp.kl_target, lr_max=self.hp.lr_max, stop_factor=self.hp.kl_stop) \
             if self.hp.kl_target > 0 else None

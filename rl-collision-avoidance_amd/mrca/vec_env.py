@@ -18,6 +18,23 @@ _DTYPES = {"f32": torch.float32, "u8": torch.uint8, "i32": torch.int32}
 RESULT_NAMES = {0: 0, 1: "Reach Goal", 2: "Crashed", 3: "Time out"}  # stage_world1.py:190-208
 
 
+def sparse_beam_index(raw_beams, beam_num):
+    """The beams get_laser_observation keeps when the world was constructed with ``beam_num`` != the lidar's sample count
+    (stage_world1.py:126-139): a float64 index advanced by raw / beam_num per pick and truncated, beam_num / 2 picks
+    ascending from beam 0 and beam_num / 2 descending from the last beam (the right half then reversed)."""
+    step = float(raw_beams) / beam_num
+    left, right = [], []
+    index = 0.0
+    for _ in range(int(beam_num / 2)):
+        left.append(int(index))
+        index += step
+    index = raw_beams - 1.0
+    for _ in range(int(beam_num / 2)):
+        right.append(int(index))
+        index -= step
+    return np.asarray(left + right[::-1], np.int32)
+
+
 class VecStageWorld:
     def __init__(self, scenario: Scenario, device=None, lib_path=None):
         if not torch.cuda.is_available():
@@ -119,6 +136,18 @@ class VecStageWorld:
         elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.N * self.B):
             raise ValueError("newest_frame: out must be a contiguous cuda float32 tensor of N x B elements")
         _lib.check(self.lib.mrca_newest_obs(self._h, out.data_ptr(), self._stream()), "mrca_newest_obs")
+        return out
+
+    def sparse_obs(self, beam_num):
+        """f32[N,F,beam_num]: the observation stacks a ``StageWorld(beam_num, ...)`` with beam_num != 512 would build
+        (stage_world1.py:126-140), formed on the device from the ring."""
+        cache = self.__dict__.setdefault("_sparse_index", {})
+        if beam_num not in cache:
+            cache[beam_num] = torch.from_numpy(sparse_beam_index(self.B, beam_num)).to(self.device)
+        idx = cache[beam_num]
+        out = torch.empty(self.N, self.F, idx.numel(), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mrca_sparse_obs(self._h, idx.data_ptr(), idx.numel(), out.data_ptr(), self._stream()),
+                   "mrca_sparse_obs")
         return out
 
     # ------------------------------------------------------------------ lifecycle

@@ -414,6 +414,51 @@ def test_hip_env_observation_of_real_scans_matches_the_reference_formula():
     assert np.abs(env.obs[:, -1].cpu().numpy().astype(np.float64) - (scan / 6.0 - 0.5)).max() <= 6e-8
 
 
+def test_sparse_beam_index_is_the_references_pick_rule():
+    """vec_env.sparse_beam_index (what mrca_sparse_obs is fed) against the beams the REFERENCE's get_laser_observation
+    picked for beam_num 256 / 128: a golden scan whose 512 values are all different identifies every pick."""
+    from mrca.vec_env import sparse_beam_index
+    g = gold("stage1")
+    assert np.array_equal(sparse_beam_index(512, 512), np.arange(512))
+    tagged = 0
+    for s, o256, o128 in zip(g["obs_scan"], g["obs_out_256"], g["obs_out_128"]):
+        if not np.isfinite(s).all() or len(np.unique(s)) != 512:
+            continue
+        tagged += 1
+        full = s.astype(np.float64) / 6.0 - 0.5
+        assert np.array_equal(full[sparse_beam_index(512, 256)], o256)
+        assert np.array_equal(full[sparse_beam_index(512, 128)], o128)
+    if not tagged:          # no golden scan with 512 distinct values: the rule against the facade's own loop instead
+        for bn in (256, 128, 300, 64):
+            step = 512.0 / bn
+            want = [int(i * step) for i in range(bn // 2)] + [int(511.0 - i * step) for i in range(bn // 2)][::-1]
+            got = sparse_beam_index(512, bn).tolist()
+            assert got == want or bn == 300, bn       # (non-dyadic steps: repeated addition may round differently)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bn", [256, 128])
+def test_hip_sparse_observation_matches_the_reference(bn):
+    """Device-side get_laser_observation for beam_num != 512 (mrca_sparse_obs): on REAL scans of the HIP env the stack a
+    StageWorld(bn, ...) would build -- every frame, deque order -- equals the reference's pick rule applied to the env's
+    own full observation, bit for bit (the affine map is the same instruction sequence)."""
+    import torch
+    from mrca.vec_env import VecStageWorld, sparse_beam_index
+    env = VecStageWorld(S.stage1(num_worlds=4, robots_per_world=24, seed=5), device="cuda:0")
+    env.reset()
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        env.step(torch.from_numpy(U.random_actions(rng, env.N)).cuda())
+    got = env.sparse_obs(bn)
+    idx = torch.from_numpy(sparse_beam_index(512, bn)).long().cuda()
+    assert got.shape == (env.N, 3, bn)
+    assert torch.equal(got, env.obs[:, :, idx])
+    # ... and the facade's float64 observation of the same scan is that row to fp32 rounding
+    scan = env.scan.cpu().numpy().astype(np.float64)
+    assert np.abs(got[:, -1].cpu().numpy().astype(np.float64) - (scan[:, idx.cpu().numpy()] / 6.0 - 0.5)).max() <= 6e-8
+    env.close()
+
+
 @pytest.mark.gpu
 def test_hip_samplers_match_the_reference_draws():
     import torch

@@ -172,9 +172,13 @@ def test_front_end_reads_the_envs_frame_ring_in_place(pol):
         # the views against the ring itself: newest scan, and torch's own x / 6 - 0.5 (the IEEE quotient minus one half)
         ar = torch.arange(env.N, device="cuda")
         assert torch.equal(env.scan, ring[ar, head.slots.long()])
-        assert torch.equal(env.obs[:, -1], env.scan / 6.0 - 0.5)
+        assert torch.equal(env.obs[:, -1], policy_ops.normalize_scans(env.scan))
+        # ... which is the correctly rounded x / 6 minus one half (numpy on the host; torch's GPU `x / 6.0` multiplies by
+        # RN(1/6) instead and differs in the last bit for one value in a few hundred)
+        host = env.scan.cpu().numpy()
+        assert np.array_equal(env.obs[:, -1].cpu().numpy(), host / np.float32(6.0) - np.float32(0.5))
         # a ring of NORMALISED frames (what a caller of ABI 3 hands over) still works: plain u8 heads
-        via_norm = policy_ops.lidar_features((ring / 6.0 - 0.5).contiguous(), rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head.slots)
+        via_norm = policy_ops.lidar_features(policy_ops.normalize_scans(ring), rc["w1"], rc["b1"], rc["w2"], rc["b2"], head=head.slots)
         assert torch.equal(via_norm, via_copy), k
         m0, v0 = pol.mean_value_fused(ring, env.local_goal, env.speed, head=head)
         m1, v1 = pol.mean_value_fused(env.obs, env.local_goal, env.speed)

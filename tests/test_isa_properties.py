@@ -42,7 +42,8 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
                if re.match(r"\s+v_(div_scale|div_fmas|div_fixup|rsq|sqrt|rcp|rcp_iflag)_f32", l)]
     assert fused and anchors
     # norm_obs (x / 6 - 0.5, two explicit __builtin_fmaf): since ABI 4 only the READERS of the scan ring form it --
-    # materialize_kernel and newest_obs_kernel, four floats at a time, which the compiler packs (v_pk_mul / v_pk_fma with
+    # materialize_kernel, newest_obs_kernel, normalize_kernel and sparse_obs_kernel, mostly four floats at a time, which the
+    # compiler packs (v_pk_mul / v_pk_fma with
     # RN(1/6) and 6.0 in scalar registers).  Every fused operation inside those two kernels is one of these; no ray-cast
     # variant holds any (it stores raw ranges).
     starts = [(i, m.group(1)) for i, l in enumerate(device_asm) for m in [re.match(r"(_Z\w+):\s*(;.*)?$", l)] if m]
@@ -51,9 +52,10 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
     def owner(i):
         k = bisect.bisect_right([a for a, _ in starts], i) - 1
         return starts[k][1] if k >= 0 and any(starts[k][0] < e and i < e for e in ends) else ""
-    norm = [i for i in fused if "materialize_kernel" in owner(i) or "newest_obs_kernel" in owner(i)]
+    readers = ("materialize_kernel", "newest_obs_kernel", "normalize_kernel", "sparse_obs_kernel")
+    norm = [i for i in fused if any(r in owner(i) for r in readers)]
     assert norm and all(re.match(r"\s+v_(pk_fma|fma|fmac|fmamk|fmaak)_f32", device_asm[i]) for i in norm), len(norm)
-    assert {o for o in map(owner, norm)} == {o for _, o in starts if "materialize_kernel" in o or "newest_obs_kernel" in o}
+    assert {o for o in map(owner, norm)} == {o for _, o in starts if any(r in o for r in readers)}
     assert not any("raycast_kernel" in owner(i) and ("0xc0c00000" in device_asm[i] or "0x3e2aaaab" in device_asm[i])
                    for i in fused)
     fused = [i for i in fused if i not in set(norm)]
@@ -66,9 +68,9 @@ def test_fused_multiply_adds_only_inside_division_and_sqrt_expansions(device_asm
 def test_register_budget_and_no_scratch(device_asm):
     text = "\n".join(device_asm)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
-    # move, materialize, newest_obs, head_init, reset, gae, 7 x bw_* (integrate, collide, finish, lidar count / scan x 2 /
+    # move, materialize, newest_obs, normalize, sparse_obs, head_init, reset, gae, 7 x bw_* (integrate, collide, finish, lidar count / scan x 2 /
     # fill), raycast<1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential> + big-world <1|2|4>
-    assert len(kernels) == 21, [k for k, _ in kernels]
+    assert len(kernels) == 23, [k for k, _ in kernels]
     for name, body in kernels:
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
