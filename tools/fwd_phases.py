@@ -25,7 +25,7 @@ for N in [int(a) for a in sys.argv[1:]] or [4096, 16384]:
     b2 = torch.randn(2, 32, device="cuda", generator=g) * 0.1
     out = torch.empty(2, N, 4096, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    args = (obs.data_ptr(), None, N, 3, 512, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), st)
+    args = (obs.data_ptr(), None, 0, N, 3, 512, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), st)
     for _ in range(3):
         _lib.check(lib.mrca_lidar_features(*args), "mrca_lidar_features")
     torch.cuda.synchronize()

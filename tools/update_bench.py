@@ -65,6 +65,21 @@ for bs in sizes:
             loss.backward()
             opt.step()
         out["fwd_bwd_adam_ms_" + ("fused" if fused else "stock")] = timed(step, n=10) * 1e3
+    # the update as mrca.ppo runs it since round 4: HIP front end forward / backward, the PPO loss tail as ONE launch
+    # (policy_ops.ppo_loss: values + gradients), Adam as one multi-tensor launch (fused=True)
+    pol.fused_train = True
+    opt_f = torch.optim.Adam(pol.parameters(), lr=5e-5, fused=True)
+    old_lp = torch.randn(bs, 1, device=dev) * 0.1 - 2.0
+    adv = torch.randn(bs, 1, device=dev)
+    tgt = torch.randn(bs, 1, device=dev)
+
+    def step_round4():
+        mean, v = pol.mean_value(x, g, s)
+        loss, _stats = policy_ops.ppo_loss(mean, v, pol.logstd, a, old_lp, adv, tgt, 0.1, 20.0, 5e-4)
+        opt_f.zero_grad()
+        loss.backward()
+        opt_f.step()
+    out["fwd_bwd_adam_ms_fused_front_end_loss_kernel_fused_adam"] = timed(step_round4, n=10) * 1e3
     print(json.dumps(out))
 
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
