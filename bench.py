@@ -85,7 +85,7 @@ def pmc_traffic(robots, scenario):
     return per_robot * robots, note
 
 
-def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
+def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0, fidelity=False):
     """The CPU port of the path timed on this box's host cores: the plain-C restatement of the oracle
     (oracle/mrca_oracle_c.c, OpenMP over worlds and robots, all cores) on the SAME workload, for a
     bounded number of ticks; the NumPy oracle's single-core figure is reported alongside."""
@@ -102,8 +102,8 @@ def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0):
         usable = max(1, min(usable, int(cpu_limit + 0.999)))
     import util as U
     from mrca import scenario as S
-    sc = S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=0) if sc_name == "stage1" else \
-        S.stage2(num_worlds=worlds, seed=0)
+    sc = S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=0, stage_resolution=fidelity) \
+        if sc_name == "stage1" else S.stage2(num_worlds=worlds, seed=0, stage_resolution=fidelity)
     env = U.COracleEnv(sc)
     env.lib.oc_set_threads(int(os.environ.get("OMP_NUM_THREADS", usable)))   # the OpenMP runtime is already up (torch)
     threads = int(env.lib.oc_max_threads())
@@ -161,6 +161,10 @@ def main():
                                                              "replaying it as one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the rollout/train side figures")
+    ap.add_argument("--fidelity", action="store_true",
+                    help="Stage's own resolutions (worlds/stage1.world:3): 0.2 m map cells, robots collide when their outlines "
+                         "share a 0.2 m raster cell and see each other's bodies through that raster (a side line: `value` of "
+                         "the default run is the exact-rectangle mode on 0.05 m cells)")
     ap.add_argument("--graph", action="store_true",
                     help="env mode: replay the timed ticks as hipGraphs (16 ticks per graph, one per entry of the action pool) "
                          "instead of launching every kernel from the host")
@@ -230,9 +234,10 @@ def main():
     from mrca.vec_env import VecStageWorld
 
     if args.scenario == "stage1":
-        sc = S.stage1(num_worlds=args.worlds, robots_per_world=args.robots_per_world, seed=1000 + rank)
+        sc = S.stage1(num_worlds=args.worlds, robots_per_world=args.robots_per_world, seed=1000 + rank,
+                      stage_resolution=args.fidelity)
     else:
-        sc = S.stage2(num_worlds=args.worlds, seed=1000 + rank)
+        sc = S.stage2(num_worlds=args.worlds, seed=1000 + rank, stage_resolution=args.fidelity)
     env = VecStageWorld(sc)
     N = sc.num_robots
     dev = env.device
@@ -410,7 +415,7 @@ def main():
         # recorded events AROUND each launch, which read ~2.5 us longer per kernel -- their sum exceeded ms_per_step
         ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
         mv_avg_s = (mv_ms / launches) * 1e-3 if launches else float("nan")
-        traffic, traffic_note = pmc_traffic(N, args.scenario)
+        traffic, traffic_note = pmc_traffic(N, args.scenario + ("-fidelity" if args.fidelity else ""))
         achieved = RAY_BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
         tick_achieved = BYTES_PER_AGENT_STEP * N / (ray_avg_s + mv_avg_s) / 1e9 if launches else None
         move_achieved = MOVE_BYTES_PER_AGENT_STEP * N / mv_avg_s / 1e9 if launches else None
@@ -422,7 +427,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scenario}: {args.worlds} worlds x {sc.robots_per_world} robots = {N} "
                                    f"robots/GPU, 512 beams, 3 frames, cell {sc.grid.cell} m, auto-reset, "
-                                   f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}",
+                                   f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}" +
+                                   ("; FIDELITY mode: Stage's resolutions, raster collisions and raster lidar returns of "
+                                    f"robots (collision_raster {sc.collision_raster} m)" if args.fidelity else ""),
                        "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode,
                        "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
                        "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
@@ -463,7 +470,7 @@ def main():
                 "note": "policy FLOPs of one tick / the WHOLE tick time (env kernels, sampling and launch gaps "
                         "included): a lower bound on the policy kernels' own rate; fp32 in, fp32 accumulate"}
         if not args.no_cpu_baseline and world_size == 1:
-            out["cpu_baseline"] = cpu_baseline(args.scenario, args.worlds, args.robots_per_world)
+            out["cpu_baseline"] = cpu_baseline(args.scenario, args.worlds, args.robots_per_world, fidelity=args.fidelity)
             out["cpu_baseline"]["reference_structural_cap"] = "240 agent-steps/s (24 robots x 10 Hz, stageros.cpp:819-828)"
         if per_rank is not None:
             out["per_rank_agent_steps_per_s"] = per_rank      # each rank's own rate on the same per-GPU workload

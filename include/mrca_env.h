@@ -90,7 +90,10 @@ enum mrca_field {
     MRCA_F_SCAN_RING,     /* f32 [N,F,B] the last F scans of every robot (RAW ranges, 0..6 m) as a ring (ABI 4): a tick writes ONE
                            *             row per robot -- the tick's only per-beam store -- logical frame f (0 = oldest) of
                            *             robot n is slot (head[n] + 1 + f) mod F.  (ABI 3 kept a ring of NORMALISED frames
-                           *             next to MRCA_F_SCAN: every beam was stored twice.)                                */
+                           *             next to MRCA_F_SCAN: every beam was stored twice.)  The SIGN BIT of an entry says
+                           *             what the beam hit: set = another robot (ranger_return 0.5, stage1.world:95 -- what
+                           *             stageros turns into LaserScan intensity 0, stageros.cpp:506), clear = the floorplan
+                           *             or nothing (range 6.0); the range is |entry|.  Every library reader takes |x|.    */
     MRCA_F_RING_HEAD,     /* u8  [N]     slot of robot n's newest scan in MRCA_F_SCAN_RING                                */
     MRCA_F_COUNT
 };

@@ -303,6 +303,27 @@ def outline_cells(res, x, y, s, c, f):
     return cells
 
 
+class RasterCells:
+    """A set of raster cells (side ``res``, aligned at the world origin) behind the occupancy protocol ``grid_march``
+    walks: fidelity mode's view of the OTHER robots for a lidar (their outline cells)."""
+
+    def __init__(self, cells, res):
+        self.cell, self.x0, self.y0 = float(res), 0.0, 0.0
+        cells = np.asarray(sorted(cells), np.int64).reshape(-1, 2)
+        self.ix0, self.iy0 = (int(cells[:, 0].min()), int(cells[:, 1].min())) if len(cells) else (0, 0)
+        w = int(cells[:, 0].max()) - self.ix0 + 1 if len(cells) else 1
+        h = int(cells[:, 1].max()) - self.iy0 + 1 if len(cells) else 1
+        self.dense = np.zeros((h, w), bool)
+        if len(cells):
+            self.dense[cells[:, 1] - self.iy0, cells[:, 0] - self.ix0] = True
+
+    def occupied(self, ix, iy):
+        jx = np.asarray(ix, np.int64) - self.ix0
+        jy = np.asarray(iy, np.int64) - self.iy0
+        inb = (jx >= 0) & (jx < self.dense.shape[1]) & (jy >= 0) & (jy < self.dense.shape[0])
+        return inb & self.dense[np.where(inb, jy, 0), np.where(inb, jx, 0)]
+
+
 def obb_overlap(xi, yi, si, ci, xj, yj, sj, cj, dtype):
     """Separating-axis test of two 0.44 x 0.38 rectangles; touching counts as overlap."""
     f = dtype
@@ -707,6 +728,8 @@ class OracleEnv:
         ox = np.broadcast_to(x[:, None], (N, B))
         oy = np.broadcast_to(y[:, None], (N, B))
         rng = grid_march(cfg.grid, ox, oy, dx, dy, f(RANGE_MAX), f)
+        rng_map = rng.copy()
+        self._hit_new = np.zeros((N, B), bool)
         for w in range(cfg.W):
             sl = slice(w * R, (w + 1) * R)
             pts = np.stack([x[sl], y[sl]], 1).astype(np.float64)
@@ -718,6 +741,7 @@ class OracleEnv:
             b = np.concatenate([pairs[:, 1], pairs[:, 0]]) + w * R      # target
             t = ray_box(x[a, None], y[a, None], dx[a], dy[a], x[b, None], y[b, None], s[b, None], c[b, None], f)
             np.minimum.at(rng, a, t)
+        self._hit_new = rng < rng_map
         return np.minimum(rng, f(RANGE_MAX)).astype(f)
 
     # ---------------------------------------------------------------- sensing
@@ -736,6 +760,27 @@ class OracleEnv:
         ox = np.broadcast_to(x[:, None], (N, B))
         oy = np.broadcast_to(y[:, None], (N, B))
         rng = grid_march(cfg.grid, ox, oy, dx, dy, f(RANGE_MAX), f)
+        # what a beam hit: True = another robot closer than the floorplan (ranger_return 0.5 -> LaserScan intensity 0,
+        # stageros.cpp:501-506); the product keeps it in the sign bit of its scan ring
+        self._hit_new = np.zeros((N, B), bool)
+        if cfg.collision_raster > 0:
+            # Fidelity mode: the lidar sees the other robots through the SAME raster they collide on (Stage's ranger walks
+            # the world raster the models are mapped into, worlds/stage1.world:3,94-95): the range is the entry distance of
+            # the first raster cell along the beam that holds a piece of another robot's outline -- the closed-form grid walk
+            # on cells of `collision_raster` metres aligned at the world origin, start cell included (range 0).
+            res = cfg.collision_raster
+            rng = rng.reshape(N, B).copy()
+            for w in range(cfg.W):
+                cells = [outline_cells(res, x[w * R + j], y[w * R + j], s[w * R + j], c[w * R + j], f) for j in range(R)]
+                for i in range(R):
+                    others = set().union(*(cells[j] for j in range(R) if j != i)) if R > 1 else set()
+                    if not others:
+                        continue
+                    n = w * R + i
+                    t = grid_march(RasterCells(others, res), ox[n], oy[n], dx[n], dy[n], f(RANGE_MAX), f)
+                    self._hit_new[n] = t < rng[n]
+                    rng[n] = np.minimum(rng[n], t)
+            return np.minimum(rng, f(RANGE_MAX)).reshape(N, B).astype(f)
         xs, ys = x.reshape(cfg.W, R), y.reshape(cfg.W, R)
         ss, cs = s.reshape(cfg.W, R), c.reshape(cfg.W, R)
         rng = rng.reshape(cfg.W, R, B)
@@ -744,6 +789,7 @@ class OracleEnv:
             tj = ray_box(xs[:, :, None], ys[:, :, None], dxw, dyw,
                          xs[:, j, None, None], ys[:, j, None, None], ss[:, j, None, None], cs[:, j, None, None], f)
             tj[:, j, :] = np.inf
+            self._hit_new |= (tj < rng).reshape(N, B)
             rng = np.minimum(rng, tj)
         return np.minimum(rng, f(RANGE_MAX)).reshape(N, B).astype(f)
 
@@ -751,6 +797,7 @@ class OracleEnv:
         f = self.f
         upd = fresh if only_fresh else np.ones(self.N, bool)
         self.scan = np.where(upd[:, None], self.raycast(), self.scan).astype(f)
+        self.hit_robot = np.where(upd[:, None], self._hit_new, getattr(self, "hit_robot", np.zeros_like(self._hit_new)))
         # stage_world1.py:122-140: NaN/inf -> 6, identity sub-sampling at 512 beams, scan/6 - 0.5
         new = (self.scan / f(6.0) - f(0.5)).astype(f)
         F = self.cfg.frames

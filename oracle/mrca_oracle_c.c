@@ -41,6 +41,7 @@ typedef struct {
                             * (dead, ppo_stage2.py:72-74) keeps driving, and the odom twist survives a teleport */
     int32_t first_world;
     float raster_res; /* fidelity mode: > 0 = robots collide when their outlines share a raster cell of this size */
+    uint8_t* hit_robot; /* [N,B] or NULL: 1 where the beam returned from another robot (closer than the floorplan) */
 } oc_env;
 
 
@@ -230,6 +231,51 @@ static int oc_outline_cells(float res, float x, float y, float s, float c, int64
     return n;
 }
 
+/* Fidelity mode, lidar: the other robots as the lidar of robot n sees them -- through the raster they collide on.  A window
+ * of raster cells around the robot's own cell (every cell a 6 m beam can enter) holds a bit per cell that carries a piece
+ * of another robot's outline; a beam walks the raster with the same closed-form boundary times and returns the entry
+ * distance of the first marked cell (0 when it starts in one).  [Stage's ranger walks the world raster the models are mapped
+ * into -- SURVEY Appendix B; restated.] */
+typedef struct {
+    int ix0, iy0, side;     /* lower-left cell of the window, cells per side */
+    uint8_t* bit;           /* side * side bytes */
+} oc_window;
+
+static int oc_win_get(const oc_window* w, int ix, int iy) {
+    const int jx = ix - w->ix0, jy = iy - w->iy0;
+    if (jx < 0 || jy < 0 || jx >= w->side || jy >= w->side) return 0;
+    return w->bit[(size_t)jy * w->side + jx];
+}
+
+static void oc_win_mark(oc_window* w, const int64_t* cells, int n) {
+    for (int k = 0; k < n; ++k) {
+        const int jx = (int)(cells[k] >> 32) - w->ix0, jy = (int)(int32_t)(uint32_t)cells[k] - w->iy0;
+        if (jx >= 0 && jy >= 0 && jx < w->side && jy < w->side) w->bit[(size_t)jy * w->side + jx] = 1;
+    }
+}
+
+static float oc_raster_march(const oc_window* w, float res, float ox, float oy, float dx, float dy, float tmax) {
+    const float inv = 1.0f / res;
+    const float fx = ox * inv, fy = oy * inv;
+    int ix = (int)floorf(fx), iy = (int)floorf(fy);
+    const float tmax_c = tmax * inv;
+    if (oc_win_get(w, ix, iy)) return 0.0f;
+    if (!(tmax_c > 0.0f)) return tmax;
+    const int xnz = dx != 0.0f, ynz = dy != 0.0f;
+    const float inv_dx = xnz ? 1.0f / dx : INFINITY, inv_dy = ynz ? 1.0f / dy : INFINITY;
+    const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
+    int bx = dx > 0.0f ? ix + 1 : ix, by = dy > 0.0f ? iy + 1 : iy;
+    float tx = xnz ? ((float)bx - fx) * inv_dx : INFINITY;
+    float ty = ynz ? ((float)by - fy) * inv_dy : INFINITY;
+    for (;;) {
+        float t;
+        if (tx < ty) { t = tx; ix += sx; bx += sx; tx = ((float)bx - fx) * inv_dx; }
+        else { t = ty; iy += sy; by += sy; ty = ynz ? ((float)by - fy) * inv_dy : INFINITY; }
+        if (t >= tmax_c) return tmax;
+        if (oc_win_get(w, ix, iy)) return t * res;
+    }
+}
+
 static int oc_cells_meet(const int64_t* a, int na, const int64_t* b, int nb) {
     for (int i = 0; i < na; ++i)
         for (int j = 0; j < nb; ++j)
@@ -358,14 +404,35 @@ void oc_observe(const oc_env* e, int only_fresh) {
             oc_sincos(e->pose[m * 3 + 2], &nb[cnt * 4 + 2], &nb[cnt * 4 + 3]);
             ++cnt;
         }
+        /* fidelity mode: the other robots' outline cells in a window of raster cells around this robot */
+        const int raster = e->raster_res > 0.0f && !lidar_hash;
+        oc_window win = {0, 0, 0, 0};
+        if (raster) {
+            const float inv = 1.0f / e->raster_res;
+            const int reach = (int)ceilf(RANGE_MAX * inv) + 2;
+            win.ix0 = (int)floorf(x * inv) - reach;
+            win.iy0 = (int)floorf(y * inv) - reach;
+            win.side = 2 * reach + 1;
+            win.bit = (uint8_t*)calloc((size_t)win.side * win.side, 1);
+            for (int k = 0; k < cnt; ++k) {
+                int64_t cells[OC_MAX_CELLS];
+                oc_win_mark(&win, cells, oc_outline_cells(e->raster_res, nb[k * 4], nb[k * 4 + 1], nb[k * 4 + 2], nb[k * 4 + 3], cells));
+            }
+        }
         for (int b = 0; b < e->B; ++b) {
             const float bc = e->beam_cos[b], bs = e->beam_sin[b];
             const float dx = c * bc - s * bs, dy = s * bc + c * bs;
             float rng = oc_march(e, x, y, dx, dy, RANGE_MAX);
+            const float rng_map = rng;
+            if (raster) {
+                const float t = oc_raster_march(&win, e->raster_res, x, y, dx, dy, RANGE_MAX);
+                if (t < rng) rng = t;
+            } else
             for (int k = 0; k < cnt; ++k) {
                 float t = oc_ray_box(x, y, dx, dy, nb[k * 4], nb[k * 4 + 1], nb[k * 4 + 2], nb[k * 4 + 3]);
                 if (t < rng) rng = t;
             }
+            if (e->hit_robot) e->hit_robot[(size_t)n * e->B + b] = rng < rng_map;
             if (!(rng < RANGE_MAX)) rng = RANGE_MAX;
             e->scan[(size_t)n * e->B + b] = rng;
             const float o = rng / 6.0f - 0.5f;
@@ -380,6 +447,7 @@ void oc_observe(const oc_env* e, int only_fresh) {
         e->local_goal[n * 2] = gx * c + gy * s;
         e->local_goal[n * 2 + 1] = gy * c - gx * s;
         if (lidar_hash) free(nb);
+        free(win.bit);
     }
     oc_hash_free(lidar_hash);
 }

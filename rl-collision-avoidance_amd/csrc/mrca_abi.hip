@@ -421,6 +421,16 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.key1 = (uint32_t)(cfg->seed >> 32);
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.raster_inv = cfg->collision_raster > 0.0f ? 1.0f / cfg->collision_raster : 0.0f;
+    v.raster_res = cfg->collision_raster;
+    v.lidar_radius = 0.2917f;
+    v.lidar_near = 0.30f;
+    v.lidar_reach2 = mrca::kLidarReach2;
+    if (cfg->collision_raster > 0.0f) {      // outline CELLS reach one cell diagonal beyond the rectangle
+        v.lidar_radius = 0.2917f + 1.4143f * cfg->collision_raster;
+        v.lidar_near = v.lidar_radius + 0.01f;
+        const float reach = 6.0f + v.lidar_radius + 0.01f;
+        v.lidar_reach2 = reach * reach;
+    }
     {   // broad phase: rectangles further apart than 2 x circumradius cannot overlap; outlines further apart than that
         // plus one raster-cell diagonal cannot share a cell
         const float reach = 2.0f * 0.2907f + 0.001f + (cfg->collision_raster > 0.0f ? 1.4143f * cfg->collision_raster : 0.0f);

@@ -644,14 +644,18 @@ MRCA_HD float atan2_approx(float y, float x) {
 
 // step = kPi / (beams - 1) and inv_step = (beams - 1) / kPi as fp32 quotients: the same for every robot and beam, so the
 // kernel takes them from the host (two IEEE divisions, ~24 VALU instructions, per neighbour candidate otherwise)
-MRCA_HD void beam_interval(float lx, float ly, int beams, float step, float inv_step, int* lo, int* hi) {
+// `radius`: what the other robot lies inside of, seen from its centre -- the circumscribed circle of the rectangle + 1 mm
+// (0.2917 m), or, in fidelity mode, that plus one raster-cell diagonal (its outline CELLS); `near`: centre distances up
+// to which every beam is kept (0.30 m / radius + 0.01 m).
+MRCA_HD void beam_interval(float lx, float ly, int beams, float step, float inv_step, float radius, float near, int* lo,
+                           int* hi) {
     const float dist = sqrtf(lx * lx + ly * ly);
-    if (dist <= 0.30f) {
+    if (dist <= near) {
         *lo = 0;
         *hi = beams - 1;
         return;
     }
-    float ratio = 0.2917f / dist;
+    float ratio = radius / dist;
     ratio = ratio < 1.0f ? ratio : 1.0f;
     const float alpha = (ratio + 0.5708f * (ratio * ratio * ratio)) + 2.0f * step + 3e-3f;
     const float phi = atan2_approx(ly, lx);
@@ -662,8 +666,26 @@ MRCA_HD void beam_interval(float lx, float ly, int beams, float step, float inv_
     *hi = h > beams - 1 ? beams - 1 : h;
 }
 MRCA_HD void beam_interval(float lx, float ly, int beams, int* lo, int* hi) {
-    beam_interval(lx, ly, beams, kPi / (float)(beams - 1), (float)(beams - 1) / kPi, lo, hi);
+    beam_interval(lx, ly, beams, kPi / (float)(beams - 1), (float)(beams - 1) / kPi, 0.2917f, 0.30f, lo, hi);
 }
+
+// ------------------------------------------------------------------------------------------
+// Fidelity mode, lidar: the other robots as Stage's ranger sees them -- through the world raster they are mapped into
+// (worlds/stage1.world:3 `resolution 0.2`, :94-95 `ranger_return`) [libstage; restated].  A window of
+// raster cells around the robot's own cell -- every cell a 6 m beam can enter -- holds one bit per cell that carries a
+// piece of another robot's outline (outline_cells' walk); a beam walks the raster with grid_march's closed-form boundary
+// times (raster aligned at the world origin: GridGeom{0, 0, res, 1 / res}) and its range is the entry distance of the first
+// marked cell, 0 when it starts in one.
+struct RasterWindow {
+    const uint32_t* bits;      // [side][wpr]
+    int32_t ix0, iy0, side, wpr;
+    MRCA_HD bool operator()(int ix, int iy) const {
+        const int jx = ix - ix0, jy = iy - iy0;
+        if ((unsigned)jx >= (unsigned)side || (unsigned)jy >= (unsigned)side) return false;
+        return (bits[jy * wpr + (jx >> 5)] >> (jx & 31)) & 1u;
+    }
+};
+MRCA_HD int raster_window_reach(float inv_res) { return (int)ceilf(kRangeMax * inv_res) + 2; }   // cells either side
 
 // ------------------------------------------------------------------------------------------
 // Spatial hashes of the big-world broad phase (worlds with more than 64 robots).  A point goes to the cell

@@ -77,6 +77,11 @@ struct EnvView {
     int32_t hold_velocity;  // 1: Stage's SetSpeed persistence (dead robots keep driving, speed survives a reset)
     uint32_t key0, key1;
     float raster_inv;     // fidelity mode: 1 / collision_raster (0 = exact rectangles), see mrca_device.h outline_cells
+    float raster_res;     // collision_raster itself (fidelity mode: the lidar sees the other robots through this raster too)
+    // the ray cast's neighbour culls: what another robot lies inside of seen from its centre (circumradius + 1 mm; in
+    // fidelity mode + one raster-cell diagonal), the centre distance below which every beam is kept, and the squared centre
+    // distance beyond which it cannot return a range below 6 m
+    float lidar_radius, lidar_near, lidar_reach2;
     float collide_reach2; // squared centre distance beyond which two robots cannot collide (broad phase)
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
     int32_t ray_shift;    // raycast_kernel marches 1 << ray_shift beams per thread in lock step

@@ -145,9 +145,11 @@ struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
 // wants -- MRCA_F_SCAN (the newest scan, contiguous) and MRCA_F_OBS (the normalised stack in deque order, what
 // CNNPolicy.forward eats) -- on demand (mrca_materialize) or after every call when the env was created with
 // lazy_obs = 0.  A thread owns float4 columns of robots [ray_first, ray_first + ray_count).
+// (the ring's SIGN BIT says what a beam hit -- set: another robot -- so every reader of a range takes |x|: a source modifier)
 __device__ __forceinline__ float4 norm_obs4(float4 v) {
-    return make_float4(norm_obs(v.x), norm_obs(v.y), norm_obs(v.z), norm_obs(v.w));
+    return make_float4(norm_obs(fabsf(v.x)), norm_obs(fabsf(v.y)), norm_obs(fabsf(v.z)), norm_obs(fabsf(v.w)));
 }
+__device__ __forceinline__ float4 fabs4(float4 v) { return make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)); }
 
 __global__ void materialize_kernel(EnvView e, int what) {
     const int fstride = e.B >> 2;
@@ -162,7 +164,7 @@ __global__ void materialize_kernel(EnvView e, int what) {
         const int hd = e.ring_head[e.ray_first + r];
         const float4* src = ring + r * e.F * fstride + col;
         const float4 newest = src[hd * fstride];
-        if (what & 1) scan[r * fstride + col] = newest;
+        if (what & 1) scan[r * fstride + col] = fabs4(newest);
         if (what & 2) {
             float4* dst = out + r * e.F * fstride + col;
             if (e.F == 3) {
@@ -211,7 +213,7 @@ __global__ void sparse_obs_kernel(EnvView e, const int32_t* __restrict__ index, 
         const int hd = e.ring_head[r];
         int slot = hd + 1 + f;
         slot -= slot >= e.F ? e.F : 0;
-        out[k] = norm_obs(e.scan_ring[((size_t)r * e.F + slot) * e.B + index[j]]);
+        out[k] = norm_obs(fabsf(e.scan_ring[((size_t)r * e.F + slot) * e.B + index[j]]));
     }
 }
 
@@ -698,6 +700,11 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(nb_count + 4);   // [B] neighbours per beam
     int* nb_more = nb_count + 1;                                      // big worlds: another chunk of neighbours follows
+    // fidelity mode (never in big worlds): the window of raster cells holding the other robots' outlines
+    const bool raster = !BIG && e.raster_inv > 0.0f;                  // block-uniform
+    uint32_t* win_bits = reinterpret_cast<uint32_t*>(nbmask + e.B);
+    const int win_reach = raster ? raster_window_reach(e.raster_inv) : 0;
+    const int win_side = 2 * win_reach + 1, win_wpr = (win_side + 31) >> 5;
 
     const int T = e.B / K;                    // marching threads
     const bool extra = (int)blockDim.x > T;   // a dedicated preparation wave sits behind the marching ones
@@ -773,7 +780,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
                 if (hash_cell_coord(cxj, kLidarCell) == qx && hash_cell_coord(cyj, kLidarCell) == qy) {
                     const float ddx = cxj - x, ddy = cyj - y;
                     if (ddx * ddx + ddy * ddy <= kLidarReach2) {
-                        beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, e.beam_step, e.beam_inv_step, &lo, &hi);
+                        beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, e.beam_step, e.beam_inv_step, e.lidar_radius,
+                                      e.lidar_near, &lo, &hi);
                         keep = lo <= hi;
                         if (keep) chj = e.head[j];
                     }
@@ -806,11 +814,13 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
       } else {
         for (int b = pl; b < e.B; b += kWave) nbmask[b] = 0ull;
         const float ddx = xj - x, ddy = yj - y;
-        // conservative cull: a hit below 6 m needs the centre within 6 + circumradius(0.2907) m
-        bool keep = cand && (ddx * ddx + ddy * ddy <= 39.69f);
+        // conservative cull: a hit below 6 m needs the centre within 6 + circumradius(0.2907) m (fidelity mode: + one
+        // raster-cell diagonal -- what is tested there are the robot's outline CELLS)
+        bool keep = cand && (ddx * ddx + ddy * ddy <= e.lidar_reach2);
         int lo = 0, hi = -1;
         if (keep) {
-            beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, e.beam_step, e.beam_inv_step, &lo, &hi);
+            beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, e.beam_step, e.beam_inv_step, e.lidar_radius, e.lidar_near,
+                          &lo, &hi);
             keep = lo <= hi;
         }
         const unsigned long long m = __ballot(keep);
@@ -828,16 +838,42 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             const int2 iv = nbi[k];
             for (int b = iv.x + pl; b <= iv.y; b += kWave) mask_or(&nbmask[b], 1ull << k);
         }
+        if (raster) {
+            // fidelity mode: lane k rasterises neighbour k's outline into the window (the LDS operations of ONE wave
+            // complete in order: the clear, the list above and the marks below need no barrier between them)
+            for (int q = pl; q < win_side * win_wpr; q += kWave) win_bits[q] = 0u;
+            if (pl < cnt0) {
+                const float4 nbq = nb[pl];
+                const int wx0 = (int)floorf(x * e.raster_inv) - win_reach, wy0 = (int)floorf(y * e.raster_inv) - win_reach;
+                for (int k = 0; k < 4; ++k) {       // the four edges, as in outline_cells
+                    const float hx = (k == 0 || k == 3) ? kHalfLen : -kHalfLen;
+                    const float hy = (k < 2) ? kHalfWid : -kHalfWid;
+                    const float ex = (k == 0) ? -nbq.w : (k == 1) ? nbq.z : (k == 2) ? nbq.w : -nbq.z;
+                    const float ey = (k == 0) ? -nbq.z : (k == 1) ? -nbq.w : (k == 2) ? nbq.z : nbq.w;
+                    const float el = (k & 1) ? 2.0f * kHalfWid : 2.0f * kHalfLen;
+                    const float cx = nbq.x + (hx * nbq.w - hy * nbq.z);
+                    const float cy = nbq.y + (hx * nbq.z + hy * nbq.w);
+                    walk_cells(e.raster_inv, cx, cy, ex, ey, el, [&](int ix, int iy) {
+                        const int jx = ix - wx0, jy = iy - wy0;
+                        if ((unsigned)jx < (unsigned)win_side && (unsigned)jy < (unsigned)win_side)
+                            (void)__hip_atomic_fetch_or(&win_bits[jy * win_wpr + (jx >> 5)], 1u << (jx & 31), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                    });
+                }
+            }
+        }
       }
     }
     MRCA_RSTAMP(2);     // wave 0: neighbour list and per-beam masks built
     // --- the march: K beams per thread in lock step
     float dx[K], dy[K], rng[K];
+    bool from_robot[K];        // the range is a return from another robot (ranger_return 0.5: LaserScan intensity 0)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         dx[k] = c * bc[k] - s * bs[k];
         dy[k] = s * bc[k] + c * bs[k];
         rng[k] = kRangeMax;
+        from_robot[k] = false;
     }
     if (marches && !MRCA_DBG(e, 2)) {
         const FreeRectField field{e.free_rect, e.g.width, e.g.height, e.free_rect_pitch};
@@ -870,12 +906,25 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
                 const int b = tid + k * T;
                 float r = rng[k];
                 unsigned long long m = cnt > 0 ? nbmask[b] : 0ull;
-                while (m) {
-                    const int q = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const float4 nbq = nb[q];
-                    const float t = ray_box(x, y, dx[k], dy[k], nbq.x, nbq.y, nbq.z, nbq.w);
-                    r = t < r ? t : r;
+                if (raster) {
+                    // fidelity mode: walk the raster window; a beam no neighbour's cells can touch skips the walk
+                    if (m) {
+                        const RasterWindow win{win_bits, (int)floorf(x * e.raster_inv) - win_reach,
+                                               (int)floorf(y * e.raster_inv) - win_reach, win_side, win_wpr};
+                        const GridGeom gr{0.0f, 0.0f, e.raster_res, e.raster_inv, 0, 0, 0};
+                        const float t = grid_march(win, gr, x, y, dx[k], dy[k], kRangeMax);
+                        from_robot[k] = from_robot[k] || t < r;
+                        r = t < r ? t : r;
+                    }
+                } else {
+                    while (m) {
+                        const int q = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const float4 nbq = nb[q];
+                        const float t = ray_box(x, y, dx[k], dy[k], nbq.x, nbq.y, nbq.z, nbq.w);
+                        from_robot[k] = from_robot[k] || t < r;
+                        r = t < r ? t : r;
+                    }
                 }
                 rng[k] = r;
             }
@@ -898,13 +947,16 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int b = tid + k * T;
-            const float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
-            // (nontemporal: the 8.4 MB of rows a launch writes are not read again by it -- they should not push the
-            // free-rectangle field, which every workgroup reads, out of the XCD's L2)
+            float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
+            // what the beam hit rides in the sign bit (a range is never negative): set = another robot.  stageros casts
+            // Stage's return value to uint8 for LaserScan.intensities (stageros.cpp:506): 1 floorplan, 0 robot or miss.
+            r = (from_robot[k] && rng[k] < kRangeMax) ? -r : r;
+            // (plain stores: nontemporal ones were measured in round 4 -- FETCH_SIZE 2502 vs 2504 KiB per launch, the
+            // free-rectangle field is not what the rows evict -- and the policy's front end reads these rows next)
             if (fresh) {     // deque([obs] * F), ppo_stage1.py:59-60: every slot, the head stays where it is
-                for (int f = 0; f < e.F; ++f) __builtin_nontemporal_store(r, &ring_row[f * e.B + b]);
+                for (int f = 0; f < e.F; ++f) ring_row[f * e.B + b] = r;
             } else {
-                __builtin_nontemporal_store(r, &ring_row[new_slot * e.B + b]);
+                ring_row[new_slot * e.B + b] = r;
             }
         }
         if (tid == 0 && !fresh) e.ring_head[n] = (uint8_t)new_slot;
@@ -1284,7 +1336,12 @@ void read_move_stamps(unsigned long long* host, int worlds) {      // [kMoveStam
 
 
 size_t ray_lds_bytes(const EnvView& e) {
-    return kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 8;
+    size_t b = kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 8;
+    if (e.raster_inv > 0.0f && !e.big) {       // fidelity mode: the window of raster cells with the other robots' outlines
+        const int side = 2 * raster_window_reach(e.raster_inv) + 1;
+        b += (size_t)side * ((side + 31) / 32) * sizeof(uint32_t);
+    }
+    return b;
 }
 
 size_t move_lds_bytes(const EnvView& e) {

@@ -21,8 +21,10 @@ Semantics kept from stageros that the per-index facade (mrca/stage_world.py) sim
 until the next cmd_vel (Stage keeps it), and the watchdog is GLOBAL: when no robot at all has sent a cmd_vel for
 ``base_watchdog_timeout`` = 0.2 s of simulated time every robot is stopped (``:318-320,466-471``).
 
-Not restated: ``intensities`` (Stage's per-beam return value cast to uint8: 1 for walls, 0 for robots and misses; the env
-does not record what a beam hit -- zeros), tf broadcasts, camera topics (no camera in any world of the reference).
+``intensities`` are Stage's per-beam return value cast to uint8 (``:501-506``): 1 for the floorplan (``ranger_return``
+default 1), 0 for another robot (``ranger_return 0.5``, worlds/stage1.world:95) and for a miss -- from the backend's
+``hit_robot`` field (the sign bit of the device's scan ring).  Not restated: tf broadcasts, camera topics (no camera in any
+world of the reference).
 """
 import math
 from dataclasses import dataclass, field
@@ -176,6 +178,13 @@ class StageBridge:
         speed = np.asarray(b.field("speed"), np.float64)
         scan = np.asarray(b.field("scan"), np.float32)
         crashed = np.asarray(b.field("crashed"))
+        # intensities: Stage's return value of what the beam hit, cast to uint8 (stageros.cpp:501-506): the floorplan's 1
+        # survives, a robot's 0.5 (ranger_return, stage1.world:95) and a miss become 0
+        try:
+            from_robot = np.asarray(b.field("hit_robot")).astype(bool)
+        except AttributeError:
+            from_robot = np.zeros(scan.shape, bool)
+        intensity = ((scan < np.float32(RANGE_MAX)) & ~from_robot).astype(np.float32)
         now = self.sim_time
         out = {}
         prev = self.base_last_globalpos
@@ -183,7 +192,7 @@ class StageBridge:
             x, y, a = (float(v) for v in pose[r])
             out[self.map_name("base_scan", r)] = LaserScan(
                 Header(now, self.map_name("base_laser_link", r)), -FOV / 2.0, FOV / 2.0, FOV / (self.samples - 1),
-                RANGE_MIN, RANGE_MAX, scan[r].astype(np.float32), np.zeros(self.samples, np.float32))
+                RANGE_MIN, RANGE_MAX, scan[r].astype(np.float32), intensity[r])
             out[self.map_name("odom", r)] = Odometry(
                 Header(now, self.map_name("odom", r)), Pose(Vector3(x, y, 0.0), quaternion_from_yaw(a)),
                 Twist(Vector3(float(speed[r, 0]), 0.0, 0.0), Vector3(0.0, 0.0, float(speed[r, 1]))))

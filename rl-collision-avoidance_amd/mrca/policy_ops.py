@@ -5,6 +5,7 @@ hand-written fp32 MFMA kernels instead of MIOpen.  The rest of the policy stays 
 There is no fallback: without the HIP library these raise."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -36,7 +37,8 @@ def normalize_scans(scans):
     RN(1/6).  CPU tensors (the tests' stand-ins) take numpy's correctly rounded quotient, which equals the kernel's
     result."""
     if not scans.is_cuda:
-        return torch.from_numpy(scans.numpy() / scans.numpy().dtype.type(6.0) - scans.numpy().dtype.type(0.5))
+        a = np.abs(scans.numpy())           # (the ring's sign bit says what a beam hit: the range is |x|)
+        return torch.from_numpy(a / a.dtype.type(6.0) - a.dtype.type(0.5))
     x = scans.contiguous()
     if x.dtype != torch.float32 or x.numel() % 4:
         raise ValueError("normalize_scans: expected a float32 tensor with a multiple of 4 elements")

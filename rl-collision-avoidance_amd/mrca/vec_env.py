@@ -116,6 +116,14 @@ class VecStageWorld:
         return self._view(_lib.VIEW_OBS, self._obs)
 
     @property
+    def hit_robot(self):
+        """bool[N,B]: beam b of robot n returned from ANOTHER ROBOT (the sign bit of the newest scan's ring entry; clear =
+        the floorplan or no return).  stageros publishes it as LaserScan.intensities: 1 floorplan, 0 robot or miss
+        (stageros.cpp:501-506, ranger_return 0.5 cast to uint8)."""
+        ar = torch.arange(self.N, device=self.device)
+        return torch.signbit(self.scan_ring[ar, self.ring_head.long()])
+
+    @property
     def _obs_current(self):
         return bool(self._views_current)
 

@@ -54,7 +54,14 @@ def test_published_fields_follow_stageros():
         assert (ls.range_min, ls.range_max) == (0.0, 6.0)              # worlds/stage1.world:13
         assert ls.ranges.dtype == np.float32 and ls.ranges.shape == (512,)      # float32[] on the wire (:505)
         assert np.array_equal(ls.ranges, backend.field("scan")[r]) and float(ls.ranges.max()) <= 6.0
-        assert ls.intensities.shape == (512,)
+        # intensities: 1 where the beam returned from the floorplan, 0 for another robot (ranger_return 0.5 cast to uint8,
+        # stageros.cpp:506) and for a miss
+        assert ls.intensities.shape == (512,) and ls.intensities.dtype == np.float32
+        rob = np.asarray(backend.field("hit_robot"))[r].astype(bool)
+        assert np.array_equal(ls.intensities, ((ls.ranges < 6.0) & ~rob).astype(np.float32))
+        assert set(np.unique(ls.intensities)) <= {0.0, 1.0}
+        assert np.asarray(backend.field("hit_robot")).any() and any(
+            (out[f"/robot_{q}/base_scan"].intensities == 1.0).any() for q in range(24))   # both kinds of return occur
         assert ls.header.frame_id == f"/robot_{r}/base_laser_link" and ls.header.stamp == pytest.approx(0.1)
         od = out[f"/robot_{r}/odom"]                                   # :543-558
         assert (od.pose.position.x, od.pose.position.y, od.pose.position.z) == (pose[r, 0], pose[r, 1], 0.0)

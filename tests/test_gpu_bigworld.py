@@ -41,6 +41,7 @@ def _exact(hip, sc, steps, seed, poses=None, check_every=4, actions=None):
         if k % check_every == check_every - 1 or k == steps - 1:
             torch.cuda.synchronize()
             U.assert_state_equal(U.HostView(env), ora, what=f"{sc.name} step {k}")
+            U.assert_hits_equal(env, ora, what=f"{sc.name} step {k}")
     env.check()          # mrca_check: the ordered collision pass never gave up on a robot
     env.close()
     return ora

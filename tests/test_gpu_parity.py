@@ -47,6 +47,7 @@ def _run_exact(hip, sc, steps, seed, check_every=1):
         if k % check_every == 0 or k == steps - 1:
             torch.cuda.synchronize()
             U.assert_state_equal(U.HostView(env), ora, what=f"{sc.name} step {k}")
+            U.assert_hits_equal(env, ora, what=f"{sc.name} step {k}")
     env.close()
     return ora
 

@@ -33,6 +33,14 @@ def test_c_oracle_stage2_hold_velocity():
     _run(S.stage2(num_worlds=1, seed=6, hold_velocity=True), 90, 2, every=6)      # first group restart at step 46
 
 
+def test_c_oracle_fidelity_mode_with_the_raster_lidar():
+    """Stage's own resolutions: 0.2 m map cells, robots collide when their outlines share a 0.2 m raster cell AND are seen
+    by each other's lidar through that raster (the C oracle marks a window of cells per robot, the NumPy oracle walks the
+    full set: bit-identical)."""
+    _run(S.stage1(num_worlds=2, robots_per_world=12, seed=3, stage_resolution=True), 40, 5, every=4)
+    _run(S.stage2(num_worlds=1, seed=2, stage_resolution=True), 24, 6, every=6)
+
+
 def test_c_oracle_circle():
     _run(S.circle(num_worlds=1, seed=1), 15, 3)
 

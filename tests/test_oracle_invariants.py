@@ -96,6 +96,34 @@ def test_lidar_sees_other_robots_but_not_self():
         assert env.scan[1].min() == 6.0                 # robot 1 looks away from robot 0
 
 
+def test_fidelity_mode_lidar_sees_other_robots_through_the_raster():
+    """collision_raster = 0.2 m (worlds/stage1.world:3): the lidar walks the raster the robots are mapped into -- the range
+    of a beam that meets another robot is the ENTRY distance of the first 0.2 m cell holding a piece of its outline
+    (quantised to the raster like Stage's ranges, up to one cell diagonal short of the analytic distance, never beyond
+    it), a robot sharing the lidar's own cell reads 0, beams that miss every outline cell keep their map range."""
+    sc = _open_world(R=3, collision_raster=0.2)
+    exact = _open_world(R=3)
+    for f in (np.float32, np.float64):
+        env, ref = U.oracle_env(sc, f), U.oracle_env(exact, f)
+        poses = [[0.03, 0.04, 0.0], [3.03, 0.04, 0.0], [-5.0, -7.0, 0.3]]
+        goals = [[0, 5], [3, 5], [0, 0]]
+        _place(env, poses, goals)
+        _place(ref, poses, goals)
+        fwd, ana = float(env.scan[0, 255]), float(ref.scan[0, 255])
+        assert abs(ana - (3.0 - 0.22)) < 1e-3
+        # the rear outline of robot 1 (x = 2.81) lies in the raster column [2.8, 3.0): entered at x = 2.8
+        assert abs(fwd - (2.8 - 0.03)) < 2e-3 and ana - 0.2 * 1.4143 <= fwd <= ana + 1e-6
+        hit_r, hit_a = env.scan[0] < 6.0, ref.scan[0] < 6.0
+        assert hit_a.sum() >= 20 and (hit_r | ~hit_a).all()       # every analytic hit is a raster hit (the cells cover the outline)
+        assert hit_r.sum() <= hit_a.sum() + 40                    # ... and the raster adds at most a cell's worth of beams
+        assert (env.scan[0][hit_r & hit_a] <= ref.scan[0][hit_r & hit_a] + 1e-6).all()
+        assert env.scan[1].min() == 6.0 and np.array_equal(env.scan[2], ref.scan[2])   # looking away / nobody in range: the map only
+        # two robots whose outlines share the lidar's own cell: every beam the cull keeps starts inside a marked cell
+        near = [[0.03, 0.04, 0.0], [0.41, 0.04, 0.0], [-5.0, -7.0, 0.3]]      # rear face at x = 0.19: the lidar's own column
+        _place(env, near, goals)
+        assert env.scan[0, 255] == 0.0
+
+
 def test_two_robots_head_on_collide_in_robot_order():
     """Gap between footprints 0.06 m, both advance 0.05 m: robot 0 moves first (free), robot 1
     then overlaps robot 0's NEW pose -> reverts and stalls; next tick robot 0 stalls too."""

@@ -196,6 +196,15 @@ def assert_state_equal(a, b, fields=STATE_FIELDS, what=""):
                                  f"{x[i]!r} vs {y[i]!r}")
 
 
+def assert_hits_equal(env, ora, what=""):
+    """What every beam hit: the device's flag (sign bit of its scan ring: another robot) against the oracle's."""
+    got = env.hit_robot.cpu().numpy()
+    want = np.asarray(ora.hit_robot).astype(bool)
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError(f"{what}: hit_robot differs at {len(bad)} of {got.size} beams; first {tuple(bad[0])}")
+
+
 class HostView:
     """Host copy of a VecStageWorld's state (optionally a slice of robots)."""
 
@@ -223,7 +232,7 @@ class OracleBackend:
 
 # ------------------------------------------------------------------------------------------------
 class _OcEnvStruct(C.Structure):
-    _fields_ = _EmulEnvStruct._fields_ + [("first_world", C.c_int32), ("raster_res", C.c_float)]
+    _fields_ = _EmulEnvStruct._fields_ + [("first_world", C.c_int32), ("raster_res", C.c_float), ("hit_robot", C.c_void_p)]
 
 
 _oc_lib = None
@@ -255,6 +264,8 @@ class COracleEnv(EmulEnv):
             setattr(st, name, getattr(self._st, name))
         st.first_world = first_world
         st.raster_res = float(getattr(sc, "collision_raster", 0.0))
+        self.hit_robot = np.zeros((sc.num_robots, sc.beams), np.uint8)     # 1: the beam returned from another robot
+        st.hit_robot = self.hit_robot.ctypes.data
         self._st = st
 
     def reset(self, mask=None, poses=None, goals=None):

@@ -17,6 +17,8 @@
 #   prof_bigworld    rocprofv3 --kernel-trace --stats of tools/bigworld_bench.py (BIGWORLD_ARGS: robot counts)
 #   circle           mrca.evaluate of the committed checkpoints (POLICY=... overrides)
 #   train            tools/train_recipe.sh (TRAIN_ARGS / S1_SECONDS / S2_SECONDS)
+#   ldsprobe         tools/lds_conflict_probe: SQ_LDS_BANK_CONFLICT of the policy front end's LDS access patterns, one by one
+#   fidelity         bench.py --fidelity (Stage's resolutions, raster collisions + raster lidar): stage1 and stage2 lines
 #   boundary         tools/launch_boundary (device-side stamps: eager vs hipGraph) + its rocprofv3 kernel trace through
 #                    tools/trace_gaps.py; bench.py env mode eager and --graph; rocprofv3 trace of both with the gaps
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -104,6 +106,17 @@ for STAGE in "$@"; do
       done ;;
     train)
       bash tools/train_recipe.sh "$O" ;;
+    ldsprobe)
+      [ -x tools/_build/lds_conflict_probe ] || hipcc --offload-arch=gfx950 -O3 tools/lds_conflict_probe.hip -o tools/_build/lds_conflict_probe
+      timeout 120 tools/_build/lds_conflict_probe > "$O/lds_conflict_probe.txt" 2>&1; cat "$O/lds_conflict_probe.txt"
+      cd /tmp
+      timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE --output-format csv -d "$O/ldsprobe" -o p -- "$R/tools/_build/lds_conflict_probe" > "$O/ldsprobe.log" 2>&1; echo "pmc rc=$?"
+      cd "$R"
+      python tools/pmc_summary.py "$O/ldsprobe" > "$O/lds_conflict_probe_counters.txt" 2>&1; grep -E "stage_scan|conv[12]_" "$O/lds_conflict_probe_counters.txt" | cut -c1-160
+      rm -rf "$O/ldsprobe" ;;
+    fidelity)
+      timeout 600 python bench.py --steps 1000 --warmup 100 --fidelity --no-extra > "$O/bench_env_fidelity.json" 2>> "$O/bench.err"; echo "fidelity rc=$?"; cut -c1-400 "$O/bench_env_fidelity.json"
+      timeout 600 python bench.py --steps 500 --warmup 50 --fidelity --scenario stage2 --no-extra --no-cpu-baseline > "$O/bench_stage2_fidelity.json" 2>> "$O/bench.err"; echo "stage2 fidelity rc=$?"; cut -c1-300 "$O/bench_stage2_fidelity.json" ;;
     boundary)
       [ -x tools/_build/launch_boundary ] || { mkdir -p tools/_build; hipcc --offload-arch=gfx950 -O3 tools/launch_boundary.hip -o tools/_build/launch_boundary; }
       timeout 120 tools/_build/launch_boundary > "$O/launch_boundary.txt" 2>&1; echo "rc=$?"; cut -c1-230 "$O/launch_boundary.txt"
