@@ -23,7 +23,11 @@
 
 using namespace mrca_pfwd;
 
+namespace mrca_ldsprobe {     // ("mrca" in the kernel names: tools/pmc_summary.py lists those)
+
 constexpr int kReps = 4096;
+// the compiler may not keep a loaded value across repetitions
+#define PROBE_RELOAD() asm volatile("" ::: "memory")
 
 #define PROBE_PROLOGUE                                                   \
     extern __shared__ __attribute__((aligned(16))) float lds_all[];     \
@@ -66,6 +70,7 @@ __global__ void conv1_operands(float* out) {
             const float* base = conv1_family(s) == 1 ? x1 : (conv1_family(s) == 2 ? x2 : x3);
             acc += base[conv1_step_off(s) + 32 * (r & 3)] + base[conv1_step_off(s) + 32 * (r & 3) + 32];
         }
+        PROBE_RELOAD();
     }
     PROBE_EPILOGUE
 }
@@ -94,6 +99,7 @@ __global__ void conv2_operands(float* out) {
             const float* base = s < 32 ? ha : hb;
             acc += base[conv2_step_off(s) + 64 * (r & 1)] + base[conv2_step_off(s) + 64 * (r & 1) + 32];
         }
+        PROBE_RELOAD();
     }
     PROBE_EPILOGUE
 }
@@ -121,11 +127,15 @@ __global__ void conv2_epilogue_r(float* out) {
             const float4 v = *reinterpret_cast<const float4*>(lds + kH1E + row * kHPitch + 64 * (r & 1) + 4 * (lane & 15));
             acc += v.x + v.y + v.z + v.w;
         }
+        PROBE_RELOAD();
     }
     PROBE_EPILOGUE
 }
 
+}  // namespace mrca_ldsprobe
+
 int main() {
+    using namespace mrca_ldsprobe;
     float* out;
     if (hipMalloc(&out, 4096) != hipSuccess) return 1;
     const size_t lds = (size_t)kWavesPerBlock * kWaveFloats * sizeof(float);
