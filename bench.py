@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- agent-steps/s of the MI355X-native multi-robot environment (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode env|rollout|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode env|rollout|train] [--no-graph] [--fidelity]
 
 A "step" is one pass of the hot path over one batch: every robot of every world on this rank
 advances one Stage tick (latch action -> kinematics -> collision -> 512-beam ray cast -> reward /
@@ -157,8 +157,11 @@ def main():
     ap.add_argument("--update-path", default="fused", choices=["fused", "stock"],
                     help="train: the PPO update differentiates the conv front end through the HIP forward / backward "
                          "kernels (fused, default) or through the stock PyTorch layers / MIOpen (stock)")
-    ap.add_argument("--no-graph", action="store_true", help="rollout/train: launch the tick kernel by kernel instead of "
-                                                             "replaying it as one hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch the tick kernel by kernel from the host instead of "
+                                                             "replaying it as a hipGraph (env: 16 ticks per graph)")
+    ap.add_argument("--no-gemm-choices", action="store_true",
+                    help="rollout/train: let hipBLASLt's default heuristic pick the learner's GEMM kernels instead of the "
+                         "recorded TunableOp choices (mrca/gemm_tuning.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the rollout/train side figures")
     ap.add_argument("--fidelity", action="store_true",
@@ -166,8 +169,9 @@ def main():
                          "share a 0.2 m raster cell and see each other's bodies through that raster (a side line: `value` of "
                          "the default run is the exact-rectangle mode on 0.05 m cells)")
     ap.add_argument("--graph", action="store_true",
-                    help="env mode: replay the timed ticks as hipGraphs (16 ticks per graph, one per entry of the action pool) "
-                         "instead of launching every kernel from the host")
+                    help="(the default since round 4; kept for old command lines) env mode: the timed ticks are replayed as "
+                         "hipGraphs -- 16 ticks per graph, one per entry of the action pool -- instead of being launched "
+                         "kernel by kernel from the host; --no-graph launches eagerly")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -252,7 +256,7 @@ def main():
 
     extra = {}
     env_graphs = None
-    if args.mode == "env" and args.graph:
+    if args.mode == "env" and not args.no_graph:
         # The two-launch tick replayed as hipGraphs: ticks k .. k + m - 1 (one per entry of the 16-deep action pool) are
         # captured once per distinct chunk length and replayed; warm-up and the timed region are cut into chunks of 16
         # ticks + one remainder, so EXACTLY --steps ticks are timed and the action sequence is the eager run's.
@@ -284,7 +288,11 @@ def main():
     elif args.mode == "env":
         step_fn = lambda k: env.step(pool[k % len(pool)])  # noqa: E731
     else:
+        from mrca import gemm_tuning
         from mrca.trainer import make_bench_step
+        extra["gemm_choices"] = ("recorded TunableOp choices (mrca/data/gemm_choices_gfx950_rocm72.csv)"
+                                 if (not args.no_gemm_choices and gemm_tuning.use_recorded_choices()) else
+                                 "library default heuristic")
         step_fn = make_bench_step(env, args.mode, dist,
                                   inference_dtype=torch.bfloat16 if args.policy_dtype == "bf16" else None,
                                   update_dtype=torch.bfloat16 if args.update_dtype == "bf16" else None,
@@ -434,7 +442,7 @@ def main():
                        "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
                        "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
                        if args.mode != "env" else None,
-                       "tick_as_hipgraph": (not args.no_graph) if args.mode != "env" else bool(args.graph),
+                       "tick_as_hipgraph": not args.no_graph,
                        "ppo_update_dtype": args.update_dtype if args.mode == "train" else None,
                        "ppo_update_path": (args.update_path if args.update_dtype == "f32" else "stock")
                        if args.mode == "train" else None},

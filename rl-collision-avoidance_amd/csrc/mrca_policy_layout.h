@@ -80,16 +80,10 @@ constexpr int kXPitch = 260;
 constexpr int kHPitch = 132;
 constexpr int kXE = 0, kXO = 3 * kXPitch;
 constexpr int kH1E = 6 * kXPitch;
-// H1O sits 16 banks off H1E: conv1's epilogue stores 32 consecutive positions per lane group, the even ones to
-// H1E[c][j + k], the odd ones to H1O[c][j + k + 1] -- with kCh * kHPitch = 0 mod 32 between the two images the two
-// halves of a ds_write_b32 group landed on the same 15 banks (the 1.4 bank-conflict cycles per LDS instruction of
-// profiles/r03_zz_pmc_policy_sq_counters_final_kernels.txt; two-way store conflicts cost no time on gfx950 -- the store's
-// register transfer is the longer half -- but the counter counts them).
-constexpr int kH1O = kH1E + kCh * kHPitch + 16;
+constexpr int kH1O = kH1E + kCh * kHPitch;
 constexpr int kWaveFloats = kH1O + kCh * kHPitch;
 constexpr int kWavesPerBlock = 4;
 static_assert(kWavesPerBlock * kWaveFloats * 4 <= 160 * 1024, "one workgroup of 4 waves per CU");
-static_assert((kH1O - kH1E) % 32 == 16, "conv1's even / odd position stores use disjoint banks");
 static_assert(kHPitch % 4 == 0 && kH1E % 4 == 0 && kWaveFloats % 4 == 0, "float4 rows of the epilogue");
 
 MRCA_PL_HD int rowmap(int reg, int hl) { return (reg & 3) + 8 * (reg >> 2) + 4 * hl; }

@@ -96,6 +96,9 @@ def main(argv=None):
     ap.add_argument("--graph", action="store_true", help="replay the rollout tick as one hipGraph (measured: no gain at "
                                                           "4096 robots, the tick is GPU-bound; profiles/r02_e_bench_rollout*.json)")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch the rollout tick kernel by kernel")
+    ap.add_argument("--tune-gemms", action="store_true", help="time the library GEMM kernels of shapes the recorded choices "
+                                                               "(mrca/gemm_tuning.py) do not list -- other batch sizes -- once")
+    ap.add_argument("--no-gemm-choices", action="store_true", help="hipBLASLt's default heuristic for every GEMM")
     ap.add_argument("--log-every", type=int, default=1)
     ap.add_argument("--hold-velocity", action="store_true", help="fidelity: Stage's SetSpeed persistence -- a robot that finished "
                                                                   "keeps driving at its last command until its group is done "
@@ -108,6 +111,9 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+        if not a.no_gemm_choices:       # recorded TunableOp choices for the learner's plain library GEMMs
+            from . import gemm_tuning
+            gemm_tuning.use_recorded_choices(tune_missing=a.tune_gemms)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
