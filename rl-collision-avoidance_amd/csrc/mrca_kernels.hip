@@ -951,12 +951,13 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             // what the beam hit rides in the sign bit (a range is never negative): set = another robot.  stageros casts
             // Stage's return value to uint8 for LaserScan.intensities (stageros.cpp:506): 1 floorplan, 0 robot or miss.
             r = (from_robot[k] && rng[k] < kRangeMax) ? -r : r;
-            // (plain stores: nontemporal ones were measured in round 4 -- FETCH_SIZE 2502 vs 2504 KiB per launch, the
-            // free-rectangle field is not what the rows evict -- and the policy's front end reads these rows next)
+            // (nontemporal stores: the launch does not read its rows again.  Measured A/B on one box, round 4: 21.7 us with
+            // them, 22.9 us with plain stores (profiles/r04_g_ab_nontemporal_row_stores.txt) -- although FETCH_SIZE does not
+            // move, 2502 vs 2504 KiB: what they relieve is the write path, not the free-rectangle field's residency)
             if (fresh) {     // deque([obs] * F), ppo_stage1.py:59-60: every slot, the head stays where it is
-                for (int f = 0; f < e.F; ++f) ring_row[f * e.B + b] = r;
+                for (int f = 0; f < e.F; ++f) __builtin_nontemporal_store(r, &ring_row[f * e.B + b]);
             } else {
-                ring_row[new_slot * e.B + b] = r;
+                __builtin_nontemporal_store(r, &ring_row[new_slot * e.B + b]);
             }
         }
         if (tid == 0 && !fresh) e.ring_head[n] = (uint8_t)new_slot;
