@@ -607,11 +607,21 @@ MRCA_HD void slab(float lo, float ld, float h, float* t0, float* t1) {
 
 // Entry distance of the ray into robot j's rectangle; +inf on a miss.  Robots are visible to
 // each other's lidar: ranger_return 0.5 (stage1.world:95).
-MRCA_HD float ray_box(float ox, float oy, float dx, float dy, float xj, float yj, float sj, float cj) {
+// The ray's ORIGIN in robot j's frame is the same for all beams of a lidar: ray_box_origin once per neighbour (the preparing
+// wave), ray_box_local per tested beam -- the same expressions in the same order as ray_box, so the same bits.
+MRCA_HD void ray_box_origin(float ox, float oy, float xj, float yj, float sj, float cj, float* lx, float* ly) {
     const float rx = ox - xj;
     const float ry = oy - yj;
-    const float lx = rx * cj + ry * sj;
-    const float ly = ry * cj - rx * sj;
+    *lx = rx * cj + ry * sj;
+    *ly = ry * cj - rx * sj;
+}
+MRCA_HD float ray_box_local(float lx, float ly, float dx, float dy, float sj, float cj);
+MRCA_HD float ray_box(float ox, float oy, float dx, float dy, float xj, float yj, float sj, float cj) {
+    float lx, ly;
+    ray_box_origin(ox, oy, xj, yj, sj, cj, &lx, &ly);
+    return ray_box_local(lx, ly, dx, dy, sj, cj);
+}
+MRCA_HD float ray_box_local(float lx, float ly, float dx, float dy, float sj, float cj) {
     const float ldx = dx * cj + dy * sj;
     const float ldy = dy * cj - dx * sj;
     float t0x, t1x, t0y, t1y;

@@ -684,7 +684,10 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
 // no difference.)  Marching the K beams of a thread in LOCK STEP (grid_march_skip_n: K lookups in flight per wait) is
 // implemented and measured too: slower than one after the other (34.7 vs 28.1 us, profiles/r02_c_*), see mrca_abi.hip.
-template <int K, bool BIG, bool SEQ>
+// RASTER: fidelity mode's lidar (the other robots seen through the collision raster) -- a kernel of its own so that the
+// default one does not carry the code: with the raster walk behind a run-time branch the default launch was 0.85 us slower
+// (A/B on one box, profiles/r04_h_ab_raster_path_in_default_kernel.txt: twice the instructions for the same instruction cache)
+template <int K, bool BIG, bool SEQ, bool RASTER = false>
 __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     MRCA_RSTAMP(0);
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(nb_count + 4);   // [B] neighbours per beam
     int* nb_more = nb_count + 1;                                      // big worlds: another chunk of neighbours follows
     // fidelity mode (never in big worlds): the window of raster cells holding the other robots' outlines
-    const bool raster = !BIG && e.raster_inv > 0.0f;                  // block-uniform
+    constexpr bool raster = RASTER && !BIG;
     uint32_t* win_bits = reinterpret_cast<uint32_t*>(nbmask + e.B);
     const int win_reach = raster ? raster_window_reach(e.raster_inv) : 0;
     const int win_side = 2 * win_reach + 1, win_wpr = (win_side + 31) >> 5;
@@ -792,7 +795,9 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             if (cnt + add > kWave) break;          // this batch opens the next chunk
             if (keep) {
                 const int idx2 = cnt + __popcll(m & ((1ull << pl) - 1ull));
-                nb[idx2] = make_float4(cxj, cyj, chj.x, chj.y);
+                float olx, oly;         // the lidar's origin in the neighbour's frame: once per neighbour, not per beam
+                ray_box_origin(x, y, cxj, cyj, chj.x, chj.y, &olx, &oly);
+                nb[idx2] = make_float4(olx, oly, chj.x, chj.y);
                 nbi[idx2] = make_int2(lo, hi);
             }
             cnt += add;
@@ -826,7 +831,11 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         const unsigned long long m = __ballot(keep);
         if (keep) {
             const int idx = __popcll(m & ((1ull << pl) - 1ull));
-            nb[idx] = make_float4(xj, yj, hj.x, hj.y);
+            // the slab tests want the lidar's origin in the neighbour's frame (once per neighbour, not per beam); the
+            // fidelity mode's outline walk wants the neighbour's centre
+            float olx = xj, oly = yj;
+            if (!raster) ray_box_origin(x, y, xj, yj, hj.x, hj.y, &olx, &oly);
+            nb[idx] = make_float4(olx, oly, hj.x, hj.y);
             nbi[idx] = make_int2(lo, hi);
         }
         const int cnt0 = MRCA_DBG(e, 1) ? 0 : __popcll(m);
@@ -921,7 +930,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
                         const int q = __ffsll((long long)m) - 1;
                         m &= m - 1;
                         const float4 nbq = nb[q];
-                        const float t = ray_box(x, y, dx[k], dy[k], nbq.x, nbq.y, nbq.z, nbq.w);
+                        const float t = ray_box_local(nbq.x, nbq.y, dx[k], dy[k], nbq.z, nbq.w);
                         from_robot[k] = from_robot[k] || t < r;
                         r = t < r ? t : r;
                     }
@@ -1430,19 +1439,27 @@ void launch_head_init(const EnvView& e, hipStream_t s) {
 }
 
 void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
-    const int threads = (e.B >> e.ray_shift) + (e.ray_prep_wave ? kWave : 0);
+    const bool raster_mode = !e.big && e.raster_inv > 0.0f;
+    // fidelity mode launches the product's shapes only (2 beams per thread one after the other, or 1; the first wave prepares)
+    const int threads = raster_mode ? (e.B >> (e.ray_shift == 0 ? 0 : 1)) : (e.B >> e.ray_shift) + (e.ray_prep_wave ? kWave : 0);
     const size_t lds = ray_lds_bytes(e);
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
     const bool seq = e.ray_sequential != 0;
-#define MRCA_RAY(K, BIG, SEQ)                                                                                          \
+#define MRCA_RAY(K, BIG, SEQ) MRCA_RAY4(K, BIG, SEQ, false)
+#define MRCA_RAY4(K, BIG, SEQ, RASTER)                                                                                        \
     do {                                                                                                               \
         if (start || stop)                                                                                             \
-            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0, e,  \
+            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0, e,  \
                                   only_fresh);                                                                         \
         else                                                                                                           \
-            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ>), grid, dim3(threads), lds, s, e, only_fresh);             \
+            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), lds, s, e, only_fresh);     \
     } while (0)
+    if (raster_mode) {
+        if (e.ray_shift == 0) MRCA_RAY4(1, false, false, true);
+        else MRCA_RAY4(2, false, true, true);
+        return;
+    }
     if (e.big) {
         switch (e.ray_shift) {
             case 0: MRCA_RAY(1, true, false); break;
@@ -1463,6 +1480,7 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t 
             break;
     }
 #undef MRCA_RAY
+#undef MRCA_RAY4
 }
 
 void launch_gae(const float* rewards, const float* values, const float* last_value, const uint8_t* dones, float gamma,

@@ -69,13 +69,13 @@ def test_register_budget_and_no_scratch(device_asm):
     text = "\n".join(device_asm)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
     # move, materialize, newest_obs, normalize, sparse_obs, head_init, reset, gae, 7 x bw_* (integrate, collide, finish, lidar count / scan x 2 /
-    # fill), raycast<1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential> + big-world <1|2|4>
-    assert len(kernels) == 23, [k for k, _ in kernels]
+    # fill), raycast<1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential> + big-world <1|2|4> + fidelity mode <1 | 2 seq>
+    assert len(kernels) == 25, [k for k, _ in kernels]
     for name, body in kernels:
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
         assert scratch == 0, f"{name} spills {scratch} B/lane to scratch"
-        ray = re.search(r"raycast_kernelILi(\d)ELb([01])ELb([01])E", name)      # <K, BIG, SEQ>
+        ray = re.search(r"raycast_kernelILi(\d)ELb([01])ELb([01])ELb([01])E", name)      # <K, BIG, SEQ, RASTER>
         assert ("raycast_kernel" in name) == bool(ray), name
         if ray and ((ray.group(1) == "4" and ray.group(3) == "0") or ray.group(2) == "1"):
             assert vgpr <= 128, f"{name} needs {vgpr} VGPRs"     # 4 rays in lock step / big worlds: not the hot shapes
