@@ -82,7 +82,13 @@ def pmc_traffic(robots, scenario):
     if d.get("move_fetch_kib") is not None:
         mv = (2.0 * d["move_fetch_kib"] + d["move_write_kib"]) * 1024.0 / d["robots"] * robots
         note += f"; the move kernel's launch: {mv / 1e6:.2f} MB"
+    global _SQ_VALU_PER_WAVE
+    if d.get("raycast_sq_insts_valu_per_launch") and d.get("raycast_sq_waves_per_launch"):
+        _SQ_VALU_PER_WAVE = d["raycast_sq_insts_valu_per_launch"] / d["raycast_sq_waves_per_launch"]
     return per_robot * robots, note
+
+
+_SQ_VALU_PER_WAVE = None       # SQ_INSTS_VALU / SQ_WAVES of the ray cast from the committed counter pass (same kernel sources)
 
 
 def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0, fidelity=False):
@@ -462,6 +468,16 @@ def main():
                                          "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
                                          "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
                          "move_kernel_avg_us": mv_avg_s * 1e6 if launches else None,
+                         # the BINDING roof (HBM is only the nominal one): vector-ALU issue.  Instructions per wave from the
+                         # committed SQ counter pass x the launch's waves x 4 cycles per wave64 instruction, over the SIMD-cycles
+                         # of the launch at the 2.4 GHz peak clock (the chip holds ~2.1 GHz under this kernel: an under-estimate)
+                         "valu_issue": ({"insts_per_wave": _SQ_VALU_PER_WAVE,
+                                         "frac_of_issue_slots": _SQ_VALU_PER_WAVE * (N * sc.beams / 2 / 64) * 4.0 /
+                                         (1024 * ray_avg_s * 2.4e9),
+                                         "note": "SQ_INSTS_VALU per wave (profiles/pmc_traffic.json, same kernel sources) x waves x "
+                                                 "4 cycles / (1024 SIMDs x launch time x 2.4 GHz)"}
+                                        if (_SQ_VALU_PER_WAVE and launches and args.scenario == "stage1" and not args.fidelity)
+                                        else None),
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
                          "note": "HBM is the nominal roof (SURVEY 8d); the launch is bound by VALU issue at eight waves per SIMD: "
                                  "553 VALU instructions per wave (608 in round 3), two residency rounds of 2048 workgroups whose "

@@ -103,7 +103,7 @@ def test_committed_pmc_traffic_matches_the_kernel_sources():
     sys.path.insert(0, U.ROOT)
     bench = importlib.import_module("bench")
     traffic, note = bench.pmc_traffic(4096, "stage1")
-    assert traffic is not None and 15e6 < traffic < 40e6, note
+    assert traffic is not None and 10e6 < traffic < 20e6, note      # ABI 4: ONE 2 kB row per robot (round 3: 21 MB)
     src = open(os.path.join(U.ROOT, "rl-collision-avoidance_amd", "csrc", "mrca_kernels.h")).read()
     assert bench.code_only(src + "\n// a comment\n/* another\n one */\n") == bench.code_only(src)
     assert bench.code_only(src + "\nstatic const int kNotThere = 1;\n") != bench.code_only(src)

@@ -231,6 +231,25 @@ def _compare_runs(ref_logs, ref_state, ref_sha, got_logs, got_state, got_sha):
     return problems
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "ppo_stage1.py")), reason="reference checkout absent")
+def test_unchanged_ppo_stage1_is_reproducible_run_to_run(monkeypatch):
+    """The SPMD runtime's deterministic schedule (mrca/spmd.py: one rank at a time, lowest ready rank next): two runs of the
+    UNCHANGED ppo_stage1.py with the same seeds on the SAME backend must agree in every tick's actions and state, in every
+    log line and in the PPO losses.  (With rank threads left to the OS scheduler they differed from the second tick on:
+    whichever rank's reset_pose teleport came first re-cast its lidar against a different world.)  This is what makes the
+    oracle-vs-HIP comparison of the GPU leg meaningful."""
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)   # no GPU in this container
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    torch.set_num_threads(1)          # (a fixed reduction order in the CPU GEMMs of the reference's policy)
+    try:
+        a = _run_unchanged("ppo_stage1.py", 24, 40, U.COracleBackend, 5)
+        b = _run_unchanged("ppo_stage1.py", 24, 40, U.COracleBackend, 5)
+    finally:
+        torch.set_num_threads(max(1, os.cpu_count() or 1))
+    assert not _compare_runs(*a, *b)
+    assert a[2] == b[2] and sum(len(v) for v in a[0]["output_per_env"].values()) > 20
+
+
 @pytest.mark.gpu
 def test_mini_script_hip_backend_matches_oracle_backend():
     if not torch.cuda.is_available():

@@ -127,3 +127,28 @@ def test_rollout_cache_follows_the_parameters_whoever_changes_them():
     pol.logstd.grad = torch.ones_like(pol.logstd)
     opt.step()
     assert torch.equal(pol._rollout_cache()["logstd"], pol.logstd.detach().reshape(-1))
+
+
+def test_ring_head_travels_opaquely_and_normalize_scans_is_the_ieee_quotient():
+    """policy_ops.RingHead (what VecStageWorld.policy_obs hands out since ABI 4: head slots + "the ring holds RAW ranges")
+    slices like a tensor; normalize_scans on the host is |x| / 6 - 0.5 with the correctly rounded quotient (the sign bit of a
+    ring entry says what the beam hit), i.e. the kernel's norm_obs."""
+    import numpy as np
+    import torch
+    from mrca import policy_ops as P
+    h = P.RingHead(torch.tensor([0, 1, 2, 1], dtype=torch.uint8), raw=True)
+    sl = h[1:3]
+    assert isinstance(sl, P.RingHead) and sl.raw and sl.slots.tolist() == [1, 2]
+    assert P.unwrap_head(h) == (h.slots, True) and P.unwrap_head(h.slots) == (h.slots, False) and P.unwrap_head(None) == (None, False)
+    x = torch.tensor([0.0, -0.0, 1.0, -2.5, 5.9999995, -6.0, 3.3333333], dtype=torch.float32)
+    want = np.abs(x.numpy()) / np.float32(6.0) - np.float32(0.5)
+    assert np.array_equal(P.normalize_scans(x).numpy(), want) and want.dtype == np.float32
+
+
+def test_recorded_gemm_choices_are_a_no_op_without_a_gpu(monkeypatch):
+    import torch
+    from mrca import gemm_tuning
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    assert gemm_tuning.use_recorded_choices() is False
+    rows = [ln.split(",") for ln in open(gemm_tuning.DEFAULT_FILE) if ln.startswith("Gemm")]
+    assert len(rows) >= 10 and all(len(r) == 4 and float(r[3]) > 0 for r in rows)
