@@ -167,7 +167,7 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
  * keeps the replicas bit-identical -- but casts the lidar only for its own robots
  * [first_robot, first_robot + num_robots): scan / obs / local_goal of the other robots are left untouched.  The
  * replicated move phase bounds the speed-up: 69 us of a 579 us tick at 50 000 robots, i.e. at most 4.4x on 8 GPUs
- * (3.85x measured on one rank's share, profiles/r03_f_bigworld_shards8.jsonl). */
+ * (3.85x measured on one rank's share, profiles/r03/r03_f_bigworld_shards8.jsonl). */
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream);
 
 /* The reference-shaped views of the ring, for all robots (asynchronous on `stream`; needed only with lazy_obs = 1):

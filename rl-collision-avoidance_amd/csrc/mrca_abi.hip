@@ -437,7 +437,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
         v.collide_reach2 = cfg->collision_raster > 0.0f ? reach * reach : mrca::kCollideReach2;
     }
     v.debug_flags = 0;
-    // Launch shape of the ray cast, measured (profiles/r02_c_ablation_launch_shapes.txt, 4096 / 8228 robots, HIP events):
+    // Launch shape of the ray cast, measured (profiles/r02/r02_c_ablation_launch_shapes.txt, 4096 / 8228 robots, HIP events):
     //   2 beams per thread one after the other, first wave prepares the neighbours   28.1 / 33.7 us   <- product
     //   1 beam per thread (512 threads), first wave prepares                           31.6 / 41.1 us
     //   2 beams per thread in lock step (two lookups in flight), first wave prepares   34.7 / 37.9 us

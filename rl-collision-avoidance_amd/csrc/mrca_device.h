@@ -56,7 +56,7 @@ MRCA_HD void sincos_det(float th, float* sn, float* cs) {
 
 // 1 / d, correctly rounded.  On the device: v_rcp_f32 (1 ulp) + ONE Newton step in FMA arithmetic -- bit-identical to the
 // IEEE quotient for every float with 2^-100 <= |d| <= 2^100 (exhaustive sweep over all 2^32 bit patterns on the MI355X,
-// tools/check_rcp.hip, profiles/r02_e_check_rcp.txt: 0 mismatches; the mismatches outside are results that underflow) --
+// tools/check_rcp.hip, profiles/r02/r02_e_check_rcp.txt: 0 mismatches; the mismatches outside are results that underflow) --
 // in 3 instructions instead of the ~11 of the compiler's division expansion; anything outside that range takes the IEEE
 // division.  The host build (test harness) is the plain quotient, which is the specification.
 MRCA_HD float rcp_exact(float d) {
@@ -193,7 +193,7 @@ MRCA_HD float grid_march(const Occ& occ, const GridGeom& g, float ox, float oy, 
 // time, are bit-identical.  ANY field of valid empty rectangles gives the same numbers; the field only decides how many
 // jumps a ray takes.
 //
-// Granularity (measured, 4096 / 8228 robots, profiles/r01_u..z_ablation.txt): 4x4-cell blocks with
+// Granularity (measured, 4096 / 8228 robots, profiles/r01/r01_u..z_ablation.txt): 4x4-cell blocks with
 // 4-bit extents 48 / 130 us per ray-cast launch on stage-1 / stage-2; 2x2-cell blocks with 8-bit
 // extents 38 / 77 us; per cell 34 / 43 us.  The per-cell field is 8 bytes per cell: 1.3 / 5.1 MB for the 20 m / 40 m
 // maps at 0.05 m.

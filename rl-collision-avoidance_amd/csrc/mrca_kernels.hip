@@ -249,7 +249,7 @@ __device__ unsigned long long g_ray_stamps[2][kRayStamps][kRayStampBlocks];
 // each wave can then shuffle any robot's values without a trip through LDS); the three phases that are loops over
 // robots -- the broad phase of the collision pass, the patch loads, the outline walks -- are split across the waves;
 // wave 0 alone carries on with the ordered pass, rewards, restarts and the stores.  (One wave per world, rounds 1-2:
-// those three phases were 73 % of the kernel's chain on the Stage-2 map, profiles/r03_g_ablate.txt.)
+// those three phases were 73 % of the kernel's chain on the Stage-2 map, profiles/r03/r03_g_ablate.txt.)
 __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, const float* __restrict__ actions) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
     MRCA_STAMP(0);
@@ -681,9 +681,9 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // The march reads the free-rectangle field straight from its L1/L2-resident global copy: ~2 dependent
 // lookups per ray.  (Staging a tile of it in LDS per robot was measured slower at every granularity tried,
 // the tile costs more to fill than the few lookups it serves.  So were persistent workgroups
-// walking several robots each -- 39 vs 37 us, profiles/r01_ad_ablation.txt -- and nontemporal stores made
+// walking several robots each -- 39 vs 37 us, profiles/r01/r01_ad_ablation.txt -- and nontemporal stores made
 // no difference.)  Marching the K beams of a thread in LOCK STEP (grid_march_skip_n: K lookups in flight per wait) is
-// implemented and measured too: slower than one after the other (34.7 vs 28.1 us, profiles/r02_c_*), see mrca_abi.hip.
+// implemented and measured too: slower than one after the other (34.7 vs 28.1 us, profiles/r02/r02_c_*), see mrca_abi.hip.
 // RASTER: fidelity mode's lidar (the other robots seen through the collision raster) -- a kernel of its own so that the
 // default one does not carry the code: with the raster walk behind a run-time branch the default launch was 0.85 us slower
 // (A/B on one box, profiles/r04_h_ab_raster_path_in_default_kernel.txt: twice the instructions for the same instruction cache)
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
     const int tid = threadIdx.x;
     // (A variant of this kernel without the early exit -- so that nothing is waited for before every request of the
-    // workgroup is out -- was measured and changed nothing: 27.96 us either way, profiles/r03_l_bench_env.json.  The
+    // workgroup is out -- was measured and changed nothing: 27.96 us either way, profiles/r03/r03_l_bench_env.json.  The
     // launch is bound by VALU issue with eight waves per SIMD, not by a workgroup's own latency chain.)
     if (only_fresh && e.fresh[n] == 0) return;  // block-uniform
 
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     // loads (the index goes through an opaque zero): as scalar loads they shared the out-of-order scalar counter with
     // the kernel arguments, and the neighbour candidate below could not be requested before they were back.
     // (Not in big worlds: there the neighbour enumeration hashes the robot's cell per chunk, wave-uniform work that
-    // belongs on the scalar unit -- measured: 513 vs 492 us per 50 000-robot launch, profiles/r03_s_bigworld_shards8.jsonl.)
+    // belongs on the scalar unit -- measured: 513 vs 492 us per 50 000-robot launch, profiles/r03/r03_s_bigworld_shards8.jsonl.)
     int lane_zero = 0;
     if constexpr (!BIG) asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     const int nv = n + lane_zero;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         if (pl == 0) *nb_count = cnt0;
         // scatter: bit k of nbmask[b] = "neighbour k can touch beam b".  ds_or_b64 without a return value: the wave
         // fires one per neighbour and moves on (as a read-modify-write every neighbour cost an LDS round trip, ~2 000
-        // of the 5 600 ticks wave 0 spent preparing, profiles/r03_k_ablate_raycast_phase_stamps.txt).
+        // of the 5 600 ticks wave 0 spent preparing, profiles/r03/r03_k_ablate_raycast_phase_stamps.txt).
         for (int k = 0; k < cnt0; ++k) {
             const int2 iv = nbi[k];
             for (int b = iv.x + pl; b <= iv.y; b += kWave) mask_or(&nbmask[b], 1ull << k);
@@ -1250,7 +1250,7 @@ __global__ void bw_lidar_count_kernel(EnvView e) {
 }
 
 // Exclusive scan of the bucket populations in three small launches (a single workgroup walking all 2N buckets took
-// 296 us at 50 000 robots -- 70 % of the move phase, profiles/r03_d_bigworld_50000_kernel_stats.csv):
+// 296 us at 50 000 robots -- 70 % of the move phase, profiles/r03/r03_d_bigworld_50000_kernel_stats.csv):
 //   scan_local   one workgroup per 1024 buckets: coalesced load, block scan, local prefix -> bw_lstart, total -> bw_lblock;
 //                zeroes the counts (for the next tick) and the fill cursors
 //   scan_apply   adds its block's offset (the totals of the blocks before it, summed by the block itself)

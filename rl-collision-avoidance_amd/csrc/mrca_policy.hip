@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     // --- the tower's weights as MFMA A fragments A[i = out channel = col][k], in the K orders of mrca_policy_layout.h.
     // Fetched COALESCED (float4 per lane, 12 + 2 instructions) into this wave's still unused H1 area, rows padded to odd
     // pitches, and picked up from there: as 56 loads with a lane stride of 96 / 15 floats every instruction touched 64 cache
-    // lines -- ~7 us of a launch's ~13 us outside the robot loop, four waves behind one L1 (profiles/r03_n_fwd_phases.txt).
+    // lines -- ~7 us of a launch's ~13 us outside the robot loop, four waves behind one L1 (profiles/r03/r03_n_fwd_phases.txt).
     float a1[8], a2[48];
     {
         constexpr int kW2L = kH1E, kW1L = kH1E + 32 * 97;       // [32][97], [32][17]

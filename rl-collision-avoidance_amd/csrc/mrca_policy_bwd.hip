@@ -1,6 +1,6 @@
 // mrca_policy_bwd.hip -- backward pass of the lidar front end of the actor-critic (model/net.py:19-25,37-49: two
 // Conv1d + ReLU per tower) as ONE fused gfx950 kernel for the PPO update (model/ppo.py:158-192 differentiates through
-// these layers for every minibatch; through MIOpen that is 85 % of an update: profiles/r01_f_ppo_update_profile.txt).
+// these layers for every minibatch; through MIOpen that is 85 % of an update: profiles/r01/r01_f_ppo_update_profile.txt).
 //
 //   given  gfeat_t[n][c*128 + l] = dLoss / dfeat of tower t  (feat = the forward kernel's output, mrca_policy.hip)
 //   g2[c][l]   = gfeat * (feat > 0)                                                       l < 128

@@ -2,7 +2,7 @@
 // (model/net.py:41-55,61-70 and model/ppo.py:57-82): ReLU of fc1's output, the concatenation with the local goal and the
 // speed, fc2 + ReLU of both towers, the three heads (sigmoid / tanh means, value), the Gaussian sample, its log-density and
 // the clip to the action bounds.  In PyTorch that tail was ~35 launches and 140 of a rollout tick's 400 us at 4096
-// robots (profiles/r02_e_rollout_kernel_stats.csv); fc1 itself stays a library GEMM (137 TFLOP/s in hipBLASLt).
+// robots (profiles/r02/r02_e_rollout_kernel_stats.csv); fc1 itself stays a library GEMM (137 TFLOP/s in hipBLASLt).
 //
 // One workgroup of 4 wavefronts owns 32 robots of ONE tower (blockIdx & 1): the robots' 260 inputs are staged in LDS
 // transposed (H[k][robot], ReLU applied on the way), wave q computes units [32q, 32q + 32) of fc2 as

@@ -8,7 +8,7 @@
 //     H        = mean_i sum_j (0.5 + 0.5 log(2 pi) + ls_j)                                      model/net.py:72-80
 //     loss     = L_pi + 20 L_v - coeff_entropy H
 // as ~30 element-wise / reduction launches over [B, 1] and [B, 2] tensors, and autograd replays as many on the way back:
-// 2 300 tiny launches per 64-minibatch update, 0.25 ms of a 3.5 ms minibatch (profiles/r03_s_train_kernel_stats.csv).
+// 2 300 tiny launches per 64-minibatch update, 0.25 ms of a 3.5 ms minibatch (profiles/r03/r03_s_train_kernel_stats.csv).
 // Here one launch produces the five scalars AND the gradients of `loss` with respect to the network's outputs:
 //     dloss/dv_i    = 20 * 2 (v_i - target_i) / B
 //     dloss/dlogp_i = -(1 / B) A_i r_i g_i,    g_i = 1 where torch.min / torch.clamp route the gradient to r_i:

@@ -63,7 +63,7 @@ class CNNPolicy(nn.Module):
     def _tower(self, tw, x, goal, speed):
         # the two Conv1d layers evaluated as H=1 conv2d on a channels-last tensor: same parameters, bitwise
         # the same result on gfx950, ~15 % faster because MIOpen skips its NCHW<->NHWC transposes
-        # (profiles/r01_l_policy_formulations.txt)
+        # (profiles/r01/r01_l_policy_formulations.txt)
         c1, c2 = getattr(self, f"{tw}_fea_cv1"), getattr(self, f"{tw}_fea_cv2")
         h = x.unsqueeze(2).contiguous(memory_format=torch.channels_last)
         h = torch.relu(F.conv2d(h, c1.weight.unsqueeze(2), c1.bias, stride=(1, 2), padding=(0, 1)))

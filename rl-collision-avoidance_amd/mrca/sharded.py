@@ -8,7 +8,7 @@ for its own slice (``mrca_step_slice``).
 
 The replicated move phase is what bounds the speed-up (Amdahl): at 50 000 robots it is 69 us of a 579 us tick on one
 MI355X, so 8 GPUs can give at most 4.4x on this design and one rank's share of 8 measures 3.85x
-(``tools/bigworld_bench.py --shards 8``, profiles/r03_f_bigworld_shards8.jsonl).  Sharding the move phase
+(``tools/bigworld_bench.py --shards 8``, profiles/r03/r03_f_bigworld_shards8.jsonl).  Sharding the move phase
 too would need a halo exchange of provisional poses inside the ordered collision pass -- not built.
 """
 import torch

@@ -94,7 +94,7 @@ def main(argv=None):
     ap.add_argument("--stock-policy-path", action="store_true", help="rollout inference through the stock PyTorch layers "
                                                                        "instead of the fused fp32 HIP front end")
     ap.add_argument("--graph", action="store_true", help="replay the rollout tick as one hipGraph (measured: no gain at "
-                                                          "4096 robots, the tick is GPU-bound; profiles/r02_e_bench_rollout*.json)")
+                                                          "4096 robots, the tick is GPU-bound; profiles/r02/r02_e_bench_rollout*.json)")
     ap.add_argument("--no-graph", action="store_true", help="(default) launch the rollout tick kernel by kernel")
     ap.add_argument("--tune-gemms", action="store_true", help="time the library GEMM kernels of shapes the recorded choices "
                                                                "(mrca/gemm_tuning.py) do not list -- other batch sizes -- once")

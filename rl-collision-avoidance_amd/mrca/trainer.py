@@ -42,7 +42,7 @@ class HParams:
     kl_stop: float = 0.0              # > 0: abandon the rest of an update when a minibatch reports KL > kl_stop x kl_target
     # > -inf: floor of the policy's log standard deviation.  The reference lets logstd run free (model/net.py:33) and
     # trains ~30 k optimiser steps at lr 5e-5; at 10x the steps the noise of the speed channel collapses (sigma 0.05,
-    # then 0.003: profiles/r02_b_*), the importance ratios blow up and the policy degrades -- opt-in floor.
+    # then 0.003: profiles/r02/r02_b_*), the importance ratios blow up and the policy degrades -- opt-in floor.
     logstd_min: float = float("-inf")
     max_grad_norm: float = 0.0        # > 0: global-norm gradient clipping (opt-in; the reference clips nothing)
 

@@ -1,6 +1,6 @@
 """The self-trained checkpoint committed under mrca/data/ on the circle test (circle_test.py:36-83), CPU side: the C
 oracle env, the policy in stock PyTorch on the CPU.  (``policy/stage2.pth`` is absent from the reference checkout, so
-this checkpoint -- Stage-1, then Stage-2 worlds mixed with circles of 10-50 robots, profiles/r02_d_* -- is the only
+this checkpoint -- Stage-1, then Stage-2 worlds mixed with circles of 10-50 robots, profiles/r02/r02_d_* -- is the only
 end-to-end evidence that the loop learns the task.  The GPU legs are in tests/test_gpu_circle.py.)"""
 import hashlib
 import os
@@ -61,7 +61,7 @@ CHECKPOINT_ALL_SIZES = os.path.join(U.ROOT, "rl-collision-avoidance_amd", "mrca"
 
 def test_second_checkpoint_solves_circles_of_every_size_on_the_oracle_env():
     """The continuation of the same run with circles of 10-50 robots in the mix and validation on 20 / 30 / 40 / 50
-    robots at once (profiles/r02_h_*; sha256 f9e51e72...): circles the paper evaluates (Long et al. 2018, Sec. V: 4-20
+    robots at once (profiles/r02/r02_h_*; sha256 f9e51e72...): circles the paper evaluates (Long et al. 2018, Sec. V: 4-20
     robots) and beyond.  Measured on this env: 1.00 / 1.00 / 1.00 / 0.98 for 20 / 30 / 40 / 50 robots."""
     from mrca import evaluate
     from mrca.net import CNNPolicy

@@ -48,7 +48,7 @@ def _trained_policy():
 
 
 def test_trained_checkpoint_solves_the_circle_test():
-    """The committed checkpoint (Stage-1 -> Stage-2 worlds mixed with circles of 10-50 robots, profiles/r02_d_*;
+    """The committed checkpoint (Stage-1 -> Stage-2 worlds mixed with circles of 10-50 robots, profiles/r02/r02_d_*;
     sha256 23b64ea9...) on the reference's 50-robot circle: every robot must reach its antipodal goal.  Deterministic
     mean action, first terminal event latched; also at 1000 robots (20 circles) and through the fused
     fp32 rollout path of the policy."""
@@ -84,7 +84,7 @@ def test_success_rate_under_perturbed_starts_every_circle_size(stage_resolution)
     deterministic one, on which a policy scores 0 or 1.  Sizes 10 / 20 / 30 / 40 / 50 robots, default maps and the
     fidelity mode (Stage's own cell size).  The seed used here was never seen in training or checkpoint selection
     (both used the unperturbed table).  Bar: the lower end of the 95 % interval of the mean success rate >= 0.95 for
-    every size (measured with 200 circles each: 0.997 .. 1.000, profiles/r03_c_circle_eval_perturbed_*.jsonl)."""
+    every size (measured with 200 circles each: 0.997 .. 1.000, profiles/r03/r03_c_circle_eval_perturbed_*.jsonl)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import __graft_entry__ as g
@@ -110,7 +110,7 @@ def test_success_rate_under_perturbed_starts_every_circle_size(stage_resolution)
 def test_checkpoint_trained_through_the_hip_backward_kernels():
     """mrca/data/policy_r03_fused_update_11min.pth: Stage-1 from scratch for 300 s, then the Stage-2 mix for 330 s, on one
     MI355X, every PPO update through lidar_features_kernel / lidar_features_bwd_kernel (tools/train_recipe.sh,
-    profiles/r03_j_train_fused_*_curve.txt; selected on perturbed validation circles of a held-out seed).  Measured there
+    profiles/r03/r03_j_train_fused_*_curve.txt; selected on perturbed validation circles of a held-out seed).  Measured there
     with 100 perturbed circles per size: 1.000 / 1.000 / 1.000 / 1.000 / 0.9998.  Here: 40 circles per size, another
     seed, inference through the HIP front end reading the frame ring in place."""
     if not torch.cuda.is_available():
@@ -133,7 +133,7 @@ def test_checkpoint_trained_through_the_hip_backward_kernels():
 
 
 def test_second_checkpoint_on_circles_of_every_size():
-    """mrca/data/policy_r02_all_circle_sizes.pth (profiles/r02_h_*): circles of 10 ... 50 robots, 20 circles each."""
+    """mrca/data/policy_r02_all_circle_sizes.pth (profiles/r02/r02_h_*): circles of 10 ... 50 robots, 20 circles each."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from mrca import evaluate

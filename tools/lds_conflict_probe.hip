@@ -1,7 +1,7 @@
 // Which LDS access of lidar_features_kernel (csrc/mrca_policy.hip) produces its bank-conflict cycles?
 //
 // The forward kernel of the policy's front end counts 1.4 SQ_LDS_BANK_CONFLICT cycles per LDS instruction
-// (profiles/r03_zz_pmc_policy_sq_counters_final_kernels.txt).  Each kernel below issues ONE of its access patterns -- the
+// (profiles/r03/r03_zz_pmc_policy_sq_counters_final_kernels.txt).  Each kernel below issues ONE of its access patterns -- the
 // address formulas of csrc/mrca_policy_layout.h (namespace mrca_pfwd), same lanes, same pitches -- kReps times per wave and
 // nothing else, so that
 //     rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE -- tools/_build/lds_conflict_probe
