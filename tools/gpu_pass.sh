@@ -46,6 +46,8 @@ for STAGE in "$@"; do
     bench_modes)
       timeout 600 python bench.py --mode rollout --steps 400 --warmup 40 --no-cpu-baseline --no-graph > "$O/bench_rollout.json" 2>> "$O/bench.err"; echo "rollout rc=$?"; cut -c1-260 "$O/bench_rollout.json"
       timeout 900 python bench.py --mode train --steps 256 --warmup 0 --no-cpu-baseline --no-graph > "$O/bench_train.json" 2>> "$O/bench.err"; echo "train rc=$?"; cut -c1-260 "$O/bench_train.json"
+      timeout 900 python bench.py --mode train --steps 256 --warmup 0 --no-cpu-baseline > "$O/bench_train_graph.json" 2>> "$O/bench.err"; echo "train (rollout tick as a hipGraph) rc=$?"; cut -c1-260 "$O/bench_train_graph.json"
+      timeout 600 python bench.py --mode rollout --steps 400 --warmup 40 --no-cpu-baseline > "$O/bench_rollout_graph.json" 2>> "$O/bench.err"; echo "rollout (hipGraph) rc=$?"; cut -c1-260 "$O/bench_rollout_graph.json"
       timeout 900 python bench.py --mode train --steps 256 --warmup 0 --no-cpu-baseline --no-graph --update-path stock > "$O/bench_train_stock.json" 2>> "$O/bench.err"; echo "train stock rc=$?"; cut -c1-260 "$O/bench_train_stock.json"
       timeout 600 python bench.py --scenario stage2 --worlds 187 --steps 500 --warmup 50 --no-cpu-baseline --no-extra > "$O/bench_stage2.json" 2>> "$O/bench.err"; echo "stage2 rc=$?"; cut -c1-260 "$O/bench_stage2.json"
       flt < "$O/bench.err" | tail -4 ;;
