@@ -480,7 +480,7 @@ def main():
                                         else None),
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
                          "note": "HBM is the nominal roof (SURVEY 8d); the launch is bound by VALU issue at eight waves per SIMD: "
-                                 "553 VALU instructions per wave (608 in round 3), two residency rounds of 2048 workgroups whose "
+                                 "546 VALU instructions per wave (608 in round 3), two residency rounds of 2048 workgroups whose "
                                  "lifetime is what eight waves per SIMD x ~550 instructions x 4 cycles come to; DESIGN.md 5.2"},
         }
         if args.mode == "rollout":

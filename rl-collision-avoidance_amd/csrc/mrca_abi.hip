@@ -708,6 +708,16 @@ int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */) {
     out[16] = (double)early / nb;
     return MRCA_OK;
 }
+
+int mrca_debug_ray_stamps_raw(mrca_env* env, uint64_t* out, int32_t blocks) {
+    if (!env || !out) return fail(MRCA_ERR_INVALID, "NULL argument");
+    if (blocks < 1 || blocks > 8192) return fail(MRCA_ERR_INVALID, "blocks = %d (1 ... 8192 workgroups are stamped)", blocks);
+    DeviceGuard guard(env->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "stamp width");
+    mrca::read_ray_stamps(reinterpret_cast<unsigned long long*>(out), blocks);
+    return MRCA_OK;
+}
 #endif
 
 int mrca_read_timing(mrca_env* env, float* move_ms_total, float* ray_ms_total, int32_t* launches) {
