@@ -14,6 +14,7 @@
 #   sq               tools/pmc_profile.sh (SQ counter sets of the env kernels)
 #   pmc_policy       SQ counter sets of the policy's forward / backward kernels (tools/update_bench.py 16384)
 #   bigworld         tools/bigworld_bench.py
+#   sliceprobe       tools/slice_probe.py: one rank's slice of a giant world's ray cast, launch shape by launch shape + timeline
 #   prof_bigworld    rocprofv3 --kernel-trace --stats of tools/bigworld_bench.py (BIGWORLD_ARGS: robot counts)
 #   circle           mrca.evaluate of the committed checkpoints (POLICY=... overrides)
 #   train            tools/train_recipe.sh (TRAIN_ARGS / S1_SECONDS / S2_SECONDS)
@@ -96,6 +97,11 @@ for STAGE in "$@"; do
       rm -rf "$O/pmc_policy" ;;
     bigworld)
       timeout 900 python tools/bigworld_bench.py ${BIGWORLD_ARGS:-} 2>&1 | flt | tee "$O/bigworld.jsonl" | cut -c1-300 ;;
+    sliceprobe)
+      timeout 600 python tools/slice_probe.py ${SLICEPROBE_ARGS:-} 2>&1 | flt | tee "$O/slice_probe.txt" | cut -c1-330
+      if [ -f tools/_build/bigseq/rl-collision-avoidance_amd/mrca/libmrca_env_prof.so ]; then
+        timeout 600 python tools/slice_probe.py --lib tools/_build/bigseq/rl-collision-avoidance_amd/mrca/libmrca_env_prof.so --lockstep-too ${SLICEPROBE_ARGS:-} 2>&1 | flt | tee "$O/slice_probe_bigseq.txt" | grep -v "^    " | cut -c1-330
+      fi ;;
     prof_bigworld)
       cd /tmp
       timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bw" -o trace -- python "$R/tools/bigworld_bench.py" ${BIGWORLD_ARGS:-50000} > "$O/prof_bigworld.log" 2>&1; echo "rc=$?"

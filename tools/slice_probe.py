@@ -2,7 +2,10 @@
 """GPU, PROFILING build: why does ONE rank's slice of a giant world's ray cast take longer than its share of the full launch?
 (79 us for 6 250 of 50 000 robots against 61.5 us pro rata, round 3.)
 
-    python tools/slice_probe.py [--robots 50000] [--shards 8]
+    python tools/slice_probe.py [--robots 50000] [--shards 8] [--lib PATH --lockstep-too]
+
+``--lib``: another profiling build (an experiment's); ``--lockstep-too`` adds the shapes with bit 12 set (the beams of a thread
+marched in lock step) for a build whose big-world launch honours that bit.
 
 For the launch shapes the big-world kernel is instantiated for (1 / 2 / 4 beams per marching thread: 512 / 256 / 128 threads
 per workgroup) it times the full launch and one rank's slice (begin / end stamps of the launches themselves), checks that the
@@ -39,12 +42,20 @@ def opt(name, default):
     return default
 
 
+LIB = _lib.PROFILING_LIB_PATH
+if "--lib" in argv:
+    i = argv.index("--lib")
+    LIB = os.path.abspath(argv[i + 1])
+    del argv[i: i + 2]
+LOCKSTEP_TOO = "--lockstep-too" in argv
 R = opt("--robots", 50000)
 SHARDS = opt("--shards", 8)
 PER = -(-R // SHARDS)
 TICK_NS = 10.0            # s_memtime / s_memrealtime: 100 MHz
 SHAPES = ((512, "2 beams per thread (product), 256 threads"), (256, "1 beam per thread, 512 threads"),
           (768, "4 beams per thread, 128 threads"))
+if LOCKSTEP_TOO:
+    SHAPES += ((512 + 4096, "2 beams per thread in lock step, 256 threads"), (768 + 4096, "4 beams per thread in lock step, 128 threads"))
 
 
 def controller(env):
@@ -93,10 +104,11 @@ def timeline(st, label):
 
 
 sc = S.circle_big(R)
+print(f"library: {os.path.relpath(LIB, ROOT)}")
 rows = {}
 summary = []
 for knob, label in SHAPES:
-    env = VecStageWorld(sc, lib_path=_lib.PROFILING_LIB_PATH)
+    env = VecStageWorld(sc, lib_path=LIB)
     env.set_debug_flags(knob)
     env.reset()
     for _ in range(20):
