@@ -35,6 +35,13 @@ namespace {
 using mrca::DeviceGuard;
 #define fail(...) mrca::set_error(__VA_ARGS__)
 
+// log2 of the beams a marching thread of the ray cast owns (EnvView::ray_shift): 2 per thread, 4 in worlds of more than 64
+// robots -- as long as that leaves the workgroup two whole wavefronts or more (the measurements: mrca_create)
+inline int32_t product_ray_shift(int32_t beams, int32_t big) {
+    if (big && (beams >> 2) >= 128 && (beams >> 2) % 64 == 0) return 2;
+    return beams >= 256 ? 1 : 0;
+}
+
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
         hipError_t _e = (expr);                                                                     \
@@ -445,7 +452,13 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     // i.e. neither more lookups in flight per thread nor taking the preparation off the marching waves pays: the
     // lock-step loop costs 62 instead of 54 VALU instructions per jump and keeps finished rays idling, the extra
     // wave costs a resident workgroup per CU.
-    v.ray_shift = (cfg->beams >= 256) ? 1 : 0;
+    // Worlds of more than 64 robots (the chunked neighbour lists of the big-world path), one circle of 50 000, PROFILING build
+    // (profiles/r04_m_slice_probe*.txt; full launch / one rank's slice of 6 250 robots):
+    //   4 beams per thread one after the other (2 waves per workgroup, 4096 workgroups resident)   445 /  77 us   <- product
+    //   2 beams per thread one after the other                                                      536 /  88 us
+    //   2 / 4 beams per thread in lock step (rounds 2-3)                                      548, 578 / 88, 94 us
+    //   1 beam per thread                                                                           844 / 133 us
+    v.ray_shift = product_ray_shift(cfg->beams, v.big);
     v.ray_prep_wave = 0;
     v.ray_sequential = 1;
     env->lds_bytes = mrca::ray_lds_bytes(v);
@@ -643,7 +656,7 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
             return fail(MRCA_ERR_INVALID, "beams-per-thread knob %d out of range", knob);
         env->view.ray_shift = shift;
     } else {
-        env->view.ray_shift = (env->cfg.beams >= 256) ? 1 : 0;   // the product's launch shape
+        env->view.ray_shift = product_ray_shift(env->cfg.beams, env->view.big);   // the product's launch shape
     }
     env->view.ray_prep_wave = (flags & 0x800) ? 1 : 0;
     env->view.ray_sequential = (flags & 0x1000) ? 0 : 1;

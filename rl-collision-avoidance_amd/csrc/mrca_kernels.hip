@@ -1463,8 +1463,14 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t 
     if (e.big) {
         switch (e.ray_shift) {
             case 0: MRCA_RAY(1, true, false); break;
-            case 1: MRCA_RAY(2, true, false); break;
-            default: MRCA_RAY(4, true, false); break;
+            case 1:
+                if (seq) MRCA_RAY(2, true, true);
+                else MRCA_RAY(2, true, false);
+                break;
+            default:
+                if (seq) MRCA_RAY(4, true, true);      // the product's shape for big worlds (mrca_abi.hip)
+                else MRCA_RAY(4, true, false);
+                break;
         }
         return;
     }

@@ -69,8 +69,8 @@ def test_register_budget_and_no_scratch(device_asm):
     text = "\n".join(device_asm)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S)
     # move, materialize, newest_obs, normalize, sparse_obs, head_init, reset, gae, 7 x bw_* (integrate, collide, finish, lidar count / scan x 2 /
-    # fill), raycast<1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential> + big-world <1|2|4> + fidelity mode <1 | 2 seq>
-    assert len(kernels) == 25, [k for k, _ in kernels]
+    # fill), raycast<1 | 2 lock-step | 2 sequential | 4 lock-step | 4 sequential> + big-world <1 | 2 | 4 lock-step, 2 | 4 sequential> + fidelity mode <1 | 2 seq>
+    assert len(kernels) == 27, [k for k, _ in kernels]
     for name, body in kernels:
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))

@@ -2,15 +2,14 @@
 """GPU, PROFILING build: why does ONE rank's slice of a giant world's ray cast take longer than its share of the full launch?
 (79 us for 6 250 of 50 000 robots against 61.5 us pro rata, round 3.)
 
-    python tools/slice_probe.py [--robots 50000] [--shards 8] [--lib PATH --lockstep-too]
+    python tools/slice_probe.py [--robots 50000] [--shards 8] [--lib PATH]
 
-``--lib``: another profiling build (an experiment's); ``--lockstep-too`` adds the shapes with bit 12 set (the beams of a thread
-marched in lock step) for a build whose big-world launch honours that bit.
+``--lib``: another profiling build (an experiment's).
 
 For the launch shapes the big-world kernel is instantiated for (1 / 2 / 4 beams per marching thread: 512 / 256 / 128 threads
-per workgroup) it times the full launch and one rank's slice (begin / end stamps of the launches themselves), checks that the
+per workgroup; several beams one after the other or in lock step) it times the full launch and one rank's slice (begin / end stamps of the launches themselves), checks that the
 slice's ring rows are bit-identical from shape to shape, and prints the slice launch's TIMELINE from the per-workgroup
-s_memtime stamps of the profiling build (100 MHz: 10 ns): how many workgroups are in flight in each twentieth of the launch, when
+s_memtime stamps of the profiling build: how many workgroups are in flight in each twentieth of the launch, when
 they start, how long one takes depending on when it started.  A launch that is "ramp and tail" shows it here."""
 import ctypes as C
 import json
@@ -47,15 +46,12 @@ if "--lib" in argv:
     i = argv.index("--lib")
     LIB = os.path.abspath(argv[i + 1])
     del argv[i: i + 2]
-LOCKSTEP_TOO = "--lockstep-too" in argv
 R = opt("--robots", 50000)
 SHARDS = opt("--shards", 8)
 PER = -(-R // SHARDS)
-TICK_NS = 10.0            # s_memtime / s_memrealtime: 100 MHz
-SHAPES = ((512, "2 beams per thread (product), 256 threads"), (256, "1 beam per thread, 512 threads"),
-          (768, "4 beams per thread, 128 threads"))
-if LOCKSTEP_TOO:
-    SHAPES += ((512 + 4096, "2 beams per thread in lock step, 256 threads"), (768 + 4096, "4 beams per thread in lock step, 128 threads"))
+SHAPES = ((768, "4 beams per thread one after the other (product), 128 threads"),
+          (512, "2 beams per thread one after the other, 256 threads"), (256, "1 beam per thread, 512 threads"),
+          (512 + 4096, "2 beams per thread in lock step, 256 threads"), (768 + 4096, "4 beams per thread in lock step, 128 threads"))
 
 
 def controller(env):
@@ -81,26 +77,42 @@ def raw_stamps(env, blocks):
     return out.astype(np.int64)
 
 
-def timeline(st, label):
-    """st[2, 7, blocks]: stamps of waves 0 / 1; entry = [0, 0], end = the later of the two waves' last stamps."""
-    start = st[0, 0]
+def timeline(st, label, launch_us):
+    """st[2, 7, blocks]: s_memtime stamps of waves 0 / 1; entry = [0, 0], end = the later of the two waves' last stamps.
+    s_memtime is a PER-XCD counter (the eight dies' counters have unrelated origins) at the shader clock: workgroup b runs on
+    XCD b % 8 (round-robin dispatch, profiles/r04_b_launch_boundary.txt), so every die's stamps are taken relative to that
+    die's first entry, and the tick length follows from the launch's own duration."""
+    blocks = st.shape[2]
+    xcd = np.arange(blocks) % 8
+    start = st[0, 0].copy()
     end = np.maximum(st[0, 6], st[1, 6])
-    t0, t1 = start.min(), end.max()
-    span = float(t1 - t0)
+    spans = []
+    for g in range(8):
+        m = xcd == g
+        t0 = start[m].min()
+        start[m] -= t0
+        end[m] -= t0
+        spans.append(int(end[m].max()))
+    span = float(max(spans))
+    if span > 1e9:
+        print(f"  {label}: the stamps of a die do not share an origin (spans {spans}): workgroup -> XCD is not b % 8 here")
+        return None
+    tick_us = launch_us / span
     dur = (end - start).astype(np.float64)
-    print(f"  {label}: {len(start)} workgroups, first entry -> last end {span * TICK_NS / 1e3:.2f} us; a workgroup lives "
-          f"{dur.mean() * TICK_NS / 1e3:.2f} us on average (min {dur.min() * TICK_NS / 1e3:.2f}, max {dur.max() * TICK_NS / 1e3:.2f}); "
-          f"workgroup-time / span = {dur.sum() / span:.0f} workgroups in flight on average")
+    print(f"  {label}: {blocks} workgroups; per-XCD first entry -> last end {min(spans)} ... {max(spans)} ticks = the launch's "
+          f"{launch_us:.1f} us => {1.0 / tick_us:.0f} ticks per us; a workgroup lives {dur.mean() * tick_us:.2f} us on average "
+          f"(min {dur.min() * tick_us:.2f}, max {dur.max() * tick_us:.2f}); workgroup-time / span = {dur.sum() / span:.0f} workgroups "
+          f"in flight on average")
     bins = 20
-    edges = t0 + span * np.arange(bins + 1) / bins
+    edges = span * np.arange(bins + 1) / bins
     print("    twentieth   in flight (mean)   started   mean life of those started [us]")
     for b in range(bins):
         lo, hi = edges[b], edges[b + 1]
         overlap = np.clip(np.minimum(end, hi) - np.maximum(start, lo), 0, None).sum() / (hi - lo)
         started = (start >= lo) & (start < hi) if b < bins - 1 else (start >= lo)
-        life = dur[started].mean() * TICK_NS / 1e3 if started.any() else float("nan")
+        life = dur[started].mean() * tick_us if started.any() else float("nan")
         print(f"    {b:9d}   {overlap:16.0f}   {int(started.sum()):7d}   {life:8.2f}")
-    return {"span_us": span * TICK_NS / 1e3, "mean_life_us": dur.mean() * TICK_NS / 1e3, "mean_in_flight": dur.sum() / span}
+    return {"mean_life_us": dur.mean() * tick_us, "mean_in_flight": dur.sum() / span, "ticks_per_us": 1.0 / tick_us}
 
 
 sc = S.circle_big(R)
@@ -130,7 +142,7 @@ for knob, label in SHAPES:
     print(json.dumps(out), flush=True)
     if PER <= 8192:
         st = raw_stamps(env, PER)
-        out["timeline"] = timeline(st, f"slice launch, {label}")
+        out["timeline"] = timeline(st, f"slice launch, {label}", sry)
     summary.append(out)
     env.check()
     env.close()
