@@ -304,12 +304,9 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags);
 int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out);
 /* s_memtime stamps of the last ray-cast launch, lane 0 of wave 0 (builds the neighbour list, then marches) and of wave 1
  * (marches only): out[w * 7 + k] = mean over workgroups of stamp k - the workgroup's entry, k = entry | loads requested |
- * neighbour list built | beams marched | through the barrier | slab tests done | stores issued; out[14] = first entry to
- * last end, out[15] = mean workgroup entry, out[16] = share of workgroups starting in the first tenth of the launch. */
+ * neighbour list built | beams marched | through the barrier | slab tests done | stores issued; out[14..16] = 0 (reserved:
+ * s_memtime counters have unrelated origins across the chip, stamps of different workgroups cannot be compared). */
 int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */);
-/* The same stamps raw: out[(w * 7 + k) * blocks + b] for workgroups b < blocks (<= 8192) of the last ray-cast launch -- the
- * launch's timeline, workgroup by workgroup (tools/slice_probe.py). */
-int mrca_debug_ray_stamps_raw(mrca_env* env, uint64_t* out, int32_t blocks);
 /* s_memtime ticks per robot a wave of the last mrca_lidar_features launch spent in conv1's tile pairs 0..3 (out[0..3]) and
  * conv2's tile pairs 0 / 1 (out[4], out[5]); out[6] = robots per wave; out[7] = shader clock during the loop [GHz].  See
  * tools/fwd_phases.py. */

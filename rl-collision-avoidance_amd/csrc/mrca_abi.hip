@@ -689,8 +689,7 @@ int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out /* [9]: 8 deltas
 #if defined(MRCA_PROFILING)
 // Profiling build only: s_memtime stamps of the LAST ray-cast launch (synchronises the device).  out[w * 7 + k], w = 0, 1
 // (wave 0 prepares the neighbour list, wave 1 only marches), k = 0..6: mean over workgroups of stamp k minus the
-// workgroup's entry stamp; out[14] = last end - first entry over all workgroups (the launch as the shader clock sees it),
-// out[15] = mean workgroup entry - first entry, out[16] = share of workgroups that started in the first 10 % of the launch.
+// workgroup's entry stamp; out[14..16] = 0 (reserved).
 int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */) {
     if (!env || !out) return fail(MRCA_ERR_INVALID, "NULL argument");
     DeviceGuard guard(env->cfg.device);
@@ -699,36 +698,15 @@ int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */) {
     std::vector<unsigned long long> h((size_t)14 * nb);
     mrca::read_ray_stamps(h.data(), nb);
     auto at = [&](int w, int k, int b) { return h[((size_t)w * 7 + k) * nb + b]; };
-    unsigned long long first = ~0ull, last = 0;
-    for (int b = 0; b < nb; ++b) {
-        first = at(0, 0, b) < first ? at(0, 0, b) : first;
-        for (int w = 0; w < 2; ++w) last = at(w, 6, b) > last ? at(w, 6, b) : last;
-    }
     for (int w = 0; w < 2; ++w)
         for (int k = 0; k < 7; ++k) {
             double sum = 0.0;
             for (int b = 0; b < nb; ++b) sum += (double)(long long)(at(w, k, b) - at(0, 0, b));
             out[w * 7 + k] = sum / nb;
         }
-    out[14] = (double)(last - first);
-    double sum = 0.0;
-    int early = 0;
-    for (int b = 0; b < nb; ++b) {
-        sum += (double)(at(0, 0, b) - first);
-        early += (double)(at(0, 0, b) - first) < 0.1 * out[14];
-    }
-    out[15] = sum / nb;
-    out[16] = (double)early / nb;
-    return MRCA_OK;
-}
-
-int mrca_debug_ray_stamps_raw(mrca_env* env, uint64_t* out, int32_t blocks) {
-    if (!env || !out) return fail(MRCA_ERR_INVALID, "NULL argument");
-    if (blocks < 1 || blocks > 8192) return fail(MRCA_ERR_INVALID, "blocks = %d (1 ... 8192 workgroups are stamped)", blocks);
-    DeviceGuard guard(env->cfg.device);
-    HIP_TRY(hipDeviceSynchronize());
-    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "stamp width");
-    mrca::read_ray_stamps(reinterpret_cast<unsigned long long*>(out), blocks);
+    // [14..16] reserved: stamps of different workgroups cannot be compared (s_memtime counters have unrelated origins from
+    // die to die and within one), only differences inside a workgroup mean something
+    out[14] = out[15] = out[16] = 0.0;
     return MRCA_OK;
 }
 #endif

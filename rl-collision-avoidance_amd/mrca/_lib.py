@@ -89,7 +89,6 @@ def load(path=None):
         lib.mrca_debug_move_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.mrca_debug_ray_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         lib.mrca_debug_fwd_stamps.argtypes = [C.POINTER(C.c_double)]
-        lib.mrca_debug_ray_stamps_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.mrca_event_pair_overhead.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]
     lib.mrca_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     if lib.mrca_abi_version() != ABI_VERSION:

@@ -85,7 +85,5 @@ for name, sc in (("stage1 128x32", S.stage1(num_worlds=128, robots_per_world=32,
         print(f"{name:<14} ray cast stamps, {label} (s_memtime ticks since the workgroup's entry, mean over workgroups and 16 launches):")
         for k, nm in enumerate(rnames):
             print(f"{'':<14}   {nm:<24} wave 0 {acc[k]:9.1f}   wave 1 {acc[7 + k]:9.1f}")
-        print(f"{'':<14}   first entry -> last end {acc[14]:9.1f} ticks; mean workgroup entry at {acc[15]:9.1f}; "
-              f"{100 * acc[16]:.0f} % of the workgroups start in the first tenth of the launch")
     env.set_debug_flags(0)
     env.close()

@@ -98,7 +98,8 @@ for STAGE in "$@"; do
     bigworld)
       timeout 900 python tools/bigworld_bench.py ${BIGWORLD_ARGS:-} 2>&1 | flt | tee "$O/bigworld.jsonl" | cut -c1-300 ;;
     sliceprobe)
-      timeout 600 python tools/slice_probe.py ${SLICEPROBE_ARGS:-} 2>&1 | flt | tee "$O/slice_probe.txt" | cut -c1-330 ;;
+      timeout 600 python tools/slice_probe.py ${SLICEPROBE_ARGS:-} 2>&1 | flt | tee "$O/slice_probe.txt" | cut -c1-330
+      timeout 600 python tools/slice_probe.py --sweep 2>&1 | flt | tee "$O/slice_sweep.txt" | cut -c1-200 ;;
     prof_bigworld)
       cd /tmp
       timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bw" -o trace -- python "$R/tools/bigworld_bench.py" ${BIGWORLD_ARGS:-50000} > "$O/prof_bigworld.log" 2>&1; echo "rc=$?"

@@ -2,16 +2,14 @@
 """GPU, PROFILING build: why does ONE rank's slice of a giant world's ray cast take longer than its share of the full launch?
 (79 us for 6 250 of 50 000 robots against 61.5 us pro rata, round 3.)
 
-    python tools/slice_probe.py [--robots 50000] [--shards 8] [--lib PATH]
+    python tools/slice_probe.py [--robots 50000] [--shards 8] [--lib PATH] [--sweep]
 
-``--lib``: another profiling build (an experiment's).
+``--lib``: another profiling build (an experiment's).  ``--sweep``: the product's shape only, slices of 1024 ... R robots -- launch
+time against slice size (steps at multiples of the 4096 workgroups the chip holds = residency rounds).
 
 For the launch shapes the big-world kernel is instantiated for (1 / 2 / 4 beams per marching thread: 512 / 256 / 128 threads
-per workgroup; several beams one after the other or in lock step) it times the full launch and one rank's slice (begin / end stamps of the launches themselves), checks that the
-slice's ring rows are bit-identical from shape to shape, and prints the slice launch's TIMELINE from the per-workgroup
-s_memtime stamps of the profiling build: how many workgroups are in flight in each twentieth of the launch, when
-they start, how long one takes depending on when it started.  A launch that is "ramp and tail" shows it here."""
-import ctypes as C
+per workgroup; several beams one after the other or in lock step) it times the full launch and one rank's slice (begin / end
+stamps of the launches themselves) and checks that the slice's ring rows are bit-identical from shape to shape."""
 import json
 import os
 import sys
@@ -71,52 +69,25 @@ def timed(env, n, ray_slice=None):
     return mv / k * 1e3, ry / k * 1e3
 
 
-def raw_stamps(env, blocks):
-    out = np.zeros((2, 7, blocks), np.uint64)
-    _lib.check(env.lib.mrca_debug_ray_stamps_raw(env._h, out.ctypes.data_as(C.c_void_p), blocks), "mrca_debug_ray_stamps_raw")
-    return out.astype(np.int64)
-
-
-def timeline(st, label, launch_us):
-    """st[2, 7, blocks]: s_memtime stamps of waves 0 / 1; entry = [0, 0], end = the later of the two waves' last stamps.
-    s_memtime is a PER-XCD counter (the eight dies' counters have unrelated origins) at the shader clock: workgroup b runs on
-    XCD b % 8 (round-robin dispatch, profiles/r04_b_launch_boundary.txt), so every die's stamps are taken relative to that
-    die's first entry, and the tick length follows from the launch's own duration."""
-    blocks = st.shape[2]
-    xcd = np.arange(blocks) % 8
-    start = st[0, 0].copy()
-    end = np.maximum(st[0, 6], st[1, 6])
-    spans = []
-    for g in range(8):
-        m = xcd == g
-        t0 = start[m].min()
-        start[m] -= t0
-        end[m] -= t0
-        spans.append(int(end[m].max()))
-    span = float(max(spans))
-    if span > 1e9:
-        print(f"  {label}: the stamps of a die do not share an origin (spans {spans}): workgroup -> XCD is not b % 8 here")
-        return None
-    tick_us = launch_us / span
-    dur = (end - start).astype(np.float64)
-    print(f"  {label}: {blocks} workgroups; per-XCD first entry -> last end {min(spans)} ... {max(spans)} ticks = the launch's "
-          f"{launch_us:.1f} us => {1.0 / tick_us:.0f} ticks per us; a workgroup lives {dur.mean() * tick_us:.2f} us on average "
-          f"(min {dur.min() * tick_us:.2f}, max {dur.max() * tick_us:.2f}); workgroup-time / span = {dur.sum() / span:.0f} workgroups "
-          f"in flight on average")
-    bins = 20
-    edges = span * np.arange(bins + 1) / bins
-    print("    twentieth   in flight (mean)   started   mean life of those started [us]")
-    for b in range(bins):
-        lo, hi = edges[b], edges[b + 1]
-        overlap = np.clip(np.minimum(end, hi) - np.maximum(start, lo), 0, None).sum() / (hi - lo)
-        started = (start >= lo) & (start < hi) if b < bins - 1 else (start >= lo)
-        life = dur[started].mean() * tick_us if started.any() else float("nan")
-        print(f"    {b:9d}   {overlap:16.0f}   {int(started.sum()):7d}   {life:8.2f}")
-    return {"mean_life_us": dur.mean() * tick_us, "mean_in_flight": dur.sum() / span, "ticks_per_us": 1.0 / tick_us}
-
-
 sc = S.circle_big(R)
 print(f"library: {os.path.relpath(LIB, ROOT)}")
+if "--sweep" in argv:
+    # the product's shape, slices of growing size: does the launch time follow the NUMBER OF RESIDENCY ROUNDS (4096 two-wave
+    # workgroups fit the chip at eight waves per SIMD) rather than the number of robots?
+    env = VecStageWorld(sc, lib_path=LIB)
+    env.reset()
+    for _ in range(20):
+        env.step(controller(env))
+    torch.cuda.synchronize()
+    for n in (1024, 2048, 3072, 4096, 4224, 5120, 6144, 6250, 7168, 8192, 8320, 10240, 12288, 12416, 16384, 16512, 25000, R):
+        if n > R:
+            continue
+        _mv, ry = timed(env, 40, ray_slice=(0, n))
+        print(json.dumps({"robots": R, "slice_robots": n, "raycast_us": ry, "rounds_of_4096": n / 4096.0,
+                          "us_per_1000_robots": ry * 1000.0 / n}), flush=True)
+    env.check()
+    env.close()
+    sys.exit(0)
 rows = {}
 summary = []
 for knob, label in SHAPES:
@@ -140,9 +111,6 @@ for knob, label in SHAPES:
                                        "pro_rata_us": ry * PER / R, "projected_speedup": (mv + ry) / (smv + sry)},
            "slice_rows_equal_to_the_other_shapes": bool(same)}
     print(json.dumps(out), flush=True)
-    if PER <= 8192:
-        st = raw_stamps(env, PER)
-        out["timeline"] = timeline(st, f"slice launch, {label}", sry)
     summary.append(out)
     env.check()
     env.close()
