@@ -225,6 +225,7 @@ struct mrca_env {
     int step_count = 0;
     std::vector<hipEvent_t> ev;  // 4 per recorded step: begin / end of the move launch, begin / end of the ray cast
     int ev_used = 0;
+    int last_ray_count = 0;   // workgroups of the last ray-cast launch (profiling build: whose stamps are current)
 };
 
 extern "C" {
@@ -536,6 +537,7 @@ static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int
     mrca::EnvView v = env->view;
     v.ray_first = first;      // the robots whose lidar outputs (scan, frame stack, local goal) this call produces
     v.ray_count = count;
+    env->last_ray_count = count;
     // timing: the launches' own begin / end stamps (hipExtLaunchKernel), not event records around them
     hipEvent_t* ev = rec ? &env->ev[env->ev_used] : nullptr;
     mrca::launch_move(v, actions_dev, s, rec ? ev[0] : nullptr, rec ? ev[1] : nullptr);
@@ -694,7 +696,8 @@ int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */) {
     if (!env || !out) return fail(MRCA_ERR_INVALID, "NULL argument");
     DeviceGuard guard(env->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
-    const int nb = env->view.N < 8192 ? env->view.N : 8192;
+    const int nb = env->last_ray_count < 8192 ? env->last_ray_count : 8192;    // the workgroups whose stamps are this launch's
+    if (nb < 1) return fail(MRCA_ERR_INVALID, "no ray-cast launch to read stamps of");
     std::vector<unsigned long long> h((size_t)14 * nb);
     mrca::read_ray_stamps(h.data(), nb);
     auto at = [&](int w, int k, int b) { return h[((size_t)w * 7 + k) * nb + b]; };

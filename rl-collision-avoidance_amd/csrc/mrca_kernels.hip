@@ -754,23 +754,41 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     // into the slot behind the previous newest one; see materialize_kernel.)
     // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
     // exceed the 64 a chunk holds: the preparation wave walks the nine bucket ranges 64 entries at a time and hands
-    // the marching threads one chunk of <= 64 neighbours per barrier pair (see the chunk loop below)
-    int big_cell = 0, big_off = 0;     // enumeration state of the preparation wave (wave-uniform)
+    // the marching threads one chunk of <= 64 neighbours per barrier pair (see the chunk loop below).
+    // The nine ranges are ONE list to it: lanes 0..8 fetch "their" cell's range in the same memory round trip, a prefix sum
+    // over those lanes numbers the entries, and a batch of 64 takes entries off.. off + 63 of that list whichever cells they
+    // belong to.  (Rounds 2-3 walked the cells one after the other -- range, entry, pose, head: four dependent round trips
+    // per cell, 36 per workgroup, and a workgroup lived 25 us whatever else the chip was doing:
+    // profiles/r04_o_slice_sweep.txt.  Now it is five.)
+    int big_off = 0;                   // enumeration state of the preparation wave (wave-uniform): entries consumed so far
     auto big_chunk = [&]() {
         const int icx = hash_cell_coord(x, kLidarCell), icy = hash_cell_coord(y, kLidarCell);
         for (int b = pl; b < e.B; b += kWave) nbmask[b] = 0ull;
+        int cell_start = 0, cell_count = 0;
+        if (pl < 9) {
+            const uint32_t h = hash_cell(icx + pl % 3 - 1, icy + pl / 3 - 1, world) & (uint32_t)e.bw_lmask;
+            cell_start = e.bw_lstart[h];
+            cell_count = e.bw_lstart[h + 1] - cell_start;
+        }
+        int cell_end = cell_count;         // inclusive prefix sum over lanes 0..8 (lanes >= 9 hold zeros)
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int up = __shfl_up(cell_end, d, kWave);
+            if (pl >= d) cell_end += up;
+        }
+        const int total = __shfl(cell_end, 8, kWave);
         int cnt = 0;
-        while (big_cell < 9) {
-            const int qx = icx + big_cell % 3 - 1, qy = icy + big_cell / 3 - 1;
-            const uint32_t h = hash_cell(qx, qy, world) & (uint32_t)e.bw_lmask;
-            const int rs = e.bw_lstart[h] + big_off, re = e.bw_lstart[h + 1];
-            if (rs >= re) {
-                ++big_cell;
-                big_off = 0;
-                continue;
-            }
-            const int idx = rs + pl;
-            const int j = idx < re ? e.bw_lsorted[idx] : -1;
+        while (big_off < total) {
+            const int entry = big_off + pl;
+            int q = 0;                     // the cell entry falls into: the number of cells ending at or before it
+#pragma unroll
+            for (int t = 0; t < 8; ++t) q += __shfl(cell_end, t, kWave) <= entry ? 1 : 0;
+            const bool valid = entry < total;          // then q <= 8
+            q = valid ? q : 0;
+            const int qx = icx + q % 3 - 1, qy = icy + q / 3 - 1;
+            const int q_end = __shfl(cell_end, q, kWave), q_count = __shfl(cell_count, q, kWave);
+            const int idx = __shfl(cell_start, q, kWave) + (entry - (q_end - q_count));
+            const int j = valid ? e.bw_lsorted[idx] : -1;
             bool keep = false;
             float cxj = 0.0f, cyj = 0.0f;
             float4 chj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -805,7 +823,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         }
         if (pl == 0) {
             *nb_count = MRCA_DBG(e, 1) ? 0 : cnt;
-            *nb_more = big_cell < 9 ? 1 : 0;
+            *nb_more = big_off < total ? 1 : 0;
         }
         for (int k = 0; k < cnt; ++k) {
             const int2 iv = nbi[k];
@@ -893,11 +911,25 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
         org.iy0 = (int)floorf(org.fy);
         org.v_lo = __float_as_uint(hd.z);
         org.v_hi = __float_as_uint(hd.w);
-        if constexpr (K == 1 || SEQ) {   // one ray at a time: the hand-tuned single-ray loop (54 VALU per jump)
+        // Big worlds are open worlds (scenario.circle_big: the map is a token patch at the origin, the robots stand
+        // kilometres from it), and outside the map the field knows nothing: a ray crawls from cell to cell, one dependent
+        // lookup of the zero border each -- 40 000 of the 54 000 ticks a workgroup of the 50 000-robot circle lived
+        // (profiles/r04_t_bigworld_raycast_phases.txt), to return kRangeMax.  A robot whose 6 m cannot reach the map's
+        // bounding box (two cells of slack for the roundings of fx / fy) has nothing to march through: every beam is
+        // kRangeMax exactly as the march would return it.
+        bool map_in_reach = true;
+        if constexpr (BIG) {
+            const float reach = kRangeMax * e.g.inv_cell + 2.0f;
+            map_in_reach = org.fx + reach >= 0.0f && org.fx - reach <= (float)e.g.width && org.fy + reach >= 0.0f &&
+                           org.fy - reach <= (float)e.g.height;
+        }
+        if (map_in_reach) {
+            if constexpr (K == 1 || SEQ) {   // one ray at a time: the hand-tuned single-ray loop (54 VALU per jump)
 #pragma unroll
-            for (int k = 0; k < K; ++k) rng[k] = grid_march_skip(field, e.g, org, dx[k], dy[k], kRangeMax);
-        } else {                         // K rays in lock step: K lookups in flight per wait
-            grid_march_skip_n<K>(field, e.g, org, dx, dy, kRangeMax, rng);
+                for (int k = 0; k < K; ++k) rng[k] = grid_march_skip(field, e.g, org, dx[k], dy[k], kRangeMax);
+            } else {                         // K rays in lock step: K lookups in flight per wait
+                grid_march_skip_n<K>(field, e.g, org, dx, dy, kRangeMax, rng);
+            }
         }
     }
     MRCA_RSTAMP(3);     // this wave's beams marched
@@ -990,7 +1022,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
 //   bw_collide    thread per robot, the ordered pass as DEPENDENCY ROUNDS: robot i looks at the 3 x 3 cells around
 //                 its provisional centre; anybody listed there within 2 x circumradius can matter.  i is decided once
 //                 every such lower-indexed moving robot is (their outcome tells which of their two poses counts);
-//                 then it runs the SAT tests and publishes its own outcome (release / acquire on bw_state).  The
+//                 then it runs the SAT tests and publishes its own outcome (an agent-scope atomic on bw_state).  The
 //                 lowest undecided robot never waits, and robot blocks are handed to workgroups by TICKET in the order
 //                 they start, so every lower-indexed robot is held by a workgroup that is already running or done: the
 //                 loop terminates whatever order the hardware dispatches workgroups in (a bounded wait + status word
@@ -1073,28 +1105,62 @@ __global__ void bw_collide_kernel(EnvView e) {
     // its ticket earlier, i.e. one that is resident (its waves are scheduled: a waiting wave sleeps, it does not starve
     // the others) or already done.  The guard below stays as a belt: should a wait ever run out, the launch ends
     // instead of hanging the GPU, the robot stays undecided (treated as not moved) and bit 0 of the env's status word
-    // is raised -- mrca_check() turns it into MRCA_ERR_HIP, never a silent wrong state.  The release store of the
+    // is raised -- mrca_check() turns it into MRCA_ERR_HIP, never a silent wrong state.  The atomic store of the
     // outcome sits inside the loop by construction (done-flag form), not by grace of the optimiser.
     bool done = false;
     for (int guard = 0; !done && guard < (1 << 22); ++guard) {
         bool ready = true;
         bool hit = (flags & kFlagStaticHit) != 0;
         if (!MRCA_DBG(e, 16)) {
+            // The nine chains are walked in LOCK STEP, one LEVEL per pass: the link and the centre of the entry each chain
+            // stands at are 27 independent loads, in flight together; what follows an entry within reach (rare outside a
+            // jam) is the slow path below.  (Walked one chain after the other, entry by entry, a robot with nobody near it
+            // still paid a dependent round trip for each of the ~9 entries hash collisions and its own two poses put into
+            // its buckets: 31 us per 50 000-robot launch, profiles/r04_r_bigworld_kernel_stats.csv.)
+            int cur[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                for (int en = head9[q]; en >= 0 && ready; en = e.bw_cnext[en]) {
+            for (int q = 0; q < 9; ++q) cur[q] = head9[q];
+            for (;;) {
+                int nxt[9];
+                float cx[9], cy[9];
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int en = cur[q];
+                    nxt[q] = -1;
+                    cx[q] = cy[q] = 0.0f;
+                    if (en >= 0) {
+                        any = true;
+                        const int j = en >> 1;
+                        // the centre this entry stands for: j's provisional pose (odd entries) or its pose at tick start
+                        const float* ctr = (en & 1) ? reinterpret_cast<const float*>(e.bw_prov + 2 * j) : e.pose + 3 * j;
+                        nxt[q] = e.bw_cnext[en];
+                        cx[q] = ctr[0];
+                        cy[q] = ctr[1];
+                    }
+                }
+                if (!any) break;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int en = cur[q];
+                    cur[q] = nxt[q];
+                    if (en < 0) continue;
                     const int j = en >> 1;
                     if (j == n || j / e.R != world) continue;
+                    // within reach of my provisional centre?
+                    const float ax = nx - cx[q], ay = ny - cy[q];
+                    if (!(ax * ax + ay * ay <= e.collide_reach2)) continue;
                     const float4 q0 = e.bw_prov[2 * j], q1 = e.bw_prov[2 * j + 1];
                     const float ox = e.pose[j * 3 + 0], oy = e.pose[j * 3 + 1];
-                    // the centre this entry stands for: within reach of my provisional centre?
-                    const float ax = nx - ((en & 1) ? q0.x : ox), ay = ny - ((en & 1) ? q0.y : oy);
-                    if (!(ax * ax + ay * ay <= e.collide_reach2)) continue;
                     // the pose j has when it is my turn: robots after me have not moved yet; a robot before me is
                     // at its provisional pose iff its own test came out free
                     int sj = 1;
                     if (j < n && (__float_as_int(q0.w) & kFlagMoving)) {
-                        sj = __hip_atomic_load(&e.bw_state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        // (relaxed: the outcome IS the message -- everything else this thread reads about j was written
+                        // by the launch before.  As an acquire / release pair every decided robot's wave wrote the L2
+                        // back (buffer_wbl2 sc1) and every look invalidated it (buffer_inv sc1): the jam's collision
+                        // pass took 777 us instead of 341, profiles/r04_{q,r}_bigworld_kernel_stats.csv)
+                        sj = __hip_atomic_load(&e.bw_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (sj == 0) {
                             ready = false;
                             break;
@@ -1110,7 +1176,7 @@ __global__ void bw_collide_kernel(EnvView e) {
         }
         if (ready) {
             e.crashed[n] = hit ? 1 : 0;
-            __hip_atomic_store(&e.bw_state[n], hit ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&e.bw_state[n], hit ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             done = true;
         } else {
             __builtin_amdgcn_s_sleep(2);

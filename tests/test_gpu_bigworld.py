@@ -54,6 +54,26 @@ def test_crowded_rink_200_robots_bit_exact(hip):
     assert o.episode.max() >= 3
 
 
+@pytest.mark.parametrize("radius", [9.98, 13.0])
+def test_robots_outside_a_walled_map_bit_exact(hip, radius):
+    """A big world whose robots stand OUTSIDE the map: a walled 8 m box (0.5 m cells) at the origin, 66 robots on a circle
+    round it driving inwards.  At 9.98 m the box's corners and faces come into the 6 m lidar reach within the first ticks
+    (beams hit its walls from outside), at 13 m it stays out of reach for a while and then comes in: both sides of the
+    ray cast's "the map is out of this robot's reach: nothing to march through" test (raycast_kernel, big worlds), every
+    field and every hit flag bit-exact against the C oracle's plain cell walk."""
+    from mrca.scenario import GridData
+    occ = np.zeros((16, 16), bool)
+    occ[0, :] = occ[-1, :] = occ[:, 0] = occ[:, -1] = True
+    occ[6:9, 7] = True                               # something inside the box too (seen through nothing: walls are closed)
+    grid = GridData.from_dense(occ, 0.5, -4.0, -4.0)
+    n = 66
+    sc = S.circle_big(n, spacing=2.0 * np.pi * radius / n, grid=grid)
+    o = _exact(hip, sc, 48, 0, check_every=2, actions=_go_to_goal(sc))
+    scan = np.asarray(o.scan)
+    assert (scan < 6.0).any(), "no beam ever saw the box: the test does not test what it says"
+    assert (scan[:, :] >= 6.0).any()
+
+
 def test_single_circle_500_robots_bit_exact(hip):
     """One circle of 500 robots, radius proportional to R (250 m, spacing 3.14 m), open world, the commands of a
     go-to-goal controller: the scenario of SURVEY 8d C5."""

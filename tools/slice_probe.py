@@ -2,7 +2,7 @@
 """GPU, PROFILING build: why does ONE rank's slice of a giant world's ray cast take longer than its share of the full launch?
 (79 us for 6 250 of 50 000 robots against 61.5 us pro rata, round 3.)
 
-    python tools/slice_probe.py [--robots 50000] [--shards 8] [--lib PATH] [--sweep]
+    python tools/slice_probe.py [--robots 50000] [--shards 8] [--lib PATH] [--sweep | --phases]
 
 ``--lib``: another profiling build (an experiment's).  ``--sweep``: the product's shape only, slices of 1024 ... R robots -- launch
 time against slice size (steps at multiples of the 4096 workgroups the chip holds = residency rounds).
@@ -49,7 +49,9 @@ SHARDS = opt("--shards", 8)
 PER = -(-R // SHARDS)
 SHAPES = ((768, "4 beams per thread one after the other (product), 128 threads"),
           (512, "2 beams per thread one after the other, 256 threads"), (256, "1 beam per thread, 512 threads"),
-          (512 + 4096, "2 beams per thread in lock step, 256 threads"), (768 + 4096, "4 beams per thread in lock step, 128 threads"))
+          (512 + 4096, "2 beams per thread in lock step, 256 threads"), (768 + 4096, "4 beams per thread in lock step, 128 threads"),
+          (768 + 2048, "4 beams one after the other + a dedicated preparation wave, 192 threads"),
+          (512 + 2048, "2 beams one after the other + a dedicated preparation wave, 320 threads"))
 
 
 def controller(env):
@@ -71,6 +73,31 @@ def timed(env, n, ray_slice=None):
 
 sc = S.circle_big(R)
 print(f"library: {os.path.relpath(LIB, ROOT)}")
+if "--phases" in argv:
+    # where a workgroup's time goes in the big-world launch (the product's shape): s_memtime stamps of waves 0 and 1, means over
+    # the first 8192 workgroups, full launch and a 1024-robot slice (a quarter of the chip's residency: latency laid bare)
+    import ctypes as C
+    names = ("entry", "loads requested", "neighbour list built", "beams marched", "through the barrier", "neighbour slab tests",
+             "stores issued")
+    env = VecStageWorld(sc, lib_path=LIB)
+    env.reset()
+    for _ in range(20):
+        env.step(controller(env))
+    for label, sl in (("full launch", None), ("slice of 1024 robots", (0, 1024))):
+        for flags, fl in ((768, "overlap untouched"), (768 + 64, "memory drained at every stamp")):
+            env.set_debug_flags(flags)
+            acc = [0.0] * 17
+            for k in range(8):
+                env.step(controller(env), ray_slice=sl)
+                out = (C.c_double * 17)()
+                _lib.check(env.lib.mrca_debug_ray_stamps(env._h, out), "mrca_debug_ray_stamps")
+                acc = [a + t / 8 for a, t in zip(acc, out)]
+            print(f"{label}, {fl} (s_memtime ticks since the workgroup's entry):")
+            for k, nm in enumerate(names):
+                print(f"    {nm:<24} wave 0 {acc[k]:9.1f}   wave 1 {acc[7 + k]:9.1f}")
+    env.check()
+    env.close()
+    sys.exit(0)
 if "--sweep" in argv:
     # the product's shape, slices of growing size: does the launch time follow the NUMBER OF RESIDENCY ROUNDS (4096 two-wave
     # workgroups fit the chip at eight waves per SIMD) rather than the number of robots?
