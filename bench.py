@@ -328,8 +328,12 @@ def main():
         elapsed = time.perf_counter() - t0
         mv_ms, ray_ms, launches = 0.0, 0.0, 0
     else:
-        for k in range(args.warmup):
-            step_fn(k)
+        replay_ticks = getattr(step_fn, "run_ticks", None)    # rollout as hipGraphs: eight ticks per replay (mrca/trainer.py)
+        if replay_ticks is not None:
+            replay_ticks(args.warmup)
+        else:
+            for k in range(args.warmup):
+                step_fn(k)
         barrier()
         # begin / end stamps on the two launches of every 8th step of the timed region (stamped launches go through
         # hipExtLaunchKernel with four events: a few us of host time each -- taken on every step they cost a 20-step run a
@@ -337,8 +341,11 @@ def main():
         every = 8
         env.enable_timing(every)
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            step_fn(k)
+        if replay_ticks is not None:
+            replay_ticks(args.steps)
+        else:
+            for k in range(args.steps):
+                step_fn(k)
         barrier()
         elapsed = time.perf_counter() - t0
         mv_ms, ray_ms, launches = env.read_timing()
@@ -375,17 +382,15 @@ def main():
     if args.mode == "env" and world_size == 1 and not args.no_extra:
         from mrca.trainer import make_bench_step
         roll = make_bench_step(env, "rollout", None, fused=True, graph=True)
-        for k in range(10):
-            roll(k)
+        roll.run_ticks(10)
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
         n_roll = 100
-        for k in range(n_roll):
-            roll(k)
+        roll.run_ticks(n_roll)
         torch.cuda.synchronize()
         extra["rollout_side_figure"] = {"value": N * n_roll / (time.perf_counter() - tr0), "unit": "agent-steps/s",
                                         "note": "env + fp32 CNNPolicy inference per tick (HIP conv front end + batched "
-                                                "GEMMs, tick replayed as a hipGraph), 100 ticks after 10 warm-up ticks; not "
+                                                "GEMMs, ticks replayed as hipGraphs of eight), 100 ticks after 10 warm-up ticks; not "
                                                 "part of `value`"}
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

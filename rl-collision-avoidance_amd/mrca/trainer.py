@@ -227,11 +227,28 @@ def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, upd
             for _ in range(3):
                 body()
         torch.cuda.current_stream(env.device).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        g.register_generator_state(tr.gen)
-        with torch.cuda.graph(g, stream=side):
-            body()
-        return lambda _k: g.replay()
+        # one graph of ONE tick and one of EIGHT: a replay has a start-up of its own (a few us the eager path hides behind
+        # the previous tick's kernels: 265 vs 256 us per tick with one tick per replay, profiles/r04_v_bench_rollout*.json),
+        # so a run of n ticks replays the long graph n // 8 times and the short one for the remainder
+        def capture(ticks):
+            g = torch.cuda.CUDAGraph()
+            g.register_generator_state(tr.gen)
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(ticks):
+                    body()
+            return g
+        g1, g8 = capture(1), capture(8)
+
+        def step_fn(_k):
+            g1.replay()
+
+        def run_ticks(n):
+            for _ in range(n // 8):
+                g8.replay()
+            for _ in range(n % 8):
+                g1.replay()
+        step_fn.run_ticks = run_ticks
+        return step_fn
     if mode == "rollout":
         def step_fn(_k):
             obs, head = ppo.policy_input(env, hp.rollout_fused)
