@@ -27,6 +27,9 @@ trap 'rm -rf "${obj}"' EXIT
 for src in mrca_kernels mrca_abi mrca_policy mrca_policy_bwd mrca_policy_tail mrca_ppo_loss; do
     per=()
     [[ "${src}" == "mrca_policy" ]] && per=(-mllvm --amdgpu-mfma-vgpr-form)
+    # the env kernels: the first 14 dwords of a kernel's arguments arrive in SGPRs (gfx950's kernarg preload) -- move_kernel and
+    # raycast_kernel lead with the scalars and pointers their first loads need (mrca_kernels.hip)
+    [[ "${src}" == "mrca_kernels" ]] && per=(-mllvm -amdgpu-kernarg-preload-count=14)
     "${HIPCC}" "${FLAGS[@]}" "${per[@]}" -c "${here}/${src}.hip" -o "${obj}/${src}.o" "$@" &
     pids+=($!)
 done

@@ -250,19 +250,25 @@ __device__ unsigned long long g_ray_stamps[2][kRayStamps][kRayStampBlocks];
 // robots -- the broad phase of the collision pass, the patch loads, the outline walks -- are split across the waves;
 // wave 0 alone carries on with the ordered pass, rewards, restarts and the stores.  (One wave per world, rounds 1-2:
 // those three phases were 73 % of the kernel's chain on the Stage-2 map, profiles/r03/r03_g_ablate.txt.)
-__global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, const float* __restrict__ actions) {
+// (Leading scalar arguments: the first 14 dwords of a kernel's arguments are PRELOADED into SGPRs by the command processor
+// (csrc/build.sh: -amdgpu-kernarg-preload-count), so the loads the tick's dependent chain starts with go out at once instead
+// of one memory round trip later, behind the s_load of a 600-byte EnvView.  A/B on one box, three alternating runs each:
+// move 11.12 -> 10.85 us, ray cast 21.35 -> 20.51 us, profiles/r04_y_ab_kernarg_preload.txt.)
+__global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const float* pose_p, const float4* head_p,
+                                                                  const float* __restrict__ actions, const uint8_t* live_p,
+                                                                  EnvView e) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
     MRCA_STAMP(0);
     const int world = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const bool valid = lane < e.R;
-    const int n = world * e.R + (valid ? lane : 0);
+    const bool valid = lane < R_;
+    const int n = world * R_ + (valid ? lane : 0);
 
     // every per-robot input is requested up front so that all of it arrives in ONE memory round trip
-    float x = e.pose[n * 3 + 0], y = e.pose[n * 3 + 1], th = e.pose[n * 3 + 2];
-    const bool live = e.live[n] != 0;
+    float x = pose_p[n * 3 + 0], y = pose_p[n * 3 + 1], th = pose_p[n * 3 + 2];
+    const bool live = live_p[n] != 0;
     const float act_v = actions[n * 2 + 0], act_w = actions[n * 2 + 1];
     float gx = e.goal[n * 2 + 0], gy = e.goal[n * 2 + 1];
     float pdist = e.prev_dist[n];
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(EnvView e, con
     const float tix = valid ? e.init_table[lane * 3 + 0] : 0.0f, tiy = valid ? e.init_table[lane * 3 + 1] : 0.0f;
     const float tith = valid ? e.init_table[lane * 3 + 2] : 0.0f;
     const float tgx = valid ? e.goal_table[lane * 2 + 0] : 0.0f, tgy = valid ? e.goal_table[lane * 2 + 1] : 0.0f;
-    const float4 hd = e.head[n];   // sin / cos of th and the field entry of the robot's cell, kept by whoever moved it
+    const float4 hd = head_p[n];   // sin / cos of th and the field entry of the robot's cell, kept by whoever moved it
     // a robot whose script no longer sends cmd_vel (dead, ppo_stage2.py:72-74): idles, or -- hold_velocity, what Stage
     // does with the last SetSpeed -- keeps driving at the command it was given last
     float held_v = 0.0f, held_w = 0.0f;
@@ -688,10 +694,15 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // default one does not carry the code: with the raster walk behind a run-time branch the default launch was 0.85 us slower
 // (A/B on one box, profiles/r04_h_ab_raster_path_in_default_kernel.txt: twice the instructions for the same instruction cache)
 template <int K, bool BIG, bool SEQ, bool RASTER = false>
-__global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh) {
+__global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_first, int ray_count, int R_,
+                                                       const float* __restrict__ pose_p, const float4* __restrict__ head_p,
+                                                       const float* __restrict__ bcos_p, const float* __restrict__ bsin_p,
+                                                       uint8_t* ring_head_p, EnvView e) {
+    // (the leading arguments repeat e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head: 14
+    // dwords preloaded into SGPRs, see move_kernel)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     MRCA_RSTAMP(0);
-    const int n = e.ray_first + block_to_robot(blockIdx.x, e.ray_count);
+    const int n = ray_first + block_to_robot(blockIdx.x, ray_count);
     const int tid = threadIdx.x;
     // (A variant of this kernel without the early exit -- so that nothing is waited for before every request of the
     // workgroup is out -- was measured and changed nothing: 27.96 us either way, profiles/r03/r03_l_bench_env.json.  The
@@ -714,8 +725,8 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     const int prep_base = extra ? T : 0;
     const bool is_prep = tid >= prep_base && tid < prep_base + kWave;   // wave-uniform
     const bool marches = tid < T;                                       // wave-uniform
-    const int world = n / e.R;
-    const int local = n - world * e.R;
+    const int world = n / R_;
+    const int local = n - world * R_;
     // the robot's own record: pose, sin / cos and the field entry of its cell.  Block-uniform -- but fetched with VECTOR
     // loads (the index goes through an opaque zero): as scalar loads they shared the out-of-order scalar counter with
     // the kernel arguments, and the neighbour candidate below could not be requested before they were back.
@@ -724,32 +735,32 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
     int lane_zero = 0;
     if constexpr (!BIG) asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     const int nv = n + lane_zero;
-    const float x = e.pose[nv * 3 + 0], y = e.pose[nv * 3 + 1];
-    const float4 hd = e.head[nv];
+    const float x = pose_p[nv * 3 + 0], y = pose_p[nv * 3 + 1];
+    const float4 hd = head_p[nv];
     const float s = hd.x, c = hd.y;
     // the preparation wave requests "its" neighbour candidate in the same memory round trip
     const int pl = tid - prep_base;
-    const bool cand = !BIG && is_prep && (pl < e.R) && (pl != local);
-    const int jn = world * e.R + (cand ? pl : local);
+    const bool cand = !BIG && is_prep && (pl < R_) && (pl != local);
+    const int jn = world * R_ + (cand ? pl : local);
     float xj = 0.0f, yj = 0.0f;
     float4 hj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (!BIG && is_prep) {
-        xj = e.pose[jn * 3 + 0];
-        yj = e.pose[jn * 3 + 1];
-        hj = e.head[jn];
+        xj = pose_p[jn * 3 + 0];
+        yj = pose_p[jn * 3 + 1];
+        hj = head_p[jn];
     }
     // beam directions in the robot frame for this thread's K beams (tid + k*T)
     float bc[K], bs[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int b = (marches ? tid : 0) + k * T;
-        bc[k] = e.beam_cos[b];
-        bs[k] = e.beam_sin[b];
+        bc[k] = bcos_p[b];
+        bs[k] = bsin_p[b];
     }
     // slot of the newest frame so far (read by every thread BEFORE the first barrier, advanced by thread 0 after it) and
     // the fresh flag: requested last, used last
     const uint8_t fresh_byte = e.fresh[n];
-    const int ring_slot = e.ring_head[n];
+    const int ring_slot = ring_head_p[n];
     // (The frame stack -- ppo_stage1.py:87-89: popleft / append -- is a ring of raw scans: only the newest one is written,
     // into the slot behind the previous newest one; see materialize_kernel.)
     // big worlds: the candidates come from the lidar hash (3 x 3 cells of 6.5 m around the robot's cell) and may
@@ -793,9 +804,9 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
             float cxj = 0.0f, cyj = 0.0f;
             float4 chj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             int lo = 0, hi = -1;
-            if (j >= 0 && j != n && j / e.R == world) {
-                cxj = e.pose[j * 3 + 0];
-                cyj = e.pose[j * 3 + 1];
+            if (j >= 0 && j != n && j / R_ == world) {
+                cxj = pose_p[j * 3 + 0];
+                cyj = pose_p[j * 3 + 1];
                 // a bucket may hold other cells too (hash collisions) and the same bucket may serve two of the nine
                 // cells: a robot counts only for the cell it really is in, so nobody is listed twice
                 if (hash_cell_coord(cxj, kLidarCell) == qx && hash_cell_coord(cyj, kLidarCell) == qy) {
@@ -804,7 +815,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
                         beam_interval(ddx * c + ddy * s, ddy * c - ddx * s, e.B, e.beam_step, e.beam_inv_step, e.lidar_radius,
                                       e.lidar_near, &lo, &hi);
                         keep = lo <= hi;
-                        if (keep) chj = e.head[j];
+                        if (keep) chj = head_p[j];
                     }
                 }
             }
@@ -1001,7 +1012,7 @@ __global__ __launch_bounds__(1024) void raycast_kernel(EnvView e, int only_fresh
                 __builtin_nontemporal_store(r, &ring_row[new_slot * e.B + b]);
             }
         }
-        if (tid == 0 && !fresh) e.ring_head[n] = (uint8_t)new_slot;
+        if (tid == 0 && !fresh) ring_head_p[n] = (uint8_t)new_slot;
     }
     if (tid == 0) {  // get_local_goal (stage_world1.py:155-160)
         const float gx = e.goal[n * 2 + 0] - x, gy = e.goal[n * 2 + 1] - y;
@@ -1433,9 +1444,10 @@ void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent
     if (!e.big) {
         if (start || stop)
             hipExtLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), (uint32_t)move_lds_bytes(e), s, start, stop, 0,
-                                  e, actions);
+                                  e.R, e.pose, e.head, actions, e.live, e);
         else
-            hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e, actions);
+            hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e.R, e.pose, e.head, actions,
+                               e.live, e);
         return;
     }
     // (the collision hash's heads and the lidar hash's counts are left clean by the tick before: bw_finish_kernel /
@@ -1516,10 +1528,12 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t 
 #define MRCA_RAY4(K, BIG, SEQ, RASTER)                                                                                        \
     do {                                                                                                               \
         if (start || stop)                                                                                             \
-            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0, e,  \
-                                  only_fresh);                                                                         \
+            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0,     \
+                                  only_fresh, e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin,         \
+                                  e.ring_head, e);                                                                       \
         else                                                                                                           \
-            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), lds, s, e, only_fresh);     \
+            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), lds, s, only_fresh, e.ray_first,    \
+                               e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head, e);              \
     } while (0)
     if (raster_mode) {
         if (e.ray_shift == 0) MRCA_RAY4(1, false, false, true);
