@@ -30,6 +30,10 @@ def device_asm(tmp_path_factory):
     flags = re.findall(r"^\s+(-f[\w=-]+(?:\s+-f[\w=-]+)*)", open(os.path.join(CSRC, "build.sh")).read(), re.M)
     flags = " ".join(flags).split()
     assert "-ffp-contract=off" in flags and "-fhip-fp32-correctly-rounded-divide-sqrt" in flags, flags
+    # + the per-file flags of mrca_kernels.hip (the kernel-argument preload)
+    per = re.search(r'"\$\{src\}" == "mrca_kernels" \]\] && per=\(([^)]*)\)', open(os.path.join(CSRC, "build.sh")).read())
+    assert per, "build.sh no longer gives mrca_kernels.hip its per-file flags"
+    flags += per.group(1).split()
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S", "--cuda-device-only",
                     os.path.join(CSRC, "mrca_kernels.hip"), "-o", str(out)], check=True, capture_output=True)
     return open(out).read().split("\n")
@@ -83,3 +87,16 @@ def test_register_budget_and_no_scratch(device_asm):
             assert vgpr <= 64, f"{name} needs {vgpr} VGPRs: fewer than 8 waves per SIMD"
         else:
             assert vgpr <= 128, f"{name} needs {vgpr} VGPRs"
+
+
+def test_env_kernels_get_their_leading_arguments_preloaded(device_asm):
+    """move_kernel and every raycast_kernel lead with the scalars / pointers their first loads need, and the build asks for
+    gfx950's kernel-argument preload: the descriptor of each must say so (14 dwords for the ray cast, 10 for the move
+    kernel: R + four pointers + padding), or the loads wait for the s_load of the EnvView again."""
+    text = "\n".join(device_asm)
+    lengths = {m.group(1): int(m.group(2)) for m in
+               re.finditer(r"\.amdhsa_kernel (\S+).*?\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text, re.S)}
+    ray = [v for k, v in lengths.items() if "raycast_kernel" in k]
+    move = [v for k, v in lengths.items() if "move_kernel" in k]
+    assert len(ray) == 12 and all(v == 14 for v in ray), lengths
+    assert move == [10], lengths
