@@ -55,7 +55,7 @@ struct Layout {
     size_t field_off[MRCA_F_COUNT];
     size_t field_bytes[MRCA_F_COUNT];
     size_t off_reset_mode, off_goal_mode, off_group_id, off_init_table, off_goal_table;
-    size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield, off_head;
+    size_t off_beam_cos, off_beam_sin, off_map, off_free_rect, off_cellfield, off_head, off_outline;
     // big worlds (robots_per_world > 64) only
     size_t off_bw_ticket, off_bw_prov, off_bw_state, off_bw_chead, off_bw_cnext, off_bw_lstart, off_bw_lcount, off_bw_lsorted, off_bw_lblock, off_bw_lcursor;
     size_t off_status;
@@ -75,9 +75,9 @@ int validate(const mrca_config* c) {
         return fail(MRCA_ERR_UNSUPPORTED, "robots_per_world %d > 64 with group-synchronous episodes (auto_reset 2)",
                     c->robots_per_world);
     if (!(c->collision_raster >= 0.0f)) return fail(MRCA_ERR_INVALID, "collision_raster must be >= 0");
-    if (c->collision_raster > 0.0f && c->collision_raster < 0.1f)
-        return fail(MRCA_ERR_UNSUPPORTED, "collision_raster %.3f m: the outline lists hold cells of >= 0.1 m",
-                    (double)c->collision_raster);
+    if (c->collision_raster > 0.0f && (c->collision_raster < 0.1f || mrca::outline_span(1.0f / c->collision_raster) > mrca::kOutlineWin))
+        return fail(MRCA_ERR_UNSUPPORTED, "collision_raster %.3f m: an outline is kept as an 8 x 8 bitmap of raster cells, which "
+                    "holds cells of >= 0.1 m", (double)c->collision_raster);
     if (c->collision_raster > 0.0f && c->robots_per_world > 64)
         return fail(MRCA_ERR_UNSUPPORTED, "collision_raster with robots_per_world > 64");
     if ((int64_t)c->num_worlds * c->robots_per_world > (1 << 24))
@@ -158,6 +158,7 @@ void make_layout(const mrca_config* c, Layout* L) {
                             4 * sizeof(uint16_t));
     L->off_cellfield = take((size_t)c->map_width * c->map_height);
     L->off_head = take(N * sizeof(float4));
+    L->off_outline = take(c->collision_raster > 0.0f ? N * sizeof(mrca::OutlineBits) : 0);   // fidelity mode only
     L->bw_cmask = L->bw_lmask = 0;
     if (c->robots_per_world > 64) {
         size_t mc = 1, ml = 1;
@@ -394,6 +395,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.free_rect_pitch = free_rect_pitch;
     v.cellfield = reinterpret_cast<const uint8_t*>(a + L.off_cellfield);
     v.head = reinterpret_cast<float4*>(a + L.off_head);
+    v.outline = cfg->collision_raster > 0.0f ? reinterpret_cast<mrca::OutlineBits*>(a + L.off_outline) : nullptr;
     v.big = R > 64 ? 1 : 0;
     if (v.big) {
         v.bw_ticket = reinterpret_cast<uint32_t*>(a + L.off_bw_ticket);
@@ -430,6 +432,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
     v.raster_inv = cfg->collision_raster > 0.0f ? 1.0f / cfg->collision_raster : 0.0f;
     v.raster_res = cfg->collision_raster;
+    // the ray cast tests 4 x 4 cells of a neighbour's outline window where that covers every outline (Stage's 0.2 m), else 8 x 8
+    v.raster_kw = (cfg->collision_raster > 0.0f && mrca::outline_span(v.raster_inv) <= 4) ? 4 : 8;
     v.lidar_radius = 0.2917f;
     v.lidar_near = 0.30f;
     v.lidar_reach2 = mrca::kLidarReach2;
@@ -570,6 +574,10 @@ int mrca_check(mrca_env* env, void* stream) {
         return fail(MRCA_ERR_HIP, "collision pass of a world with more than 64 robots gave up waiting for a lower-indexed "
                                   "robot (its bounded wait ran out): at least one robot was left undecided since the last "
                                   "check; the env's state is not to be trusted");
+    if (bits & mrca::kStatusOutlineWindow)
+        return fail(MRCA_ERR_HIP, "fidelity mode: a cell of a robot's outline fell outside the 8 x 8 window of its bitmap since the "
+                                  "last check (coordinates beyond the supported range?); collisions and lidar returns of that "
+                                  "robot are not to be trusted");
     return fail(MRCA_ERR_HIP, "device status word 0x%x", bits);
 }
 

@@ -582,6 +582,129 @@ MRCA_HD bool cells_intersect(const long long* a, int na, const long long* b, int
     return hit;
 }
 
+// The same outline as an ANCHORED BITMAP (what the kernels keep: round 5).  Every point of the outline lies within the
+// footprint's circumradius (0.29069 m) of the centre, so its raster cells fall into a window of
+// floor(2 * 0.2927 / res) + 2 <= 7 columns / rows (res >= 0.1 m) that starts at the cell of (centre - 0.2927 m): the SET of
+// outline cells -- all the collision rule and the raster lidar ever ask about -- is 64 bits, bit jy * 8 + jx for the cell
+// (ax + jx, ay + jy), plus the anchor.  A robot's record is 16 bytes, lives in registers, and is published per robot next
+// to its `head` record by whoever moves it (EnvView::outline); two outlines meet iff one bitmap, shifted by the anchors'
+// difference, ANDs with the other -- a dozen integer instructions where rounds 3-4 compared two 40-entry cell lists in LDS
+// (1600 64-bit compares per pair, between two workgroup barriers per turn of the ordered pass).
+constexpr float kOutlineReach = 0.2927f;   // circumradius + 2 mm: far beyond any rounding of the corner positions
+constexpr int kOutlineWin = 8;             // window side in cells
+struct OutlineBits {
+    int32_t ax, ay;       // raster cell of the window's (0, 0) corner
+    uint32_t lo, hi;      // rows 0..3 | rows 4..7, bit (jy & 3) * 8 + jx
+};
+MRCA_HD int outline_anchor(float v, float inv_res) { return (int)floorf((v - kOutlineReach) * inv_res); }
+// columns / rows of the window an outline can occupy at this resolution (host side: validation, kernel variant)
+MRCA_HD int outline_span(float inv_res) { return (int)floorf((0.2907f + kOutlineReach + 0.002f) * inv_res) + 2; }
+
+// the cells of outline edge k of the pose (x, y, sin, cos) -- walk_cells, i.e. exactly outline_cells' cells -- ORed into
+// (*lo, *hi) relative to the anchor; false if a cell fell outside the window (never, for res >= 0.1 m: the callers raise
+// the env's status word instead of dropping it silently)
+MRCA_HD bool outline_edge_bits(float inv_res, float x, float y, float s, float c, int k, int ax, int ay, uint32_t* lo,
+                               uint32_t* hi) {
+    const float hx = (k == 0 || k == 3) ? kHalfLen : -kHalfLen;
+    const float hy = (k < 2) ? kHalfWid : -kHalfWid;
+    const float ex = (k == 0) ? -c : (k == 1) ? s : (k == 2) ? c : -s;
+    const float ey = (k == 0) ? -s : (k == 1) ? -c : (k == 2) ? s : c;
+    const float el = (k & 1) ? 2.0f * kHalfWid : 2.0f * kHalfLen;
+    const float cx = x + (hx * c - hy * s);
+    const float cy = y + (hx * s + hy * c);
+    bool ok = true;
+    uint32_t l = *lo, h = *hi;
+    walk_cells(inv_res, cx, cy, ex, ey, el, [&](int ix, int iy) {
+        const int jx = ix - ax, jy = iy - ay;
+        const bool in = (unsigned)jx < (unsigned)kOutlineWin && (unsigned)jy < (unsigned)kOutlineWin;
+        ok = ok && in;
+        const uint32_t m = in ? 1u << (((jy & 3) << 3) + jx) : 0u;
+        l |= jy < 4 ? m : 0u;
+        h |= jy < 4 ? 0u : m;
+    });
+    *lo = l;
+    *hi = h;
+    return ok;
+}
+MRCA_HD bool outline_bits(float inv_res, float x, float y, float s, float c, OutlineBits* out) {
+    OutlineBits o{outline_anchor(x, inv_res), outline_anchor(y, inv_res), 0u, 0u};
+    bool ok = true;
+    for (int k = 0; k < 4; ++k) ok = outline_edge_bits(inv_res, x, y, s, c, k, o.ax, o.ay, &o.lo, &o.hi) && ok;
+    *out = o;
+    return ok;
+}
+
+// do two outlines share a raster cell?  q's bitmap is moved into p's window (columns by the anchors' x difference, rows by
+// the y difference; what leaves the window cannot be a cell of p) and ANDed.
+MRCA_HD bool outline_bits_meet(const OutlineBits& p, const OutlineBits& q) {
+    const int dx = q.ax - p.ax, dy = q.ay - p.ay;
+    if (dx <= -kOutlineWin || dx >= kOutlineWin || dy <= -kOutlineWin || dy >= kOutlineWin) return false;
+    const uint64_t P = (uint64_t)p.lo | ((uint64_t)p.hi << 32);
+    uint64_t Q = (uint64_t)q.lo | ((uint64_t)q.hi << 32);
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    const uint64_t keep = 0x0101010101010101ull * (uint64_t)(0xFFu >> adx);      // the columns that stay inside the window
+    Q = dx >= 0 ? (Q & keep) << adx : (Q >> adx) & keep;
+    Q = dy >= 0 ? Q << (8 * ady) : Q >> (8 * ady);
+    return (P & Q) != 0ull;
+}
+
+// Fidelity mode's lidar return of ONE other robot, in closed form.  grid_march's walk is a two-way merge of the x
+// crossings tx(b) = (float(b) - fx) * (1 / dx) and the y crossings ty(b) (both monotone in b; tx < ty steps in x, ties and
+// ty < tx in y), so WHICH cells a ray visits and WHEN it enters them follows from four crossing times per cell, without
+// walking: the ray is in column c from the crossing of c's near face (time -inf for the origin's column, +inf for a column
+// behind the origin or for any other column of a ray with dx = 0) until the crossing of its far face, likewise for rows;
+// cell (c, r) is visited iff   enterX(c) < leaveY(r)   (the merge takes x_i before y_{j+1} iff tx_i < ty_{j+1})   and
+// not leaveX(c) < enterY(r)   (it takes y_j before x_{i+1} iff not tx_{i+1} < ty_j),   and is entered at
+// max(enterX(c), enterY(r)) -- the later of the two crossings, the value grid_march returns.  Entry times never decrease
+// along the walk, so the first marked cell the walk meets is the marked visited cell with the smallest entry time, and the
+// minimum over several robots' outlines is the walk through the union of their marks.  KW x KW cells of the neighbour's
+// window are tested (KW = 4 covers res >= 0.195 m -- Stage's 0.2 m -- KW = 8 everything down to 0.1 m).  Returns the entry time
+// in CELLS (0 when the origin's cell is marked), +inf when the ray meets no marked cell; the caller applies t < tmax and
+// * res exactly as grid_march does.  Rounds 3-4 walked a window of LDS bits cell by cell (up to 60 dependent LDS reads per
+// beam); tests/test_fidelity_closed_form.py holds this against that walk on adversarial rays.
+template <int KW>
+MRCA_HD float ray_outline_entry(float fx, float fy, int ix0, int iy0, float dx, float dy, float inv_dx, float inv_dy,
+                                const OutlineBits& o) {
+    const bool xnz = dx != 0.0f, ynz = dy != 0.0f;
+    const bool xpos = dx > 0.0f, ypos = dy > 0.0f;
+    float eX[KW], lX[KW], eY[KW], lY[KW];
+    {
+        float T[KW + 1];
+#pragma unroll
+        for (int q = 0; q <= KW; ++q) T[q] = ((float)(o.ax + q) - fx) * inv_dx;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            const int rel = o.ax + j - ix0;
+            const bool behind = xpos ? rel < 0 : rel > 0;
+            const float en = xpos ? T[j] : T[j + 1], lv = xpos ? T[j + 1] : T[j];
+            eX[j] = rel == 0 ? -kInf : ((behind || !xnz) ? kInf : en);
+            lX[j] = xnz ? lv : kInf;
+        }
+#pragma unroll
+        for (int q = 0; q <= KW; ++q) T[q] = ((float)(o.ay + q) - fy) * inv_dy;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            const int rel = o.ay + j - iy0;
+            const bool behind = ypos ? rel < 0 : rel > 0;
+            const float en = ypos ? T[j] : T[j + 1], lv = ypos ? T[j + 1] : T[j];
+            eY[j] = rel == 0 ? -kInf : ((behind || !ynz) ? kInf : en);
+            lY[j] = ynz ? lv : kInf;
+        }
+    }
+    float best = kInf;
+#pragma unroll
+    for (int jy = 0; jy < KW; ++jy) {
+        const uint32_t row = ((jy < 4 ? o.lo : o.hi) >> ((jy & 3) << 3)) & 0xFFu;
+#pragma unroll
+        for (int jx = 0; jx < KW; ++jx) {
+            const bool visited = (eX[jx] < lY[jy]) & !(lX[jx] < eY[jy]) & (((row >> jx) & 1u) != 0u);
+            const float t = eX[jx] < eY[jy] ? eY[jy] : eX[jx];
+            best = (visited & (t < best)) ? t : best;
+        }
+    }
+    return best > 0.0f ? best : 0.0f;      // the origin's own cell is entered at "-inf": range 0
+}
+
 // Separating-axis test of two robot rectangles; touching counts as overlap.
 MRCA_HD bool obb_overlap(float xi, float yi, float si, float ci, float xj, float yj, float sj, float cj) {
     const float tx = xj - xi;

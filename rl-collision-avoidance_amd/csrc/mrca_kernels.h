@@ -36,6 +36,10 @@ struct EnvView {
     // cos of the heading (deterministic sincos_det) and the four quadrant entries of the free-rectangle field for the
     // cell the robot stands in (as float bits).  The ray cast starts from it instead of recomputing all three per wave.
     float4* head;       // [N] (sin, cos, bits(quadrants 0 | 1 << 16), bits(quadrants 2 | 3 << 16))
+    // fidelity mode only (raster_inv > 0): the robot's outline as an anchored 8 x 8 bitmap of raster cells (mrca_device.h
+    // OutlineBits), kept like `head` by whoever changes a pose: the collision pass intersects two of them in registers, the
+    // ray cast tests a beam against one in closed form
+    OutlineBits* outline;   // [N]
     // worlds with more than 64 robots ("big" worlds: one wavefront no longer holds a world): scratch of the
     // per-tick broad phase, see the bw_* kernels.  All NULL / 0 otherwise.
     int32_t big;            // 1: robots_per_world > 64
@@ -78,6 +82,7 @@ struct EnvView {
     uint32_t key0, key1;
     float raster_inv;     // fidelity mode: 1 / collision_raster (0 = exact rectangles), see mrca_device.h outline_cells
     float raster_res;     // collision_raster itself (fidelity mode: the lidar sees the other robots through this raster too)
+    int32_t raster_kw;    // cells per side of an outline's window the ray cast tests: 4 (res >= 0.195 m) or 8
     // the ray cast's neighbour culls: what another robot lies inside of seen from its centre (circumradius + 1 mm; in
     // fidelity mode + one raster-cell diagonal), the centre distance below which every beam is kept, and the squared centre
     // distance beyond which it cannot return a range below 6 m
@@ -93,6 +98,7 @@ struct EnvView {
 
 // bits of EnvView::status
 constexpr uint32_t kStatusCollideUndecided = 1u;   // bw_collide_kernel gave up waiting for a lower-indexed robot
+constexpr uint32_t kStatusOutlineWindow = 2u;      // fidelity mode: an outline cell fell outside the 8 x 8 window of its bitmap
 
 // Ablation switches exist only in the profiling build of the library (csrc/build.sh --profiling ->
 // libmrca_env_prof.so, used by tools/ablate.py); in the product they fold to `false` at compile time.

@@ -287,6 +287,12 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const 
     const float tith = valid ? e.init_table[lane * 3 + 2] : 0.0f;
     const float tgx = valid ? e.goal_table[lane * 2 + 0] : 0.0f, tgy = valid ? e.goal_table[lane * 2 + 1] : 0.0f;
     const float4 hd = head_p[n];   // sin / cos of th and the field entry of the robot's cell, kept by whoever moved it
+    // fidelity mode (collision_raster): robots collide when their OUTLINES SHARE A RASTER CELL (Stage's rule) instead of when
+    // their rectangles overlap.  An outline is an anchored 8 x 8 bitmap (mrca_device.h OutlineBits); the one of the pose at
+    // tick start comes with the robot's record, kept by whoever moved it
+    const bool raster = e.raster_inv > 0.0f;
+    OutlineBits ob_old{0, 0, 0u, 0u};
+    if (raster) ob_old = e.outline[n];
     // a robot whose script no longer sends cmd_vel (dead, ppo_stage2.py:72-74): idles, or -- hold_velocity, what Stage
     // does with the last SetSpeed -- keeps driving at the command it was given last
     float held_v = 0.0f, held_w = 0.0f;
@@ -422,23 +428,38 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const 
             if (static_edge_hit(mg, e.g, sx_, sy_, ss_, sc_, tid & 3)) hit_flag[src] = 1;
         }
     }
+    // fidelity mode: the outline of every PROVISIONAL pose, four lanes per robot (one per edge: a walk of ~5 raster cells),
+    // all 64 robots of the world in one pass over the block -- next to the walks above, behind the same barrier.  (Rounds
+    // 3-4: ONE lane walked the four edges of the robot taking its turn INSIDE the ordered pass, into a list in LDS, between
+    // two workgroup barriers per turn: 181 us per launch on the Stage-1 worlds, 316 us on Stage-2.)
+    uint2* bm_new = reinterpret_cast<uint2*>(inv_part + kMoveWaves * kWave);   // [64] bitmap of the provisional outline
+    if (raster) {
+        const int q = tid >> 2, k = tid & 3;
+        const float qx = __shfl(nx, q, kWave), qy = __shfl(ny, q, kWave);
+        const float qs = __shfl(ns, q, kWave), qc = __shfl(nc, q, kWave);
+        const bool qmoving = __shfl(moving ? 1 : 0, q, kWave) != 0;
+        uint32_t lo = 0u, hi = 0u;
+        bool ok = true;
+        if (qmoving)
+            ok = outline_edge_bits(e.raster_inv, qx, qy, qs, qc, k, outline_anchor(qx, e.raster_inv),
+                                   outline_anchor(qy, e.raster_inv), &lo, &hi);
+        lo |= __shfl_xor(lo, 1, kWave);
+        hi |= __shfl_xor(hi, 1, kWave);
+        lo |= __shfl_xor(lo, 2, kWave);
+        hi |= __shfl_xor(hi, 2, kWave);
+        if (k == 0) bm_new[q] = make_uint2(lo, hi);
+        if (!ok) atomicOr(e.status, kStatusOutlineWindow);     // never, for res >= 0.1 m (mrca_check reports it)
+    }
     __syncthreads();
     if (wave != 0) return;      // the helpers are done; wave 0 carries the rest of the tick
     const bool shit = need && hit_flag[lane] != 0;
     MRCA_STAMP(4);      // outline walks done
-
-    // --- fidelity mode (collision_raster): robots collide when their OUTLINES SHARE A RASTER CELL (Stage's rule) instead
-    //     of when their rectangles overlap.  Every robot's current outline cells live in LDS; a robot that commits a
-    //     move inside the ordered pass replaces its own.
-    const bool raster = e.raster_inv > 0.0f;
-    long long* cur_cells = reinterpret_cast<long long*>(inv_part + kMoveWaves * kWave);   // [64][kMaxOutlineCells]
-    int* cur_n = reinterpret_cast<int*>(cur_cells + kWave * kMaxOutlineCells);   // [64]
-    long long* turn_cells = reinterpret_cast<long long*>(cur_n + kWave);         // [kMaxOutlineCells]
-    int* turn_n = reinterpret_cast<int*>(turn_cells + kMaxOutlineCells);
-    if (raster) {
-        if (valid) cur_n[lane] = outline_cells(e.raster_inv, x, y, s, c, cur_cells + lane * kMaxOutlineCells);
-        __syncthreads();
+    OutlineBits ob_new = ob_old;              // a robot that stands still keeps its outline
+    if (raster && moving) {
+        const uint2 b = bm_new[lane];
+        ob_new = OutlineBits{outline_anchor(nx, e.raster_inv), outline_anchor(ny, e.raster_inv), b.x, b.y};
     }
+    OutlineBits ob_cur = ob_old;              // follows the commits, like (x, y, s, c)
 
     // --- collision pass in robot order (Stage's sequential model loop)
     // committed pose of a robot that is not involved: moves unless the map stops it
@@ -453,6 +474,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const 
         c = nc;
         cellv = cellv_new;
         cellw = cellw_new;
+        ob_cur = ob_new;
     }
     {
         unsigned long long turn = __ballot(involved);
@@ -465,13 +487,11 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const 
             const float cx_ = later ? ox_ : x, cy_ = later ? oy_ : y, cs_ = later ? os_ : s, cc_ = later ? oc_ : c;
             bool ov;
             if (raster) {
-                // robot i's provisional outline goes to LDS, everybody in reach compares it with the outline of the
-                // pose they have now (cur_cells follows the commits, so "later" robots still hold their old outline)
-                if (lane == i) *turn_n = outline_cells(e.raster_inv, xi, yi, si, ci, turn_cells);
-                __syncthreads();
-                const float ax = cx_ - xi, ay = cy_ - yi;
-                ov = valid && (lane != i) && (ax * ax + ay * ay <= e.collide_reach2) &&
-                     cells_intersect(cur_cells + lane * kMaxOutlineCells, cur_n[lane], turn_cells, *turn_n);
+                // robot i's provisional outline is broadcast like its pose; every lane intersects it, in registers, with the
+                // outline of the pose it has at this point of the order
+                const OutlineBits oi{ibcast(ob_new.ax, i), ibcast(ob_new.ay, i), (uint32_t)ibcast((int)ob_new.lo, i),
+                                     (uint32_t)ibcast((int)ob_new.hi, i)};
+                ov = valid && (lane != i) && outline_bits_meet(oi, later ? ob_old : ob_cur);
             } else {
                 ov = valid && (lane != i) && obb_overlap(xi, yi, si, ci, cx_, cy_, cs_, cc_);
             }
@@ -487,15 +507,10 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const 
                     cellv = cellv_new;
                     cellw = cellw_new;
                     moved = true;
-                    if (raster) {
-                        const int tn = *turn_n;
-                        for (int q = 0; q < tn; ++q) cur_cells[lane * kMaxOutlineCells + q] = turn_cells[q];
-                        cur_n[lane] = tn;
-                    }
+                    ob_cur = ob_new;
                 }
                 crashed = hit ? 1 : 0;
             }
-            if (raster) __syncthreads();   // turn_cells / cur_cells settled before the next turn
         }
     }
 
@@ -595,6 +610,25 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const 
         sincos_det(th, &s, &c);
         rect_field.cell((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell), &cellv, &cellw);
     }
+    if (raster) {   // ... and their outlines: lanes 0..3 walk the four edges of one restarted robot's new pose
+        unsigned long long fm = __ballot(fresh);
+        bool ok = true;
+        while (fm) {
+            const int src = __ffsll((long long)fm) - 1;
+            fm &= fm - 1;
+            const float fx_ = fbcast(x, src), fy_ = fbcast(y, src), fs_ = fbcast(s, src), fc_ = fbcast(c, src);
+            const int ax = outline_anchor(fx_, e.raster_inv), ay = outline_anchor(fy_, e.raster_inv);
+            uint32_t lo = 0u, hi = 0u;
+            if (lane < 4) ok = outline_edge_bits(e.raster_inv, fx_, fy_, fs_, fc_, lane, ax, ay, &lo, &hi) && ok;
+            lo |= __shfl_xor(lo, 1, kWave);
+            hi |= __shfl_xor(hi, 1, kWave);
+            lo |= __shfl_xor(lo, 2, kWave);
+            hi |= __shfl_xor(hi, 2, kWave);
+            const uint32_t lo0 = (uint32_t)ibcast((int)lo, 0), hi0 = (uint32_t)ibcast((int)hi, 0);
+            if (lane == src) ob_cur = OutlineBits{ax, ay, lo0, hi0};
+        }
+        if (!ok) atomicOr(e.status, kStatusOutlineWindow);
+    }
 
     MRCA_STAMP(7);      // restarts done
     if (valid) {
@@ -618,6 +652,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const 
         e.episode[n] = ep;
         e.fresh[n] = fresh ? 1 : 0;
         e.head[n] = make_float4(s, c, __uint_as_float(cellv), __uint_as_float(cellw));
+        if (raster) e.outline[n] = ob_cur;
     }
     MRCA_STAMP(8);      // stores drained
 }
@@ -629,6 +664,11 @@ __device__ __forceinline__ void write_head(const EnvView& e, int n, float x, flo
     uint32_t v0, v1;
     rect_field.cell((int)floorf((x - e.g.x0) * e.g.inv_cell), (int)floorf((y - e.g.y0) * e.g.inv_cell), &v0, &v1);
     e.head[n] = make_float4(s, c, __uint_as_float(v0), __uint_as_float(v1));
+    if (e.raster_inv > 0.0f) {   // fidelity mode: the outline of the new pose
+        OutlineBits o;
+        if (!outline_bits(e.raster_inv, x, y, s, c, &o)) atomicOr(e.status, kStatusOutlineWindow);
+        e.outline[n] = o;
+    }
 }
 
 // head records from the poses as they are (mrca_create: before the first reset every robot sits at the origin)
@@ -690,10 +730,12 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // walking several robots each -- 39 vs 37 us, profiles/r01/r01_ad_ablation.txt -- and nontemporal stores made
 // no difference.)  Marching the K beams of a thread in LOCK STEP (grid_march_skip_n: K lookups in flight per wait) is
 // implemented and measured too: slower than one after the other (34.7 vs 28.1 us, profiles/r02/r02_c_*), see mrca_abi.hip.
-// RASTER: fidelity mode's lidar (the other robots seen through the collision raster) -- a kernel of its own so that the
-// default one does not carry the code: with the raster walk behind a run-time branch the default launch was 0.85 us slower
-// (A/B on one box, profiles/r04_h_ab_raster_path_in_default_kernel.txt: twice the instructions for the same instruction cache)
-template <int K, bool BIG, bool SEQ, bool RASTER = false>
+// RKW > 0: fidelity mode's lidar (the other robots seen through the collision raster; RKW = cells per side of an outline's
+// window, 4 or 8) -- a kernel of its own so that the default one does not carry the code: with the raster path behind a
+// run-time branch the default launch was 0.85 us slower (A/B on one box, profiles/r04_h_ab_raster_path_in_default_kernel.txt:
+// twice the instructions for the same instruction cache).  Since round 5 a beam's return from another robot's outline is a
+// closed form over that robot's 16-byte outline record (ray_outline_entry) instead of a walk through a window of LDS bits.
+template <int K, bool BIG, bool SEQ, int RKW = 0>
 __global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_first, int ray_count, int R_,
                                                        const float* __restrict__ pose_p, const float4* __restrict__ head_p,
                                                        const float* __restrict__ bcos_p, const float* __restrict__ bsin_p,
@@ -714,11 +756,9 @@ __global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_f
     int* nb_count = reinterpret_cast<int*>(nbi + kWave);
     unsigned long long* nbmask = reinterpret_cast<unsigned long long*>(nb_count + 4);   // [B] neighbours per beam
     int* nb_more = nb_count + 1;                                      // big worlds: another chunk of neighbours follows
-    // fidelity mode (never in big worlds): the window of raster cells holding the other robots' outlines
-    constexpr bool raster = RASTER && !BIG;
-    uint32_t* win_bits = reinterpret_cast<uint32_t*>(nbmask + e.B);
-    const int win_reach = raster ? raster_window_reach(e.raster_inv) : 0;
-    const int win_side = 2 * win_reach + 1, win_wpr = (win_side + 31) >> 5;
+    // fidelity mode (never in big worlds): the neighbours' outline records
+    constexpr bool raster = RKW > 0 && !BIG;
+    int4* nbo = reinterpret_cast<int4*>(nbmask + e.B);   // [64] OutlineBits as (ax, ay, lo, hi)
 
     const int T = e.B / K;                    // marching threads
     const bool extra = (int)blockDim.x > T;   // a dedicated preparation wave sits behind the marching ones
@@ -744,10 +784,12 @@ __global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_f
     const int jn = world * R_ + (cand ? pl : local);
     float xj = 0.0f, yj = 0.0f;
     float4 hj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int4 oj = make_int4(0, 0, 0, 0);
     if (!BIG && is_prep) {
         xj = pose_p[jn * 3 + 0];
         yj = pose_p[jn * 3 + 1];
-        hj = head_p[jn];
+        if constexpr (raster) oj = reinterpret_cast<const int4*>(e.outline)[jn];
+        else hj = head_p[jn];
     }
     // beam directions in the robot frame for this thread's K beams (tid + k*T)
     float bc[K], bs[K];
@@ -861,10 +903,14 @@ __global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_f
         if (keep) {
             const int idx = __popcll(m & ((1ull << pl) - 1ull));
             // the slab tests want the lidar's origin in the neighbour's frame (once per neighbour, not per beam); the
-            // fidelity mode's outline walk wants the neighbour's centre
-            float olx = xj, oly = yj;
-            if (!raster) ray_box_origin(x, y, xj, yj, hj.x, hj.y, &olx, &oly);
-            nb[idx] = make_float4(olx, oly, hj.x, hj.y);
+            // fidelity mode's closed form wants the neighbour's outline record
+            if constexpr (raster) {
+                nbo[idx] = oj;
+            } else {
+                float olx, oly;
+                ray_box_origin(x, y, xj, yj, hj.x, hj.y, &olx, &oly);
+                nb[idx] = make_float4(olx, oly, hj.x, hj.y);
+            }
             nbi[idx] = make_int2(lo, hi);
         }
         const int cnt0 = MRCA_DBG(e, 1) ? 0 : __popcll(m);
@@ -875,30 +921,6 @@ __global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_f
         for (int k = 0; k < cnt0; ++k) {
             const int2 iv = nbi[k];
             for (int b = iv.x + pl; b <= iv.y; b += kWave) mask_or(&nbmask[b], 1ull << k);
-        }
-        if (raster) {
-            // fidelity mode: lane k rasterises neighbour k's outline into the window (the LDS operations of ONE wave
-            // complete in order: the clear, the list above and the marks below need no barrier between them)
-            for (int q = pl; q < win_side * win_wpr; q += kWave) win_bits[q] = 0u;
-            if (pl < cnt0) {
-                const float4 nbq = nb[pl];
-                const int wx0 = (int)floorf(x * e.raster_inv) - win_reach, wy0 = (int)floorf(y * e.raster_inv) - win_reach;
-                for (int k = 0; k < 4; ++k) {       // the four edges, as in outline_cells
-                    const float hx = (k == 0 || k == 3) ? kHalfLen : -kHalfLen;
-                    const float hy = (k < 2) ? kHalfWid : -kHalfWid;
-                    const float ex = (k == 0) ? -nbq.w : (k == 1) ? nbq.z : (k == 2) ? nbq.w : -nbq.z;
-                    const float ey = (k == 0) ? -nbq.z : (k == 1) ? -nbq.w : (k == 2) ? nbq.z : nbq.w;
-                    const float el = (k & 1) ? 2.0f * kHalfWid : 2.0f * kHalfLen;
-                    const float cx = nbq.x + (hx * nbq.w - hy * nbq.z);
-                    const float cy = nbq.y + (hx * nbq.z + hy * nbq.w);
-                    walk_cells(e.raster_inv, cx, cy, ex, ey, el, [&](int ix, int iy) {
-                        const int jx = ix - wx0, jy = iy - wy0;
-                        if ((unsigned)jx < (unsigned)win_side && (unsigned)jy < (unsigned)win_side)
-                            (void)__hip_atomic_fetch_or(&win_bits[jy * win_wpr + (jx >> 5)], 1u << (jx & 31), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                    });
-                }
-            }
         }
       }
     }
@@ -958,15 +980,25 @@ __global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_f
                 const int b = tid + k * T;
                 float r = rng[k];
                 unsigned long long m = cnt > 0 ? nbmask[b] : 0ull;
-                if (raster) {
-                    // fidelity mode: walk the raster window; a beam no neighbour's cells can touch skips the walk
+                if constexpr (raster) {
+                    // fidelity mode: the entry time of the first raster cell of each flagged neighbour's outline the beam's
+                    // walk visits -- in closed form, the same times grid_march's walk over the raster would compare
                     if (m) {
-                        const RasterWindow win{win_bits, (int)floorf(x * e.raster_inv) - win_reach,
-                                               (int)floorf(y * e.raster_inv) - win_reach, win_side, win_wpr};
-                        const GridGeom gr{0.0f, 0.0f, e.raster_res, e.raster_inv, 0, 0, 0};
-                        const float t = grid_march(win, gr, x, y, dx[k], dy[k], kRangeMax);
-                        from_robot[k] = from_robot[k] || t < r;
-                        r = t < r ? t : r;
+                        const float fxr = x * e.raster_inv, fyr = y * e.raster_inv;
+                        const int ixr = (int)floorf(fxr), iyr = (int)floorf(fyr);
+                        const float tmax_c = kRangeMax * e.raster_inv;
+                        const float inv_dx = dx[k] != 0.0f ? rcp_exact(dx[k]) : kInf;
+                        const float inv_dy = dy[k] != 0.0f ? rcp_exact(dy[k]) : kInf;
+                        do {
+                            const int q = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const int4 oq = nbo[q];
+                            const float tc = ray_outline_entry<RKW>(fxr, fyr, ixr, iyr, dx[k], dy[k], inv_dx, inv_dy,
+                                                                    OutlineBits{oq.x, oq.y, (uint32_t)oq.z, (uint32_t)oq.w});
+                            const float t = tc < tmax_c ? tc * e.raster_res : kInf;
+                            from_robot[k] = from_robot[k] || t < r;
+                            r = t < r ? t : r;
+                        } while (m);
                     }
                 } else {
                     while (m) {
@@ -1424,10 +1456,7 @@ void read_move_stamps(unsigned long long* host, int worlds) {      // [kMoveStam
 
 size_t ray_lds_bytes(const EnvView& e) {
     size_t b = kWave * (sizeof(float4) + sizeof(int2)) + 16 + (size_t)e.B * 8;
-    if (e.raster_inv > 0.0f && !e.big) {       // fidelity mode: the window of raster cells with the other robots' outlines
-        const int side = 2 * raster_window_reach(e.raster_inv) + 1;
-        b += (size_t)side * ((side + 31) / 32) * sizeof(uint32_t);
-    }
+    if (e.raster_inv > 0.0f && !e.big) b += kWave * sizeof(OutlineBits);   // fidelity mode: the neighbours' outline records
     return b;
 }
 
@@ -1435,8 +1464,7 @@ size_t move_lds_bytes(const EnvView& e) {
     const int rows = 2 * e.foot_hc + 1;
     const int words = (rows + 31) / 32 + 1;
     size_t b = (size_t)kWave * rows * words * 4 + (2 + kMoveWaves) * kWave * sizeof(int);
-    if (e.raster_inv > 0.0f)   // outline cells of every robot + of the robot taking its turn (fidelity mode)
-        b = (b + 7) / 8 * 8 + (size_t)(kWave + 1) * kMaxOutlineCells * sizeof(long long) + (kWave + 2) * sizeof(int);
+    if (e.raster_inv > 0.0f) b += (size_t)kWave * sizeof(uint2);   // fidelity mode: the provisional outlines' bitmaps
     return b;
 }
 
@@ -1524,20 +1552,25 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t 
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
     const bool seq = e.ray_sequential != 0;
-#define MRCA_RAY(K, BIG, SEQ) MRCA_RAY4(K, BIG, SEQ, false)
-#define MRCA_RAY4(K, BIG, SEQ, RASTER)                                                                                        \
+#define MRCA_RAY(K, BIG, SEQ) MRCA_RAY4(K, BIG, SEQ, 0)
+#define MRCA_RAY4(K, BIG, SEQ, RKWV)                                                                                          \
     do {                                                                                                               \
         if (start || stop)                                                                                             \
-            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0,     \
+            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0,     \
                                   only_fresh, e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin,         \
                                   e.ring_head, e);                                                                       \
         else                                                                                                           \
-            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RASTER>), grid, dim3(threads), lds, s, only_fresh, e.ray_first,    \
+            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV>), grid, dim3(threads), lds, s, only_fresh, e.ray_first,    \
                                e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head, e);              \
     } while (0)
     if (raster_mode) {
-        if (e.ray_shift == 0) MRCA_RAY4(1, false, false, true);
-        else MRCA_RAY4(2, false, true, true);
+        if (e.raster_kw <= 4) {
+            if (e.ray_shift == 0) MRCA_RAY4(1, false, false, 4);
+            else MRCA_RAY4(2, false, true, 4);
+        } else {
+            if (e.ray_shift == 0) MRCA_RAY4(1, false, false, 8);
+            else MRCA_RAY4(2, false, true, 8);
+        }
         return;
     }
     if (e.big) {

@@ -353,6 +353,55 @@ void emul_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
 }
 
+// --- fidelity mode (round 5): the anchored outline bitmaps and the closed-form raster lidar of the kernels against the
+//     cell lists / the cell-by-cell walk they replace (tests/test_fidelity_closed_form.py)
+int emul_outline_bits(float res, float x, float y, float th, int32_t* out /* ax, ay, lo, hi */) {
+    float s, c;
+    sincos_det(th, &s, &c);
+    OutlineBits o;
+    const bool ok = outline_bits(1.0f / res, x, y, s, c, &o);
+    out[0] = o.ax; out[1] = o.ay; out[2] = (int32_t)o.lo; out[3] = (int32_t)o.hi;
+    return ok ? 1 : 0;
+}
+int emul_outline_span(float res) { return outline_span(1.0f / res); }
+int emul_outline_cells(float res, float x, float y, float th, long long* out /* [kMaxOutlineCells] */) {
+    float s, c;
+    sincos_det(th, &s, &c);
+    return outline_cells(1.0f / res, x, y, s, c, out);
+}
+static OutlineBits ob_of(const int32_t* p) { return OutlineBits{p[0], p[1], (uint32_t)p[2], (uint32_t)p[3]}; }
+int emul_outline_meet(const int32_t* p, const int32_t* q) { return outline_bits_meet(ob_of(p), ob_of(q)) ? 1 : 0; }
+
+// n rays (ox, oy, dx, dy) against ONE outline each (ob[4 * i ..]): the closed form of the kernel (window side kw = 4 | 8) and
+// grid_march's walk through a window of marked cells around the origin (what rounds 3-4 ran on the device)
+void emul_ray_outline(int n, int kw, float res, const float* ox, const float* oy, const float* dx, const float* dy,
+                      const int32_t* ob, float tmax, float* out_closed, float* out_walk) {
+    const float inv = 1.0f / res;
+    const int reach = raster_window_reach(inv);
+    const int side = 2 * reach + 1, wpr = (side + 31) >> 5;
+    std::vector<uint32_t> bits((size_t)side * wpr);
+    const GridGeom gr{0.0f, 0.0f, res, inv, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        const OutlineBits o = ob_of(ob + 4 * i);
+        const float fx = ox[i] * inv, fy = oy[i] * inv;
+        const int ix0 = (int)floorf(fx), iy0 = (int)floorf(fy);
+        const float inv_dx = dx[i] != 0.0f ? rcp_exact(dx[i]) : kInf, inv_dy = dy[i] != 0.0f ? rcp_exact(dy[i]) : kInf;
+        const float t = kw == 4 ? ray_outline_entry<4>(fx, fy, ix0, iy0, dx[i], dy[i], inv_dx, inv_dy, o)
+                                : ray_outline_entry<8>(fx, fy, ix0, iy0, dx[i], dy[i], inv_dx, inv_dy, o);
+        out_closed[i] = t < tmax * inv ? t * res : tmax;
+        std::fill(bits.begin(), bits.end(), 0u);
+        const RasterWindow win{bits.data(), ix0 - reach, iy0 - reach, side, wpr};
+        for (int jy = 0; jy < kOutlineWin; ++jy)
+            for (int jx = 0; jx < kOutlineWin; ++jx) {
+                const uint32_t half = jy < 4 ? o.lo : o.hi;
+                if (!((half >> (((jy & 3) << 3) + jx)) & 1u)) continue;
+                const int wx = o.ax + jx - win.ix0, wy = o.ay + jy - win.iy0;
+                if (wx >= 0 && wy >= 0 && wx < side && wy < side) bits[(size_t)wy * wpr + (wx >> 5)] |= 1u << (wx & 31);
+            }
+        out_walk[i] = grid_march(win, gr, ox[i], oy[i], dx[i], dy[i], tmax);
+    }
+}
+
 // --- the LDS image / operand address formulas of the policy's backward kernel (mrca_policy_layout.h), for
 //     tests/test_policy_bwd_layout.py
 int pl_rowmap(int reg, int hl) { return mrca_pbwd::rowmap(reg, hl); }
