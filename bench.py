@@ -13,9 +13,12 @@ worlds are sharded across ranks with no data-path collective (weak scaling: 4096
 --mode rollout  env + policy inference per tick                                  
 --mode train    rollout + GAE + PPO update with RCCL gradient all-reduce         
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (raycast_kernel), timed live
-with HIP events on the stream it is launched on; `cpu_baseline` times the NumPy oracle (a port,
-not the reference binary, which cannot run here -- BASELINE.md 3) on one host core.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (raycast_kernel): its launches' own begin / end stamps
+(hipExtLaunchKernel) in an eager pass over all worlds right after the timed region; `cpu_baseline` times the plain-C / OpenMP
+port of the oracle on all host threads over the same workload (a port, not the reference binary, which cannot run here --
+BASELINE.md 3) and reports the NumPy oracle's one-core figure beside it.  The line also carries side figures of the other
+configurations the documents quote (Stage-2 map, fidelity mode, reference-shaped observations, rollout), each measured
+after the timed region.
 """
 import argparse
 import json
@@ -140,6 +143,134 @@ def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0, fidelit
     return out
 
 
+class TickSchedule:
+    """How env mode runs ticks [first, first + count) of every world, with tick k taking its actions from pool[k % len(pool)].
+
+    graph=True (the default of bench.py): the ticks are replayed as hipGraphs, cut so that a graph never wraps round the action
+    pool (16 ticks per graph + one remainder graph): EXACTLY the ticks asked for run, with the eager run's action sequence.
+    graph=False: every kernel is launched from the host.
+
+    chains = P > 1: the worlds are dealt to P contiguous ranges, each a chain of its own -- move launch, ray cast, move launch,
+    ... on its own stream (its own branch of the graph) -- held half a tick apart by one event per tick: range c's move launch
+    waits for range c - 1's move launch of the same tick, so it runs NEXT TO that range's ray cast.  Worlds never interact
+    (mrca_step_worlds), so the result is the one-chain result bit for bit (tests/test_gpu_parity.py); what changes is that
+    the latency-bound move launch (10 us at 4 % of the chip's issue slots) no longer has the chip to itself."""
+
+    def __init__(self, env, pool, chains=1, graph=True):
+        self.env, self.pool, self.graph = env, pool, graph
+        self.chains = max(1, min(int(chains), env.W))
+        W, P = env.W, self.chains
+        self.ranges = [(c * W // P, (c + 1) * W // P - c * W // P) for c in range(P)]
+        self.side = torch.cuda.Stream(device=env.device)
+        self.extra_streams = [torch.cuda.Stream(device=env.device) for _ in range(P - 1)]
+        self.graphs = {}
+        self.sync_every_tick = os.environ.get("MRCA_CHAIN_SYNC", "first") == "every"
+
+    def chunks(self, first, count):
+        """(start, length) pieces of ticks [first, first + count) that never wrap round the action pool."""
+        L = len(self.pool)
+        k = first
+        while k < first + count:
+            m = min(L - k % L, first + count - k)
+            yield k, m
+            k += m
+
+    def issue(self, start, count):
+        """the launches of ticks [start, start + count) on the current stream (and, with chains, on the extra streams forked
+        from it and joined back into it)"""
+        env, pool, L = self.env, self.pool, len(self.pool)
+        if self.chains == 1:
+            for j in range(count):
+                env.step(pool[(start + j) % L])
+            return
+        cur = torch.cuda.current_stream(env.device)
+        streams = [cur] + self.extra_streams
+        for s in streams[1:]:
+            s.wait_stream(cur)
+        for j in range(count):
+            a = pool[(start + j) % L]
+            moved = None
+            for s, r in zip(streams, self.ranges):
+                with torch.cuda.stream(s):
+                    if moved is not None and (j == 0 or self.sync_every_tick):
+                        s.wait_event(moved)         # half a tick behind the previous range
+                    env.move(a, r)
+                    moved = torch.cuda.Event()
+                    moved.record(s)
+                    env.observe(r)
+        for s in streams[1:]:
+            cur.wait_stream(s)
+
+    def graph_of(self, start, count):
+        key = (start % len(self.pool), count)
+        if key not in self.graphs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.side):
+                self.issue(start, count)
+            self.graphs[key] = g
+        return self.graphs[key]
+
+    def capture(self, first, count):
+        """every capture the ticks [first, first + count) need (a capture replays nothing: the env stands still)"""
+        if self.graph:
+            for k, m in self.chunks(first, count):
+                self.graph_of(k, m)
+
+    def prime(self, first, count):
+        """a graph's FIRST launch uploads it to the device: launch every graph of [first, first + count) once -> the number of
+        (extra, really executed) ticks that took"""
+        primed = 0
+        if self.graph:
+            for key in sorted({(k % len(self.pool), m) for k, m in self.chunks(first, count)}):
+                self.graphs[key].replay()
+                primed += key[1]
+        return primed
+
+    def run(self, first, count):
+        if not self.graph:
+            self.issue(first, count)
+        else:
+            for k, m in self.chunks(first, count):
+                self.graph_of(k, m).replay()
+        if hasattr(self.env, "invalidate_views"):
+            self.env.invalidate_views()
+
+
+def action_pool(N, dev, seed, depth=16):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    return [torch.stack([torch.rand(N, generator=gen, device=dev),
+                         torch.rand(N, generator=gen, device=dev) * 2 - 1], 1).contiguous() for _ in range(depth)]
+
+
+def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note=""):
+    """agent-steps/s of another configuration, measured outside the timed region with the same schedule as `value` (ticks
+    replayed as hipGraphs off a 16-deep action pool): a new env, reset, the graphs captured and launched once, 32 warm-up
+    ticks, then `ticks` timed ticks between two device synchronisations."""
+    from mrca.vec_env import VecStageWorld
+    env = VecStageWorld(sc, lazy_obs=lazy_obs)
+    try:
+        pool = action_pool(sc.num_robots, env.device, seed)
+        sched = TickSchedule(env, pool, chains=chains)
+        env.reset()
+        for k in range(3):
+            env.step(pool[k])
+        torch.cuda.synchronize()
+        sched.capture(0, 32)
+        sched.capture(32, ticks)
+        sched.prime(32, ticks)
+        sched.run(0, 32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sched.run(32, ticks)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        env.check()
+        return {"value": sc.num_robots * ticks / dt, "unit": "agent-steps/s", "ms_per_step": dt / ticks * 1e3,
+                "robots": sc.num_robots, "ticks": ticks, "chains": sched.chains, "note": note}
+    finally:
+        env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +305,11 @@ def main():
                     help="Stage's own resolutions (worlds/stage1.world:3): 0.2 m map cells, robots collide when their outlines "
                          "share a 0.2 m raster cell and see each other's bodies through that raster (a side line: `value` of "
                          "the default run is the exact-rectangle mode on 0.05 m cells)")
+    ap.add_argument("--chains", type=int, default=None,
+                    help="env mode: the worlds as this many world ranges, each a chain of (move launch, ray cast) on its own stream "
+                         "/ graph branch, half a tick apart, so that one range's move launch runs next to another's ray cast "
+                         "(TickSchedule; mrca_move_worlds / mrca_observe_worlds).  1 = every tick as two launches over all worlds "
+                         "(rounds 1-4).  Default: 2")
     ap.add_argument("--graph", action="store_true",
                     help="(the default since round 4; kept for old command lines) env mode: the timed ticks are replayed as "
                          "hipGraphs -- 16 ticks per graph, one per entry of the action pool -- instead of being launched "
@@ -251,9 +387,7 @@ def main():
     env = VecStageWorld(sc)
     N = sc.num_robots
     dev = env.device
-    gen = torch.Generator(device=dev).manual_seed(1 + rank)
-    pool = [torch.stack([torch.rand(N, generator=gen, device=dev),
-                         torch.rand(N, generator=gen, device=dev) * 2 - 1], 1).contiguous() for _ in range(16)]
+    pool = action_pool(N, dev, 1 + rank)
 
     def barrier():
         if dist is not None:
@@ -261,38 +395,14 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
-    env_graphs = None
-    if args.mode == "env" and not args.no_graph:
-        # The two-launch tick replayed as hipGraphs: ticks k .. k + m - 1 (one per entry of the 16-deep action pool) are
-        # captured once per distinct chunk length and replayed; warm-up and the timed region are cut into chunks of 16
-        # ticks + one remainder, so EXACTLY --steps ticks are timed and the action sequence is the eager run's.
-        side = torch.cuda.Stream(device=dev)
-        env_graphs = {}
-
-        def chunks(first, count):
-            """(start, length) pieces of ticks [first, first + count) that never wrap round the action pool."""
-            k = first
-            while k < first + count:
-                m = min(len(pool) - k % len(pool), first + count - k)
-                yield k, m
-                k += m
-
-        def graph_of(start, count):
-            key = (start % len(pool), count)
-            if key not in env_graphs:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    for j in range(count):
-                        env.step(pool[(start + j) % len(pool)])
-                env_graphs[key] = g
-            return env_graphs[key]
-
-        def run_ticks(first, count):
-            for k, m in chunks(first, count):
-                graph_of(k, m).replay()
+    sched = None
+    if args.chains is None:
+        args.chains = 2
+    if args.mode == "env":
+        # The tick replayed as hipGraphs (default) or launched from the host (--no-graph), as one chain over all worlds or as
+        # --chains world ranges half a tick apart: TickSchedule above.
+        sched = TickSchedule(env, pool, chains=args.chains, graph=not args.no_graph)
         step_fn = None
-    elif args.mode == "env":
-        step_fn = lambda k: env.step(pool[k % len(pool)])  # noqa: E731
     else:
         from mrca import gemm_tuning
         from mrca.trainer import make_bench_step
@@ -313,27 +423,23 @@ def main():
         args.warmup = max(hz, (args.warmup + hz - 1) // hz * hz)
         args.steps = max(hz, (args.steps + hz - 1) // hz * hz)
     env.reset()
-    if env_graphs is not None:
+    if sched is not None:
         for k in range(3):                      # lazy initialisation outside any capture
             env.step(pool[k])
         torch.cuda.synchronize()
-        for k, m in list(chunks(0, args.warmup)) + list(chunks(args.warmup, args.steps)):
-            graph_of(k, m)                      # every capture happens here (a capture replays nothing: the env stands still)
+        sched.capture(0, args.warmup)           # every capture happens here (a capture replays nothing: the env stands still)
+        sched.capture(args.warmup, args.steps)
         torch.cuda.synchronize()
         # a graph's FIRST launch uploads it to the device (tens of us): every graph the timed region replays is launched once
         # here, untimed and before the warm-up -- in a 20-step region (0.65 ms) the uploads are several per cent of the figure,
         # in a 1000-step one nothing.  These are extra untimed ticks (reported as `graph_prime_ticks`); the timed region stays
         # EXACTLY --steps ticks.
-        primed = 0
-        for key in sorted({(k % len(pool), m) for k, m in chunks(args.warmup, args.steps)}):
-            env_graphs[key].replay()
-            primed += key[1]
-        extra["graph_prime_ticks"] = primed
+        extra["graph_prime_ticks"] = sched.prime(args.warmup, args.steps)
         torch.cuda.synchronize()
-        run_ticks(0, args.warmup)
+        sched.run(0, args.warmup)
         barrier()
         t0 = time.perf_counter()
-        run_ticks(args.warmup, args.steps)
+        sched.run(args.warmup, args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
         mv_ms, ray_ms, launches = 0.0, 0.0, 0
@@ -403,6 +509,49 @@ def main():
                                                 "GEMMs, ticks replayed as hipGraphs of eight), 100 ticks after 10 warm-up ticks; not "
                                                 "part of `value`"}
 
+    # Side figures of the OTHER configurations DESIGN.md / README quote (each a fresh env, a few hundred ticks after the timed
+    # region, same schedule as `value`; a failure is reported in its place and never costs the run its line):
+    #   stage2_side_figure                 BASELINE configs[2] / the per-GPU share of configs[3]: 187 Stage-2 worlds x 44 robots
+    #   fidelity_side_figure               this workload at Stage's own resolutions with raster collisions + raster lidar returns
+    #   reference_shaped_obs_side_figure   this workload with lazy_obs = 0: every tick also forms MRCA_F_SCAN and the
+    #                                      deque-ordered, normalised MRCA_F_OBS (SURVEY 8d's "obs normalise + frame-stack update")
+    if args.mode == "env" and not args.no_extra and not args.fidelity:
+        def side(name, make, note, **kw):
+            try:
+                extra[name] = env_side_figure(make(), ticks=kw.pop("ticks", 300), chains=args.chains, note=note, **kw)
+            except Exception as exc:
+                extra[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if args.scenario == "stage1":
+            side("stage2_side_figure", lambda: S.stage2(num_worlds=187, seed=1000 + rank),
+                 "BASELINE configs[2] (and configs[3]'s share of one GPU): 187 Stage-2 worlds x 44 robots = 8228 robots on the "
+                 "800 x 800 obstacle map, group-synchronous episodes; not part of `value`", ticks=200)
+        if world_size == 1:
+            side("fidelity_side_figure",
+                 lambda: (S.stage1(num_worlds=args.worlds, robots_per_world=args.robots_per_world, seed=1000 + rank,
+                                   stage_resolution=True) if args.scenario == "stage1" else
+                          S.stage2(num_worlds=args.worlds, seed=1000 + rank, stage_resolution=True)),
+                 "the same worlds in FIDELITY mode: Stage's own resolution (0.2 m, worlds/stage1.world:3), robots collide when "
+                 "their outlines share a raster cell and see each other through that raster; not part of `value`")
+            side("reference_shaped_obs_side_figure", lambda: sc,
+                 "the same workload with lazy_obs = 0: every tick also materialises MRCA_F_SCAN and the normalised, deque-ordered "
+                 "MRCA_F_OBS [N,3,512] a reference-shaped caller reads (one more kernel per range and tick); not part of `value`",
+                 lazy_obs=False)
+        if dist is not None and "stage2_side_figure" in extra:
+            # configs[3] = 65 536 robots over 8 GPUs: every rank ran its 8228 Stage-2 robots; the job's figure is all of them
+            # over the slowest rank's time.  (Every rank takes part in the reduction whatever happened to its own figure: a
+            # rank without one contributes +inf and the job's figure is reported as missing.)
+            f = extra["stage2_side_figure"]
+            tt = torch.tensor([f.get("ms_per_step", float("inf"))], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if "value" in f and float(tt.item()) < float("inf"):
+                f["per_rank_value"] = f["value"]
+                f["value"] = f["robots"] * world_size / (float(tt.item()) * 1e-3)
+                f["robots_all_ranks"] = f["robots"] * world_size
+                f["note"] += f"; value = {world_size} ranks x {f['robots']} robots over the slowest rank's time"
+            elif "value" in f:
+                f["error"] = "another rank has no Stage-2 figure: the job's figure is missing (this rank's own: per_rank_value)"
+                f["per_rank_value"] = f.pop("value")
+
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     per_rank = None
     ranks_seen, devices = None, None
@@ -464,6 +613,12 @@ def main():
                        "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
                        if args.mode != "env" else None,
                        "tick_as_hipgraph": not args.no_graph,
+                       "chains": (sched.chains if sched is not None else None),
+                       "schedule": (None if sched is None else
+                                    "one chain: move launch, ray cast over all worlds" if sched.chains == 1 else
+                                    f"{sched.chains} world ranges half a tick apart (a range's move launch runs next to the "
+                                    "previous range's ray cast: mrca_move_worlds / mrca_observe_worlds on two streams / graph "
+                                    "branches)"),
                        "ppo_update_dtype": args.update_dtype if args.mode == "train" else None,
                        "ppo_update_path": (args.update_path if args.update_dtype == "f32" else "stock")
                        if args.mode == "train" else None},
@@ -493,6 +648,10 @@ def main():
                                                  "4 cycles / (1024 SIMDs x launch time x 2.4 GHz)"}
                                         if (_SQ_VALU_PER_WAVE and launches and args.scenario == "stage1" and not args.fidelity)
                                         else None),
+                         # the two launches of a tick over ALL worlds, by their own stamps: the tick a single chain cannot beat,
+                         # free of the host and of the timed region's length (a 20-step region is 0.5 ms of wall clock)
+                         "kernel_sum_us": (ray_avg_s + mv_avg_s) * 1e6 if launches else None,
+                         "value_at_kernel_sum": N * world_size / (ray_avg_s + mv_avg_s) if launches else None,
                          "launches_timed": launches, "kernel_timing": kernel_timing_note,
                          "note": "HBM is the nominal roof (SURVEY 8d); the launch is bound by VALU issue at eight waves per SIMD: "
                                  "546 VALU instructions per wave (608 in round 3), two residency rounds of 2048 workgroups whose "

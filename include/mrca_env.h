@@ -170,6 +170,23 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
  * (3.85x measured on one rank's share, profiles/r03/r03_f_bigworld_shards8.jsonl). */
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream);
 
+/* The same tick for the worlds [first_world, first_world + num_worlds) ONLY: their robots advance and are observed, every
+ * other world is left exactly as it is.  Worlds never interact (one `stageros` process per world in the reference:
+ * stage_world1.py:17-84), so a caller may step disjoint world ranges on DIFFERENT streams -- the latency-bound move launch
+ * of one range then runs under the issue-bound ray cast of another (bench.py --chains) -- or give the policy of
+ * one range the time the simulator spends on the other.  actions_dev is still f32[N,2] indexed by robot; only the rows of the
+ * range are read.  Calls on overlapping ranges must be ordered by the caller (same stream, or events).
+ * robots_per_world > 64: only the full range (MRCA_ERR_UNSUPPORTED otherwise: one world's move phase is one launch chain). */
+int mrca_step_worlds(mrca_env* env, const float* actions_dev, int32_t first_world, int32_t num_worlds, void* stream);
+/* ... and its two launches one by one: mrca_move_worlds = control_vel + the Stage tick + get_reward_and_terminate + episode
+ * bookkeeping of the range (stage_world1.py:225-234,180-211; stageros.cpp:445-449), mrca_observe_worlds = the ray cast at the
+ * poses it left + get_local_goal (stageros.cpp:479-516, stage_world1.py:126-160) (+ the two views with lazy_obs = 0).
+ * mrca_step_worlds(r) == mrca_move_worlds(r) then mrca_observe_worlds(r) on one stream.  What the split is for: a caller with
+ * two streams and an event can hold two world ranges half a tick apart -- range B's move launch goes out when range A's has
+ * finished, i.e. next to A's ray cast, tick after tick (bench.py --chains 2: the schedule, DESIGN.md 5.9: what it buys). */
+int mrca_move_worlds(mrca_env* env, const float* actions_dev, int32_t first_world, int32_t num_worlds, void* stream);
+int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, void* stream);
+
 /* The reference-shaped views of the ring, for all robots (asynchronous on `stream`; needed only with lazy_obs = 1):
  * what & MRCA_VIEW_SCAN: MRCA_F_SCAN := every robot's newest scan; what & MRCA_VIEW_OBS: MRCA_F_OBS := x / 6 - 0.5
  * (stage_world1.py:140) of the ring in deque order. */

@@ -414,6 +414,8 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.status = reinterpret_cast<uint32_t*>(a + L.off_status);
     v.ray_first = 0;
     v.ray_count = (int32_t)N;
+    v.world_first = 0;
+    v.world_count = cfg->num_worlds;
     v.g.x0 = cfg->map_x0;
     v.g.y0 = cfg->map_y0;
     v.g.cell = cfg->map_cell;
@@ -529,25 +531,32 @@ int mrca_newest_obs(mrca_env* env, float* out_dev, void* stream) {
     return MRCA_OK;
 }
 
-static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int32_t count, void* stream) {
+enum { kPhaseMove = 1, kPhaseObserve = 2 };
+static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int32_t count, void* stream,
+                     int32_t world_first = 0, int32_t world_count = -1, int phases = kPhaseMove | kPhaseObserve) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
-    if (!actions_dev) return fail(MRCA_ERR_INVALID, "actions_dev is NULL");
+    if ((phases & kPhaseMove) && !actions_dev) return fail(MRCA_ERR_INVALID, "actions_dev is NULL");
     if (first < 0 || count < 0 || first + count > env->view.N)
         return fail(MRCA_ERR_INVALID, "ray-cast slice [%d, %d) outside [0, %d)", first, first + count, env->view.N);
+    if (world_count < 0) world_count = env->view.W;
     DeviceGuard guard(env->cfg.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool rec = env->timing > 0 && (env->step_count++ % env->timing) == 0 &&
+    const bool rec = phases == (kPhaseMove | kPhaseObserve) && env->timing > 0 && (env->step_count++ % env->timing) == 0 &&
                      env->ev_used + 4 <= (int)env->ev.size();
     mrca::EnvView v = env->view;
     v.ray_first = first;      // the robots whose lidar outputs (scan, frame stack, local goal) this call produces
     v.ray_count = count;
+    v.world_first = world_first;   // the worlds the move launch advances (mrca_step_worlds; otherwise all of them)
+    v.world_count = world_count;
     env->last_ray_count = count;
     // timing: the launches' own begin / end stamps (hipExtLaunchKernel), not event records around them
     hipEvent_t* ev = rec ? &env->ev[env->ev_used] : nullptr;
-    mrca::launch_move(v, actions_dev, s, rec ? ev[0] : nullptr, rec ? ev[1] : nullptr);
-    mrca::launch_lidar_grid(v, /*counted=*/1, s);
-    mrca::launch_raycast(v, /*only_fresh=*/0, s, rec ? ev[2] : nullptr, rec ? ev[3] : nullptr);
-    if (!env->cfg.lazy_obs) mrca::launch_materialize(v, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, s);
+    if (phases & kPhaseMove) mrca::launch_move(v, actions_dev, s, rec ? ev[0] : nullptr, rec ? ev[1] : nullptr);
+    if (phases & kPhaseObserve) {
+        mrca::launch_lidar_grid(v, /*counted=*/1, s);
+        mrca::launch_raycast(v, /*only_fresh=*/0, s, rec ? ev[2] : nullptr, rec ? ev[3] : nullptr);
+        if (!env->cfg.lazy_obs) mrca::launch_materialize(v, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, s);
+    }
     if (rec) env->ev_used += 4;
     HIP_TRY(hipGetLastError());
     return MRCA_OK;
@@ -559,6 +568,28 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream) {
 
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream) {
     return step_impl(env, actions_dev, first_robot, num_robots, stream);
+}
+
+static int worlds_impl(mrca_env* env, const float* actions_dev, int32_t first_world, int32_t num_worlds, void* stream, int phases) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (first_world < 0 || num_worlds < 0 || first_world + num_worlds > env->view.W)
+        return fail(MRCA_ERR_INVALID, "world range [%d, %d) outside [0, %d)", first_world, first_world + num_worlds, env->view.W);
+    if (env->view.big && (first_world != 0 || num_worlds != env->view.W || phases != (kPhaseMove | kPhaseObserve)))
+        return fail(MRCA_ERR_UNSUPPORTED, "a part of the worlds / of the tick with robots_per_world > 64");
+    const int32_t R = env->view.R;
+    return step_impl(env, actions_dev, first_world * R, num_worlds * R, stream, first_world, num_worlds, phases);
+}
+
+int mrca_step_worlds(mrca_env* env, const float* actions_dev, int32_t first_world, int32_t num_worlds, void* stream) {
+    return worlds_impl(env, actions_dev, first_world, num_worlds, stream, kPhaseMove | kPhaseObserve);
+}
+
+int mrca_move_worlds(mrca_env* env, const float* actions_dev, int32_t first_world, int32_t num_worlds, void* stream) {
+    return worlds_impl(env, actions_dev, first_world, num_worlds, stream, kPhaseMove);
+}
+
+int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, void* stream) {
+    return worlds_impl(env, nullptr, first_world, num_worlds, stream, kPhaseObserve);
 }
 
 int mrca_check(mrca_env* env, void* stream) {

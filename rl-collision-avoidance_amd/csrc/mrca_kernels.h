@@ -56,6 +56,7 @@ struct EnvView {
     int32_t* bw_lblock;     // [(bw_lmask+1)/1024 + 1] totals / offsets of the scan's 1024-bucket blocks
     int32_t bw_lmask;
     int32_t ray_first, ray_count;   // the ray cast covers robots [ray_first, ray_first + ray_count) (mrca_step_slice)
+    int32_t world_first, world_count;   // the move launch covers worlds [world_first, world_first + world_count) (mrca_step_worlds)
     // scenario tables, per local index
     const int32_t* reset_mode;
     const int32_t* goal_mode;

@@ -254,12 +254,12 @@ __device__ unsigned long long g_ray_stamps[2][kRayStamps][kRayStampBlocks];
 // (csrc/build.sh: -amdgpu-kernarg-preload-count), so the loads the tick's dependent chain starts with go out at once instead
 // of one memory round trip later, behind the s_load of a 600-byte EnvView.  A/B on one box, three alternating runs each:
 // move 11.12 -> 10.85 us, ray cast 21.35 -> 20.51 us, profiles/r04_y_ab_kernarg_preload.txt.)
-__global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, const float* pose_p, const float4* head_p,
-                                                                  const float* __restrict__ actions, const uint8_t* live_p,
-                                                                  EnvView e) {
+__global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int world_first, const float* pose_p,
+                                                                  const float4* head_p, const float* __restrict__ actions,
+                                                                  const uint8_t* live_p, EnvView e) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
     MRCA_STAMP(0);
-    const int world = blockIdx.x;
+    const int world = world_first + blockIdx.x;     // (mrca_step_worlds: a launch may cover a range of worlds)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
@@ -1470,12 +1470,13 @@ size_t move_lds_bytes(const EnvView& e) {
 
 void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     if (!e.big) {
+        if (e.world_count <= 0) return;
         if (start || stop)
-            hipExtLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), (uint32_t)move_lds_bytes(e), s, start, stop, 0,
-                                  e.R, e.pose, e.head, actions, e.live, e);
+            hipExtLaunchKernelGGL(move_kernel, dim3(e.world_count), dim3(kWave * kMoveWaves), (uint32_t)move_lds_bytes(e), s, start,
+                                  stop, 0, e.R, e.world_first, e.pose, e.head, actions, e.live, e);
         else
-            hipLaunchKernelGGL(move_kernel, dim3(e.W), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e.R, e.pose, e.head, actions,
-                               e.live, e);
+            hipLaunchKernelGGL(move_kernel, dim3(e.world_count), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e.R, e.world_first,
+                               e.pose, e.head, actions, e.live, e);
         return;
     }
     // (the collision hash's heads and the lidar hash's counts are left clean by the tick before: bw_finish_kernel /

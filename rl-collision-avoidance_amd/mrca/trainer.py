@@ -148,8 +148,8 @@ class Stage1Trainer:
             buf.begin_horizon(env.obs)      # one-frame store: the older frames of the stack the first tick sees
         if hp.graph_tick:
             self._graph.replay()
-            if hasattr(env, "_obs_current"):
-                env._obs_current = False        # the replayed tick advanced the ring behind the binding's back
+            if hasattr(env, "invalidate_views"):
+                env.invalidate_views()          # the replayed tick advanced the ring behind the binding's back
         else:
             obs, head = ppo.policy_input(env, hp.rollout_fused)
             v, a, logprob, scaled = ppo.generate_action(self.policy, obs, env.local_goal, env.speed,

@@ -36,7 +36,10 @@ def sparse_beam_index(raw_beams, beam_num):
 
 
 class VecStageWorld:
-    def __init__(self, scenario: Scenario, device=None, lib_path=None):
+    def __init__(self, scenario: Scenario, device=None, lib_path=None, lazy_obs=True):
+        """``lazy_obs=False``: the library forms the two reference-shaped views (MRCA_F_SCAN, MRCA_F_OBS) inside every
+        ``step`` / ``reset`` -- what a plain C caller written against the reference's getters expects (mrca_config.lazy_obs
+        = 0: one more kernel per call); the default leaves them to the ``scan`` / ``obs`` properties."""
         if not torch.cuda.is_available():
             raise RuntimeError("VecStageWorld needs an MI355X (torch.cuda is unavailable); there is no CPU path")
         self.lib = _lib.load(lib_path)      # lib_path: another build of the same library (the profiling build)
@@ -68,7 +71,7 @@ class VecStageWorld:
             goal_table=goal_table.ctypes.data, group_id=group_id.ctypes.data,
             collision_raster=float(getattr(sc, "collision_raster", 0.0)),
             hold_velocity=int(bool(getattr(sc, "hold_velocity", False))),
-            lazy_obs=1)      # MRCA_F_OBS is materialised by the ``obs`` property when somebody asks for it
+            lazy_obs=1 if lazy_obs else 0)   # 1: MRCA_F_OBS is materialised by the ``obs`` property when somebody asks for it
         nbytes = C.c_size_t()
         _lib.check(self.lib.mrca_arena_bytes(C.byref(cfg), C.byref(nbytes)), "mrca_arena_bytes")
         # the arena is a torch allocation so that every field is a plain torch view (zero copy)
@@ -92,6 +95,7 @@ class VecStageWorld:
             else:
                 t = flat.view(self.N, shape)
             setattr(self, "_" + name if name in ("obs", "scan") else name, t)
+        self._eager_views = 0 if lazy_obs else (_lib.VIEW_SCAN | _lib.VIEW_OBS)   # views the library itself keeps current
         self._views_current = 0          # bits of _lib.VIEW_*: which of MRCA_F_SCAN / MRCA_F_OBS follow the ring right now
 
     # ------------------------------------------------------------------ the scans and the observation stack
@@ -123,14 +127,20 @@ class VecStageWorld:
         ar = torch.arange(self.N, device=self.device)
         return torch.signbit(self.scan_ring[ar, self.ring_head.long()])
 
+    def invalidate_views(self):
+        """Tell the binding that the env moved on without it: ticks replayed as a hipGraph (or stepped by another binding of
+        the same handle) advance the scan ring behind its back, so ``scan`` / ``obs`` must be formed again at their next
+        read.  (With ``lazy_obs=False`` the replayed ticks re-formed them themselves.)"""
+        self._views_current = self._eager_views
+
     @property
     def _obs_current(self):
         return bool(self._views_current)
 
     @_obs_current.setter
-    def _obs_current(self, value):      # (a tick replayed as a hipGraph advances the ring behind the binding's back)
+    def _obs_current(self, value):      # (older spelling of invalidate_views(), kept for callers written against it)
         if not value:
-            self._views_current = 0
+            self.invalidate_views()
 
     def policy_obs(self):
         """-> (ring, heads) for consumers that understand the ring: (scan_ring f32[N,F,B] of RAW ranges, RingHead)."""
@@ -189,20 +199,45 @@ class VecStageWorld:
         _lib.check(self.lib.mrca_reset(self._h, self._ptr(mask, torch.uint8, self.N),
                                        self._ptr(poses, torch.float32, self.N * 3),
                                        self._ptr(goals, torch.float32, self.N * 2), self._stream()), "mrca_reset")
-        self._views_current = 0
+        self._views_current = self._eager_views
         return self
 
-    def step(self, actions, ray_slice=None):
+    def step(self, actions, ray_slice=None, worlds=None):
         """control_vel + one Stage tick + get_reward_and_terminate + next observation for every
         robot (ppo_stage1.py:75-91).  ``actions`` f32[N,2] = clipped (v, omega).
         ``ray_slice=(first, count)``: one world sharded over ranks (mrca_step_slice) -- all robots advance, the
-        lidar is cast for robots [first, first + count) only."""
+        lidar is cast for robots [first, first + count) only.
+        ``worlds=(first, count)``: only these worlds tick (mrca_step_worlds), on the current stream; disjoint ranges may be
+        stepped on different streams at the same time (worlds never interact)."""
         a = self._ptr(actions, torch.float32, self.N * 2)
-        if ray_slice is None:
+        if worlds is not None:
+            if ray_slice is not None:
+                raise ValueError("step: ray_slice and worlds exclude each other")
+            _lib.check(self.lib.mrca_step_worlds(self._h, a, int(worlds[0]), int(worlds[1]), self._stream()),
+                       "mrca_step_worlds")
+            self._views_current = 0       # (lazy_obs=False re-formed the views of this range only)
+        elif ray_slice is None:
             _lib.check(self.lib.mrca_step(self._h, a, self._stream()), "mrca_step")
+            self._views_current = self._eager_views
         else:
             _lib.check(self.lib.mrca_step_slice(self._h, a, int(ray_slice[0]), int(ray_slice[1]), self._stream()),
                        "mrca_step_slice")
+            self._views_current = 0
+        return self
+
+    def move(self, actions, worlds):
+        """First launch of ``step(actions, worlds=...)``: control_vel, the Stage tick, reward / terminal and episode
+        bookkeeping of the worlds (first, count) (mrca_move_worlds).  ``observe`` must follow before the next ``move``."""
+        _lib.check(self.lib.mrca_move_worlds(self._h, self._ptr(actions, torch.float32, self.N * 2), int(worlds[0]),
+                                             int(worlds[1]), self._stream()), "mrca_move_worlds")
+        self._views_current = 0
+        return self
+
+    def observe(self, worlds):
+        """Second launch: the lidar scans and local goals of the worlds (first, count) at their current poses
+        (mrca_observe_worlds)."""
+        _lib.check(self.lib.mrca_observe_worlds(self._h, int(worlds[0]), int(worlds[1]), self._stream()),
+                   "mrca_observe_worlds")
         self._views_current = 0
         return self
 
