@@ -146,8 +146,8 @@ def cpu_baseline(sc_name, worlds, robots_per_world, seconds_target=12.0, fidelit
 class TickSchedule:
     """How env mode runs ticks [first, first + count) of every world, with tick k taking its actions from pool[k % len(pool)].
 
-    graph=True (the default of bench.py): the ticks are replayed as hipGraphs, cut so that a graph never wraps round the action
-    pool (16 ticks per graph + one remainder graph): EXACTLY the ticks asked for run, with the eager run's action sequence.
+    graph=True (the default of bench.py): the ticks are replayed as hipGraphs of up to 64 ticks (+ remainder graphs): EXACTLY
+    the ticks asked for run, with the eager run's action sequence.
     graph=False: every kernel is launched from the host.
 
     chains = P > 1: the worlds are dealt to P contiguous ranges, each a chain of its own -- move launch, ray cast, move launch,
@@ -156,8 +156,11 @@ class TickSchedule:
     (mrca_step_worlds), so the result is the one-chain result bit for bit (tests/test_gpu_parity.py); what changes is that
     the latency-bound move launch (10 us at 4 % of the chip's issue slots) no longer has the chip to itself."""
 
-    def __init__(self, env, pool, chains=1, graph=True):
-        self.env, self.pool, self.graph = env, pool, graph
+    def __init__(self, env, pool, chains=1, graph=True, native=False):
+        # native=True: one mrca_step_many call per run() -- the library enqueues every launch of the ticks itself (two plain
+        # streams for two chains, one event to set them half a tick apart): no graph to instantiate, upload or launch, and no
+        # Python between the launches
+        self.env, self.pool, self.graph, self.native = env, pool, graph and not native, native
         self.chains = max(1, min(int(chains), env.W))
         W, P = env.W, self.chains
         self.ranges = [(c * W // P, (c + 1) * W // P - c * W // P) for c in range(P)]
@@ -165,13 +168,18 @@ class TickSchedule:
         self.extra_streams = [torch.cuda.Stream(device=env.device) for _ in range(P - 1)]
         self.graphs = {}
         self.sync_every_tick = os.environ.get("MRCA_CHAIN_SYNC", "first") == "every"
+        # ticks per hipGraph: a graph forks into the chains at its head and joins them at its end, and the chains are set half
+        # a tick apart once per graph -- the longer the graph, the less of a tick that is
+        self.ticks_per_graph = int(os.environ.get("MRCA_TICKS_PER_GRAPH", "64"))
 
     def chunks(self, first, count):
-        """(start, length) pieces of ticks [first, first + count) that never wrap round the action pool."""
-        L = len(self.pool)
+        """(start, length) pieces of ticks [first, first + count): at most `ticks_per_graph` ticks each (a graph may run round the
+        action pool several times: tick k takes pool[k % len(pool)] wherever it sits), cut at multiples of it so that the same
+        few graphs serve a long run."""
+        G = self.ticks_per_graph
         k = first
         while k < first + count:
-            m = min(L - k % L, first + count - k)
+            m = min(G - k % G, first + count - k)
             yield k, m
             k += m
 
@@ -202,7 +210,7 @@ class TickSchedule:
             cur.wait_stream(s)
 
     def graph_of(self, start, count):
-        key = (start % len(self.pool), count)
+        key = (start % len(self.pool), count)       # (a graph is its first pool entry and its length)
         if key not in self.graphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.side):
@@ -227,7 +235,9 @@ class TickSchedule:
         return primed
 
     def run(self, first, count):
-        if not self.graph:
+        if self.native:
+            self.env.step_many(self.pool, first, count, self.chains)
+        elif not self.graph:
             self.issue(first, count)
         else:
             for k, m in self.chunks(first, count):
@@ -242,7 +252,7 @@ def action_pool(N, dev, seed, depth=16):
                          torch.rand(N, generator=gen, device=dev) * 2 - 1], 1).contiguous() for _ in range(depth)]
 
 
-def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note=""):
+def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note="", schedule="native"):
     """agent-steps/s of another configuration, measured outside the timed region with the same schedule as `value` (ticks
     replayed as hipGraphs off a 16-deep action pool): a new env, reset, the graphs captured and launched once, 32 warm-up
     ticks, then `ticks` timed ticks between two device synchronisations."""
@@ -250,7 +260,7 @@ def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note=""):
     env = VecStageWorld(sc, lazy_obs=lazy_obs)
     try:
         pool = action_pool(sc.num_robots, env.device, seed)
-        sched = TickSchedule(env, pool, chains=chains)
+        sched = TickSchedule(env, pool, chains=chains, graph=schedule == "graph", native=schedule == "native")
         env.reset()
         for k in range(3):
             env.step(pool[k])
@@ -310,6 +320,10 @@ def main():
                          "/ graph branch, half a tick apart, so that one range's move launch runs next to another's ray cast "
                          "(TickSchedule; mrca_move_worlds / mrca_observe_worlds).  1 = every tick as two launches over all worlds "
                          "(rounds 1-4).  Default: 2")
+    ap.add_argument("--schedule", default=None, choices=["native", "graph", "eager"],
+                    help="env mode: how the timed ticks reach the GPU.  native (default): ONE mrca_step_many call, the library "
+                         "enqueues every launch itself; graph: replayed as hipGraphs captured from Python; eager (= --no-graph): "
+                         "launched tick by tick from Python")
     ap.add_argument("--graph", action="store_true",
                     help="(the default since round 4; kept for old command lines) env mode: the timed ticks are replayed as "
                          "hipGraphs -- 16 ticks per graph, one per entry of the action pool -- instead of being launched "
@@ -401,7 +415,9 @@ def main():
     if args.mode == "env":
         # The tick replayed as hipGraphs (default) or launched from the host (--no-graph), as one chain over all worlds or as
         # --chains world ranges half a tick apart: TickSchedule above.
-        sched = TickSchedule(env, pool, chains=args.chains, graph=not args.no_graph)
+        if args.schedule is None:
+            args.schedule = "eager" if args.no_graph else ("graph" if args.graph else "native")
+        sched = TickSchedule(env, pool, chains=args.chains, graph=args.schedule == "graph", native=args.schedule == "native")
         step_fn = None
     else:
         from mrca import gemm_tuning
@@ -518,7 +534,8 @@ def main():
     if args.mode == "env" and not args.no_extra and not args.fidelity:
         def side(name, make, note, **kw):
             try:
-                extra[name] = env_side_figure(make(), ticks=kw.pop("ticks", 300), chains=args.chains, note=note, **kw)
+                extra[name] = env_side_figure(make(), ticks=kw.pop("ticks", 300), chains=args.chains, note=note,
+                                              schedule=args.schedule, **kw)
             except Exception as exc:
                 extra[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if args.scenario == "stage1":
@@ -612,7 +629,10 @@ def main():
                        "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
                        "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
                        if args.mode != "env" else None,
-                       "tick_as_hipgraph": not args.no_graph,
+                       "tick_as_hipgraph": (sched.graph if sched is not None else not args.no_graph),
+                       "launches_from": (None if sched is None else "one mrca_step_many call per timed region (the library "
+                                         "enqueues every launch)" if sched.native else "hipGraph replays" if sched.graph else
+                                         "Python, tick by tick"),
                        "chains": (sched.chains if sched is not None else None),
                        "schedule": (None if sched is None else
                                     "one chain: move launch, ray cast over all worlds" if sched.chains == 1 else

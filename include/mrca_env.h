@@ -187,6 +187,17 @@ int mrca_step_worlds(mrca_env* env, const float* actions_dev, int32_t first_worl
 int mrca_move_worlds(mrca_env* env, const float* actions_dev, int32_t first_world, int32_t num_worlds, void* stream);
 int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, void* stream);
 
+/* num_ticks ticks of every world from ONE call, with commands that are already on the device (a scripted scenario, a replayed
+ * log, the benchmark's action pool): tick k (k = 0 .. num_ticks - 1) takes actions_dev[(first_tick + k) % num_actions], each
+ * f32[N,2] as for mrca_step.  Equal, field for field, to num_ticks calls of mrca_step.
+ * chains = P > 1: the worlds are dealt to P contiguous ranges, each ticking on a stream of its own (range 0 on `stream`, the
+ * others on streams the env creates once and keeps), the ranges set half a tick apart at the start -- range c's first move
+ * launch waits for range c - 1's -- so that one range's move launch runs next to another's ray cast; `stream` waits for all
+ * of them before the call's work counts as done, and they for everything queued on `stream` before the call.  The host only
+ * enqueues (no synchronisation); the call is capturable into a hipGraph like any other.  robots_per_world > 64: P is 1. */
+int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_actions, int32_t first_tick, int32_t num_ticks,
+                   int32_t chains, void* stream);
+
 /* The reference-shaped views of the ring, for all robots (asynchronous on `stream`; needed only with lazy_obs = 1):
  * what & MRCA_VIEW_SCAN: MRCA_F_SCAN := every robot's newest scan; what & MRCA_VIEW_OBS: MRCA_F_OBS := x / 6 - 0.5
  * (stage_world1.py:140) of the ring in deque order. */

@@ -227,6 +227,10 @@ struct mrca_env {
     std::vector<hipEvent_t> ev;  // 4 per recorded step: begin / end of the move launch, begin / end of the ray cast
     int ev_used = 0;
     int last_ray_count = 0;   // workgroups of the last ray-cast launch (profiling build: whose stamps are current)
+    // mrca_step_many with chains > 1: the streams of world ranges 1 .. P-1 and the events that order them against the caller's
+    std::vector<hipStream_t> chain_stream;
+    std::vector<hipEvent_t> chain_moved, chain_done;
+    hipEvent_t chain_fork = nullptr;
 };
 
 extern "C" {
@@ -486,6 +490,13 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
 int mrca_destroy(mrca_env* env) {
     if (!env) return MRCA_OK;
     for (hipEvent_t e : env->ev) (void)hipEventDestroy(e);
+    for (hipStream_t s : env->chain_stream) {
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+    }
+    for (hipEvent_t e : env->chain_moved) (void)hipEventDestroy(e);
+    for (hipEvent_t e : env->chain_done) (void)hipEventDestroy(e);
+    if (env->chain_fork) (void)hipEventDestroy(env->chain_fork);
     if (env->owns_arena) HIP_TRY(hipFree(env->arena));
     delete env;
     return MRCA_OK;
@@ -590,6 +601,62 @@ int mrca_move_worlds(mrca_env* env, const float* actions_dev, int32_t first_worl
 
 int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, void* stream) {
     return worlds_impl(env, nullptr, first_world, num_worlds, stream, kPhaseObserve);
+}
+
+int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_actions, int32_t first_tick, int32_t num_ticks,
+                   int32_t chains, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (!actions_dev || num_actions < 1) return fail(MRCA_ERR_INVALID, "mrca_step_many: no actions");
+    if (first_tick < 0 || num_ticks < 0) return fail(MRCA_ERR_INVALID, "mrca_step_many: first_tick %d, num_ticks %d", first_tick, num_ticks);
+    for (int i = 0; i < num_actions; ++i)
+        if (!actions_dev[i]) return fail(MRCA_ERR_INVALID, "mrca_step_many: actions_dev[%d] is NULL", i);
+    const int W = env->view.W;
+    int P = chains < 1 ? 1 : chains;
+    if (P > W) P = W;
+    if (env->view.big) P = 1;
+    auto act = [&](int k) { return actions_dev[(size_t)((int64_t)first_tick + k) % (size_t)num_actions]; };
+    if (P == 1) {
+        for (int k = 0; k < num_ticks; ++k)
+            if (int rc = step_impl(env, act(k), 0, env->view.N, stream)) return rc;
+        return MRCA_OK;
+    }
+    DeviceGuard guard(env->cfg.device);
+    hipStream_t s0 = static_cast<hipStream_t>(stream);
+    while ((int)env->chain_stream.size() < P - 1) {
+        hipStream_t s;
+        hipEvent_t a, b;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        env->chain_stream.push_back(s);
+        env->chain_moved.push_back(a);
+        env->chain_done.push_back(b);
+    }
+    if (!env->chain_fork) HIP_TRY(hipEventCreateWithFlags(&env->chain_fork, hipEventDisableTiming));
+    if (num_ticks == 0) return MRCA_OK;
+    auto stream_of = [&](int c) { return c == 0 ? s0 : env->chain_stream[c - 1]; };
+    auto first_world = [&](int c) { return (int)((int64_t)c * W / P); };
+    // fork: the other ranges' streams start behind everything queued on the caller's
+    HIP_TRY(hipEventRecord(env->chain_fork, s0));
+    for (int c = 1; c < P; ++c) HIP_TRY(hipStreamWaitEvent(stream_of(c), env->chain_fork, 0));
+    for (int k = 0; k < num_ticks; ++k) {
+        const float* a = act(k);
+        for (int c = 0; c < P; ++c) {
+            hipStream_t sc = stream_of(c);
+            const int w0 = first_world(c), wn = first_world(c + 1) - w0;
+            // half a tick behind the previous range, once: its first move launch has finished, its first ray cast is starting
+            if (k == 0 && c > 0) HIP_TRY(hipStreamWaitEvent(sc, env->chain_moved[c - 1], 0));
+            if (int rc = worlds_impl(env, a, w0, wn, sc, kPhaseMove)) return rc;
+            if (k == 0 && c + 1 < P) HIP_TRY(hipEventRecord(env->chain_moved[c], sc));
+            if (int rc = worlds_impl(env, nullptr, w0, wn, sc, kPhaseObserve)) return rc;
+        }
+    }
+    // join: the caller's stream continues when every range is through
+    for (int c = 1; c < P; ++c) {
+        HIP_TRY(hipEventRecord(env->chain_done[c - 1], stream_of(c)));
+        HIP_TRY(hipStreamWaitEvent(s0, env->chain_done[c - 1], 0));
+    }
+    return MRCA_OK;
 }
 
 int mrca_check(mrca_env* env, void* stream) {

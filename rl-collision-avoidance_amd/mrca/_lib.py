@@ -21,7 +21,7 @@ FIELDS = [  # order = enum mrca_field
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",
-           "mrca_step", "mrca_step_slice", "mrca_step_worlds", "mrca_move_worlds", "mrca_observe_worlds", "mrca_materialize", "mrca_newest_obs", "mrca_sparse_obs", "mrca_normalize_scans", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
+           "mrca_step", "mrca_step_slice", "mrca_step_worlds", "mrca_move_worlds", "mrca_observe_worlds", "mrca_step_many", "mrca_materialize", "mrca_newest_obs", "mrca_sparse_obs", "mrca_normalize_scans", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
            "mrca_event_pair_overhead",
            "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
            "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch"]
@@ -68,6 +68,7 @@ def load(path=None):
     lib.mrca_step_worlds.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.mrca_move_worlds.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.mrca_observe_worlds.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.mrca_step_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.mrca_check.argtypes = [C.c_void_p, C.c_void_p]
     lib.mrca_materialize.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.mrca_newest_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

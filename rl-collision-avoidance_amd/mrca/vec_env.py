@@ -241,6 +241,22 @@ class VecStageWorld:
         self._views_current = 0
         return self
 
+    def step_many(self, actions, first_tick, num_ticks, chains=1):
+        """``num_ticks`` ticks from ONE call: tick k takes ``actions[(first_tick + k) % len(actions)]`` (a list of f32[N,2]
+        device tensors: a scripted scenario, the benchmark's action pool); ``chains`` world ranges tick on streams of their
+        own, half a tick apart (mrca_step_many).  Equal to ``num_ticks`` calls of ``step``."""
+        key = tuple(t.data_ptr() for t in actions)
+        cache = self.__dict__.setdefault("_many_ptrs", {})
+        if key not in cache:
+            for t in actions:
+                self._ptr(t, torch.float32, self.N * 2)
+            cache.clear()
+            cache[key] = (C.c_void_p * len(actions))(*key)
+        _lib.check(self.lib.mrca_step_many(self._h, cache[key], len(actions), int(first_tick), int(num_ticks), int(chains),
+                                           self._stream()), "mrca_step_many")
+        self._views_current = self._eager_views if chains <= 1 else 0
+        return self
+
     def check(self):
         """Host round trip: raises if a kernel flagged a device-side failure since the last check (mrca_check)."""
         _lib.check(self.lib.mrca_check(self._h, self._stream()), "mrca_check")

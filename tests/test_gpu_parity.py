@@ -187,11 +187,13 @@ def test_fp64_oracle_one_tick_from_identical_state(hip, name):
     env.close()
 
 
-@pytest.mark.parametrize("chains,graph", [(1, True), (2, True), (4, True), (2, False), (3, False)])
+@pytest.mark.parametrize("chains,graph", [(1, True), (2, True), (4, True), (2, False), (3, False), (1, "native"), (2, "native"),
+                                          (3, "native")])
 @pytest.mark.parametrize("name", ["stage1", "stage2", "stage1_fidelity"])
 def test_bench_schedule_leaves_the_world_where_the_c_oracle_leaves_it(hip, name, chains, graph):
-    """The execution mode bench.py TIMES -- ticks replayed as hipGraphs off the 16-deep action pool, optionally as world
-    ranges half a tick apart on several streams (bench.TickSchedule: mrca_move_worlds / mrca_observe_worlds) -- against
+    """The execution modes bench.py TIMES -- one mrca_step_many call ("native": the library enqueues every launch, world ranges
+    on streams of their own), ticks replayed as hipGraphs off the 16-deep action pool, or launched tick by tick; optionally as
+    world ranges half a tick apart (bench.TickSchedule: mrca_move_worlds / mrca_observe_worlds) -- against
     the C oracle stepping the same action sequence tick by tick: 37 ticks (two full graphs and a remainder), every field of
     every robot."""
     import bench
@@ -202,7 +204,8 @@ def test_bench_schedule_leaves_the_world_where_the_c_oracle_leaves_it(hip, name,
     ora = U.COracleEnv(sc)
     pool = bench.action_pool(sc.num_robots, env.device, 5)
     host_pool = [a.cpu().numpy() for a in pool]
-    sched = bench.TickSchedule(env, pool, chains=chains, graph=graph)
+    sched = bench.TickSchedule(env, pool, chains=chains, graph=graph is True, native=graph == "native")
+    sched.ticks_per_graph = 16
     assert sched.chains == min(chains, sc.num_worlds) and sum(c for _f, c in sched.ranges) == sc.num_worlds
     env.reset()
     ora.reset()
