@@ -36,6 +36,7 @@ import torch  # noqa: E402
 
 SIDE_FIGURE_TIMEOUT_S = 240
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_NS_PER_WAVE_INST = 1.03   # ns a SIMD takes per wave64 VALU instruction at 8 waves per SIMD (tools/valu_rate_probe.hip, measured)
 # Algorithmic HBM bytes per agent-step.  Since round 4 (ABI 4) the frame history is a ring of RAW scans: a tick
 # writes ONE 2 kB row per robot and ~0.1 kB of state -- SURVEY's strict B_env.  (Round 3 stored every beam twice, scan +
 # normalised frame: 4188 B; rounds 1-2 shifted the stack as well: B_env_stack = 10 332 B.)
@@ -279,6 +280,109 @@ def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note="", schedule=
                 "robots": sc.num_robots, "ticks": ticks, "chains": sched.chains, "note": note}
     finally:
         env.close()
+
+
+def assemble_line(*, args, sc, N, world_size, value, elapsed, ray_ms, mv_ms, launches, kernel_timing_note, sched, extra,
+                  per_rank=None, ranks_seen=None, devices=None, backend=None, cpu_baseline_fn=None):
+    """The ONE JSON line of a run as a dict, from what the run measured (rank 0; a pure function of its arguments, so that
+    tests/test_host_bench_line.py can put an 8-rank run through it without eight GPUs).  `sched`: None or the schedule's
+    {graph, native, chains}."""
+    # the launches' own begin / end stamps (hipExtLaunchKernel start / stop events: what rocprofv3 reports); rounds 1-3
+    # recorded events AROUND each launch, which read ~2.5 us longer per kernel -- their sum exceeded ms_per_step
+    ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
+    mv_avg_s = (mv_ms / launches) * 1e-3 if launches else float("nan")
+    traffic, traffic_note = pmc_traffic(N, args.scenario + ("-fidelity" if args.fidelity else ""))
+    achieved = RAY_BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
+    tick_achieved = BYTES_PER_AGENT_STEP * N / (ray_avg_s + mv_avg_s) / 1e9 if launches else None
+    move_achieved = MOVE_BYTES_PER_AGENT_STEP * N / mv_avg_s / 1e9 if launches else None
+    out = {
+        "metric": "agent-steps/s (N robots x 512-beam lidar)" if args.mode == "env" else
+                  f"agent-steps/s ({args.mode}: env + policy" + (" + GAE + PPO update)" if args.mode == "train" else ")"),
+        "value": value, "unit": "agent-steps/s", "n_gpus": world_size, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.scenario}: {args.worlds} worlds x {sc.robots_per_world} robots = {N} "
+                               f"robots/GPU, 512 beams, 3 frames, cell {sc.grid.cell} m, auto-reset, "
+                               f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}" +
+                               ("; FIDELITY mode: Stage's resolutions, raster collisions and raster lidar returns of "
+                                f"robots (collision_raster {sc.collision_raster} m)" if args.fidelity else ""),
+                   "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode,
+                   "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
+                   "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
+                   if args.mode != "env" else None,
+                   "tick_as_hipgraph": (sched['graph'] if sched is not None else not args.no_graph),
+                   "launches_from": (None if sched is None else "one mrca_step_many call per timed region (the library "
+                                     "enqueues every launch)" if sched['native'] else "hipGraph replays" if sched['graph'] else
+                                     "Python, tick by tick"),
+                   "chains": (sched['chains'] if sched is not None else None),
+                   "schedule": (None if sched is None else
+                                "one chain: move launch, ray cast over all worlds" if sched['chains'] == 1 else
+                                f"{sched['chains']} world ranges half a tick apart (a range's move launch runs next to the "
+                                "previous range's ray cast: mrca_move_worlds / mrca_observe_worlds on two streams / graph "
+                                "branches)"),
+                   "ppo_update_dtype": args.update_dtype if args.mode == "train" else None,
+                   "ppo_update_path": (args.update_path if args.update_dtype == "f32" else "stock")
+                   if args.mode == "train" else None},
+        "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "traffic_note": traffic_note,
+                     "bytes_per_agent_step": RAY_BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
+                     "tick": {"achieved": tick_achieved, "frac": tick_achieved / HBM_PEAK_GBS if tick_achieved else None,
+                              "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
+                              "frac_at_survey_B_env_2140": (tick_achieved * B_ENV_STRICT / BYTES_PER_AGENT_STEP / HBM_PEAK_GBS)
+                              if tick_achieved else None,
+                              "note": "both launches of the tick (move, ray cast) against ONE scan row + state = 2236 B per "
+                                      "agent-step (SURVEY's strict B_env = 2140): since ABI 4 the frame history is a ring of "
+                                      "raw scans, the observation x/6 - 0.5 is formed by its readers (round 3: 4188 B, every "
+                                      "beam stored twice; rounds 1-2: 10 332 B with the shift)"},
+                     "move_launch": {"achieved": move_achieved,
+                                     "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
+                                     "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
+                     "move_kernel_avg_us": mv_avg_s * 1e6 if launches else None,
+                     # the OTHER roof (HBM is only the nominal one): vector-ALU issue.  Instructions per wave from the committed
+                     # SQ counter pass x the launch's waves x the time a SIMD needs per wave64 instruction -- MEASURED: 1.03 ns
+                     # with eight waves per SIMD (tools/valu_rate_probe.hip, profiles/r05_h_valu_rate_probe.txt: 2.2 cycles at
+                     # the clock the chip holds; rounds 1-4 priced 4 cycles and called the launch issue-bound at 63 %)
+                     "valu_issue": ({"insts_per_wave": _SQ_VALU_PER_WAVE,
+                                     "frac_of_issue_slots": _SQ_VALU_PER_WAVE * (N * sc.beams / 2 / 64) * VALU_NS_PER_WAVE_INST * 1e-9 /
+                                     (1024 * ray_avg_s),
+                                     "note": "SQ_INSTS_VALU per wave (profiles/pmc_traffic.json, same kernel sources) x waves x "
+                                             "1.03 ns per wave64 instruction and SIMD (measured, tools/valu_rate_probe.hip) / (1024 "
+                                             "SIMDs x launch time)"}
+                                    if (_SQ_VALU_PER_WAVE and launches and args.scenario == "stage1" and not args.fidelity)
+                                    else None),
+                     # the two launches of a tick over ALL worlds, by their own stamps: the tick a single chain cannot beat,
+                     # free of the host and of the timed region's length (a 20-step region is 0.5 ms of wall clock)
+                     "kernel_sum_us": (ray_avg_s + mv_avg_s) * 1e6 if launches else None,
+                     "value_at_kernel_sum": N * world_size / (ray_avg_s + mv_avg_s) if launches else None,
+                     "launches_timed": launches, "kernel_timing": kernel_timing_note,
+                     "note": "HBM is the nominal roof (SURVEY 8d: 2.1 kB per agent-step).  What the launch is made of: two "
+                             "residency rounds of 2048 workgroups at eight waves per SIMD, each wave a chain of dependent memory "
+                             "round trips (robot record, ~2.6 field lookups per beam, LDS hand-offs) around ~546 VALU instructions "
+                             "-- about half of the SIMDs' issue slots while it runs, neither issue- nor bandwidth-bound: "
+                             "launch time = one workgroup's lifetime + robots / throughput (8.2 us + 3.05 us per 1000 robots, "
+                             "profiles/r05_c_*), which is why world ranges on two streams pay; DESIGN.md 5.2, 5.9"},
+    }
+    if args.mode == "rollout":
+        # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (SURVEY 8d: conv1 0.49 + conv2
+        # 1.57 + fc1 4.19 + fc2/heads 0.13, both towers), fp32 on the MFMA / vector pipes (157.3 TFLOP/s dense)
+        flops = 6.4e6 * N
+        tick_s = elapsed / args.steps
+        out["roofline_rollout"] = {
+            "bound": "mfma", "achieved": flops / tick_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+            "frac": flops / tick_s / 1e12 / 157.3,
+            "note": "policy FLOPs of one tick / the WHOLE tick time (env kernels, sampling and launch gaps "
+                    "included): a lower bound on the policy kernels' own rate; fp32 in, fp32 accumulate"}
+    if cpu_baseline_fn is not None and not args.no_cpu_baseline and world_size == 1:
+        out["cpu_baseline"] = cpu_baseline_fn(args.scenario, args.worlds, args.robots_per_world, fidelity=args.fidelity)
+        out["cpu_baseline"]["reference_structural_cap"] = "240 agent-steps/s (24 robots x 10 Hz, stageros.cpp:819-828)"
+    if per_rank is not None:
+        out["per_rank_agent_steps_per_s"] = per_rank      # each rank's own rate on the same per-GPU workload
+        out["collective_backend"] = backend
+        out["rccl_ranks_seen"] = ranks_seen               # sum over ranks of 1.0 through the same process group
+        out["devices"] = devices
+    out.update(extra)
+    return out
 
 
 def main():
@@ -606,97 +710,12 @@ def main():
             _emit()
 
     def _emit():
-        # the launches' own begin / end stamps (hipExtLaunchKernel start / stop events: what rocprofv3 reports); rounds 1-3
-        # recorded events AROUND each launch, which read ~2.5 us longer per kernel -- their sum exceeded ms_per_step
-        ray_avg_s = (ray_ms / launches) * 1e-3 if launches else float("nan")
-        mv_avg_s = (mv_ms / launches) * 1e-3 if launches else float("nan")
-        traffic, traffic_note = pmc_traffic(N, args.scenario + ("-fidelity" if args.fidelity else ""))
-        achieved = RAY_BYTES_PER_AGENT_STEP * N / ray_avg_s / 1e9 if launches else None
-        tick_achieved = BYTES_PER_AGENT_STEP * N / (ray_avg_s + mv_avg_s) / 1e9 if launches else None
-        move_achieved = MOVE_BYTES_PER_AGENT_STEP * N / mv_avg_s / 1e9 if launches else None
-        out = {
-            "metric": "agent-steps/s (N robots x 512-beam lidar)" if args.mode == "env" else
-                      f"agent-steps/s ({args.mode}: env + policy" + (" + GAE + PPO update)" if args.mode == "train" else ")"),
-            "value": value, "unit": "agent-steps/s", "n_gpus": world_size, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scenario}: {args.worlds} worlds x {sc.robots_per_world} robots = {N} "
-                                   f"robots/GPU, 512 beams, 3 frames, cell {sc.grid.cell} m, auto-reset, "
-                                   f"random actions v~U(0,1) w~U(-1,1); mode={args.mode}" +
-                                   ("; FIDELITY mode: Stage's resolutions, raster collisions and raster lidar returns of "
-                                    f"robots (collision_raster {sc.collision_raster} m)" if args.fidelity else ""),
-                       "robots_per_gpu": N, "beams": sc.beams, "mode": args.mode,
-                       "policy_inference_dtype": args.policy_dtype if args.mode != "env" else None,
-                       "policy_inference_path": (args.policy_path if args.policy_dtype == "f32" else "stock")
-                       if args.mode != "env" else None,
-                       "tick_as_hipgraph": (sched.graph if sched is not None else not args.no_graph),
-                       "launches_from": (None if sched is None else "one mrca_step_many call per timed region (the library "
-                                         "enqueues every launch)" if sched.native else "hipGraph replays" if sched.graph else
-                                         "Python, tick by tick"),
-                       "chains": (sched.chains if sched is not None else None),
-                       "schedule": (None if sched is None else
-                                    "one chain: move launch, ray cast over all worlds" if sched.chains == 1 else
-                                    f"{sched.chains} world ranges half a tick apart (a range's move launch runs next to the "
-                                    "previous range's ray cast: mrca_move_worlds / mrca_observe_worlds on two streams / graph "
-                                    "branches)"),
-                       "ppo_update_dtype": args.update_dtype if args.mode == "train" else None,
-                       "ppo_update_path": (args.update_path if args.update_dtype == "f32" else "stock")
-                       if args.mode == "train" else None},
-            "roofline": {"bound": "hbm", "kernel": "raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_note": traffic_note,
-                         "bytes_per_agent_step": RAY_BYTES_PER_AGENT_STEP, "kernel_avg_us": ray_avg_s * 1e6,
-                         "tick": {"achieved": tick_achieved, "frac": tick_achieved / HBM_PEAK_GBS if tick_achieved else None,
-                                  "bytes_per_agent_step": BYTES_PER_AGENT_STEP,
-                                  "frac_at_survey_B_env_2140": (tick_achieved * B_ENV_STRICT / BYTES_PER_AGENT_STEP / HBM_PEAK_GBS)
-                                  if tick_achieved else None,
-                                  "note": "both launches of the tick (move, ray cast) against ONE scan row + state = 2236 B per "
-                                          "agent-step (SURVEY's strict B_env = 2140): since ABI 4 the frame history is a ring of "
-                                          "raw scans, the observation x/6 - 0.5 is formed by its readers (round 3: 4188 B, every "
-                                          "beam stored twice; rounds 1-2: 10 332 B with the shift)"},
-                         "move_launch": {"achieved": move_achieved,
-                                         "frac": move_achieved / HBM_PEAK_GBS if move_achieved else None,
-                                         "bytes_per_agent_step": MOVE_BYTES_PER_AGENT_STEP},
-                         "move_kernel_avg_us": mv_avg_s * 1e6 if launches else None,
-                         # the BINDING roof (HBM is only the nominal one): vector-ALU issue.  Instructions per wave from the
-                         # committed SQ counter pass x the launch's waves x 4 cycles per wave64 instruction, over the SIMD-cycles
-                         # of the launch at the 2.4 GHz peak clock (the chip holds ~2.1 GHz under this kernel: an under-estimate)
-                         "valu_issue": ({"insts_per_wave": _SQ_VALU_PER_WAVE,
-                                         "frac_of_issue_slots": _SQ_VALU_PER_WAVE * (N * sc.beams / 2 / 64) * 4.0 /
-                                         (1024 * ray_avg_s * 2.4e9),
-                                         "note": "SQ_INSTS_VALU per wave (profiles/pmc_traffic.json, same kernel sources) x waves x "
-                                                 "4 cycles / (1024 SIMDs x launch time x 2.4 GHz)"}
-                                        if (_SQ_VALU_PER_WAVE and launches and args.scenario == "stage1" and not args.fidelity)
-                                        else None),
-                         # the two launches of a tick over ALL worlds, by their own stamps: the tick a single chain cannot beat,
-                         # free of the host and of the timed region's length (a 20-step region is 0.5 ms of wall clock)
-                         "kernel_sum_us": (ray_avg_s + mv_avg_s) * 1e6 if launches else None,
-                         "value_at_kernel_sum": N * world_size / (ray_avg_s + mv_avg_s) if launches else None,
-                         "launches_timed": launches, "kernel_timing": kernel_timing_note,
-                         "note": "HBM is the nominal roof (SURVEY 8d); the launch is bound by VALU issue at eight waves per SIMD: "
-                                 "546 VALU instructions per wave (608 in round 3), two residency rounds of 2048 workgroups whose "
-                                 "lifetime is what eight waves per SIMD x ~550 instructions x 4 cycles come to; DESIGN.md 5.2"},
-        }
-        if args.mode == "rollout":
-            # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2
-            # 1.57 + fc1 4.19 + fc2/heads 0.13, both towers), fp32 on the MFMA / vector pipes (157.3 TFLOP/s dense)
-            flops = 6.4e6 * N
-            tick_s = elapsed / args.steps
-            out["roofline_rollout"] = {
-                "bound": "mfma", "achieved": flops / tick_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                "frac": flops / tick_s / 1e12 / 157.3,
-                "note": "policy FLOPs of one tick / the WHOLE tick time (env kernels, sampling and launch gaps "
-                        "included): a lower bound on the policy kernels' own rate; fp32 in, fp32 accumulate"}
-        if not args.no_cpu_baseline and world_size == 1:
-            out["cpu_baseline"] = cpu_baseline(args.scenario, args.worlds, args.robots_per_world, fidelity=args.fidelity)
-            out["cpu_baseline"]["reference_structural_cap"] = "240 agent-steps/s (24 robots x 10 Hz, stageros.cpp:819-828)"
-        if per_rank is not None:
-            out["per_rank_agent_steps_per_s"] = per_rank      # each rank's own rate on the same per-GPU workload
-            out["collective_backend"] = dist.get_backend()
-            out["rccl_ranks_seen"] = ranks_seen               # sum over ranks of 1.0 through the same process group
-            out["devices"] = devices
-        out.update(extra)
-        print(json.dumps(out))
+        line = assemble_line(args=args, sc=sc, N=N, world_size=world_size, value=value, elapsed=elapsed, ray_ms=ray_ms, mv_ms=mv_ms,
+                             launches=launches, kernel_timing_note=kernel_timing_note,
+                             sched=None if sched is None else {"graph": sched.graph, "native": sched.native, "chains": sched.chains},
+                             extra=extra, per_rank=per_rank, ranks_seen=ranks_seen, devices=devices,
+                             backend=dist.get_backend() if dist is not None else None, cpu_baseline_fn=cpu_baseline)
+        print(json.dumps(line))
 
     # multi-GPU side figure: a few PPO updates with the flat-bucket gradient all-reduce on the measured path
     # (the env tick itself needs no collective, so `value` alone would never touch RCCL)

@@ -166,8 +166,9 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
  * step) and advances all of them -- the ordered collision pass needs every provisional pose, and identical arithmetic
  * keeps the replicas bit-identical -- but casts the lidar only for its own robots
  * [first_robot, first_robot + num_robots): scan / obs / local_goal of the other robots are left untouched.  The
- * replicated move phase bounds the speed-up: 69 us of a 579 us tick at 50 000 robots, i.e. at most 4.4x on 8 GPUs
- * (3.85x measured on one rank's share, profiles/r03/r03_f_bigworld_shards8.jsonl). */
+ * replicated move phase bounds the speed-up (DESIGN.md 7 carries the current figures: at 50 000 robots it was 43.5 us of a
+ * 144 us tick in round 4, a ceiling of 2.6x on 8 GPUs, 2.2x projected from one rank's measured share,
+ * profiles/r04_u_bigworld_shards8.jsonl). */
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream);
 
 /* The same tick for the worlds [first_world, first_world + num_worlds) ONLY: their robots advance and are observed, every

@@ -676,6 +676,9 @@ int mrca_check(mrca_env* env, void* stream) {
         return fail(MRCA_ERR_HIP, "fidelity mode: a cell of a robot's outline fell outside the 8 x 8 window of its bitmap since the "
                                   "last check (coordinates beyond the supported range?); collisions and lidar returns of that "
                                   "robot are not to be trusted");
+    if (bits & mrca::kStatusBadBeamIndex)
+        return fail(MRCA_ERR_INVALID, "mrca_sparse_obs: the beam table held an index outside [0, beams) since the last check "
+                                      "(clamped to the nearest beam)");
     return fail(MRCA_ERR_HIP, "device status word 0x%x", bits);
 }
 
@@ -730,20 +733,28 @@ int mrca_enable_timing(mrca_env* env, int32_t on) {
 int mrca_event_pair_overhead(void* stream, int32_t samples, float* us_out) {
     if (!us_out || samples < 1 || samples > 4096) return fail(MRCA_ERR_INVALID, "mrca_event_pair_overhead: bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipEvent_t a, b;
+    int dev = 0;
+    if (s) {     // the events belong on the stream's device, whatever the caller's current one is
+        HIP_TRY(hipStreamGetDevice(s, &dev));
+    } else {
+        HIP_TRY(hipGetDevice(&dev));
+    }
+    DeviceGuard guard(dev);
+    hipEvent_t a = nullptr, b = nullptr;
     HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
+    hipError_t err = hipEventCreate(&b);
     double sum = 0.0;
-    for (int i = 0; i < samples; ++i) {
-        HIP_TRY(hipEventRecord(a, s));
-        HIP_TRY(hipEventRecord(b, s));
-        HIP_TRY(hipEventSynchronize(b));
+    for (int i = 0; err == hipSuccess && i < samples; ++i) {
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        if ((err = hipEventRecord(a, s)) != hipSuccess) break;
+        if ((err = hipEventRecord(b, s)) != hipSuccess) break;
+        if ((err = hipEventSynchronize(b)) != hipSuccess) break;
+        if ((err = hipEventElapsedTime(&ms, a, b)) != hipSuccess) break;
         sum += ms;
     }
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    (void)hipEventDestroy(a);          // on every path
+    if (b) (void)hipEventDestroy(b);
+    if (err != hipSuccess) return fail(MRCA_ERR_HIP, "mrca_event_pair_overhead: %s", hipGetErrorString(err));
     *us_out = (float)(sum / samples * 1e3);
     return MRCA_OK;
 }

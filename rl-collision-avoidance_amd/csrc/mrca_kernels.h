@@ -99,6 +99,7 @@ struct EnvView {
 
 // bits of EnvView::status
 constexpr uint32_t kStatusCollideUndecided = 1u;   // bw_collide_kernel gave up waiting for a lower-indexed robot
+constexpr uint32_t kStatusBadBeamIndex = 4u;       // mrca_sparse_obs: an entry of the caller's beam table was outside [0, beams)
 constexpr uint32_t kStatusOutlineWindow = 2u;      // fidelity mode: an outline cell fell outside the 8 x 8 window of its bitmap
 
 // Ablation switches exist only in the profiling build of the library (csrc/build.sh --profiling ->

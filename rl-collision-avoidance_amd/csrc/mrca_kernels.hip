@@ -213,7 +213,13 @@ __global__ void sparse_obs_kernel(EnvView e, const int32_t* __restrict__ index, 
         const int hd = e.ring_head[r];
         int slot = hd + 1 + f;
         slot -= slot >= e.F ? e.F : 0;
-        out[k] = norm_obs(fabsf(e.scan_ring[((size_t)r * e.F + slot) * e.B + index[j]]));
+        // (the table is the caller's: an entry outside [0, B) must not become an out-of-bounds read -- clamped, and flagged)
+        int bi = index[j];
+        if ((unsigned)bi >= (unsigned)e.B) {
+            atomicOr(e.status, kStatusBadBeamIndex);
+            bi = bi < 0 ? 0 : e.B - 1;
+        }
+        out[k] = norm_obs(fabsf(e.scan_ring[((size_t)r * e.F + slot) * e.B + bi]));
     }
 }
 

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(kThreads) void ppo_loss_kernel(
         const float dv = value[i] - target[i];
         reinterpret_cast<float2*>(gmean)[i] = make_float2(dlp * (d0 / var0), dlp * (d1 / var1));
         gvalue[i] = value_coef * 2.0f * dv * inv_n;
-        acc[0] += (double)fminf(s1, s2);
+        // torch.min propagates a NaN surrogate (a diverged update must show up in the loss, not train on silently); fminf drops it
+        acc[0] += (double)((s1 < s2 || s1 != s1) ? s1 : s2);
         acc[1] += (double)(dv * dv);
         acc[2] += (double)((r - 1.0f) - log_ratio);              // k3 estimator of KL(old || new)
         acc[3] += (double)(dlp * (d0 * d0 / var0 - 1.0f));
@@ -143,6 +144,10 @@ extern "C" int mrca_ppo_loss(const float* mean_dev, const float* value_dev, cons
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     double* partial = static_cast<double*>(scratch_dev);
     unsigned int* ticket = reinterpret_cast<unsigned int*>(static_cast<char*>(scratch_dev) + sizeof(double) * kMaxBlocks * kSums);
+    // the ticket starts at 0 for THIS launch whatever became of the launch before (an aborted launch never resets it, and every
+    // launch after it would have no "last" workgroup: `out` uninitialised): a 4-byte memset node on the same stream
+    if (hipMemsetAsync(ticket, 0, sizeof(unsigned int), static_cast<hipStream_t>(stream)) != hipSuccess)
+        return mrca::set_error(MRCA_ERR_HIP, "mrca_ppo_loss: hipMemsetAsync of the ticket failed");
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream), mean_dev, value_dev,
                        logstd_dev, action_dev, old_logprob_dev, adv_dev, target_dev, n, clip_value, value_coef, coeff_entropy,
                        out_dev, gmean_dev, gvalue_dev, partial, ticket);

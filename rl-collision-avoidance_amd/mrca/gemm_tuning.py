@@ -28,6 +28,13 @@ def use_recorded_choices(path=None, tune_missing=False):
     t = torch.cuda.tunable
     t.enable(True)
     t.tuning_enable(bool(tune_missing))
+    if tune_missing:
+        # newly timed shapes are written at exit -- into `path` (+ the device ordinal PyTorch appends), not into a
+        # tunableop_results<N>.csv in whatever the current directory happens to be
+        try:
+            t.set_filename(path or DEFAULT_FILE, insert_device_ordinal=True)
+        except Exception:
+            pass
     ok = False
     try:
         ok = bool(t.read_file(path or DEFAULT_FILE))

@@ -176,13 +176,18 @@ def lidar_features_fn(obs, w1, b1, w2, b2):
 _loss_scratch = {}
 
 
-def _ppo_loss_scratch(device):
-    key = (device.type, device.index)
+def _ppo_loss_scratch(device, stream):
+    """The loss kernel's partial sums + ticket: one buffer per (device, STREAM) -- two trainers / rank threads / side streams in
+    one process must not share the ticket -- allocated outside any graph capture (a buffer first created inside a capture
+    would live in that graph's private pool)."""
+    key = (device.type, device.index, int(stream))
     if key not in _loss_scratch:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ppo_loss: first use on this stream inside a graph capture -- call it once before capturing")
         lib = _lib.load()
         n = C.c_size_t()
         _lib.check(lib.mrca_ppo_loss_scratch(C.byref(n)), "mrca_ppo_loss_scratch")
-        _loss_scratch[key] = torch.zeros(n.value, dtype=torch.uint8, device=device)      # zeroed once: the ticket counter
+        _loss_scratch[key] = torch.zeros(n.value, dtype=torch.uint8, device=device)
     return _loss_scratch[key]
 
 
@@ -204,9 +209,9 @@ class _PPOLoss(torch.autograd.Function):
         out = torch.empty(8, dtype=torch.float32, device=dev)
         gmean = torch.empty(n, 2, dtype=torch.float32, device=dev)
         gvalue = torch.empty(n, 1, dtype=torch.float32, device=dev)
-        scratch = _ppo_loss_scratch(dev)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            scratch = _ppo_loss_scratch(dev, stream.value or 0)
             _lib.check(lib.mrca_ppo_loss(*[t.data_ptr() for t in args], n, float(clip_value), float(value_coef),
                                          float(coeff_entropy), out.data_ptr(), gmean.data_ptr(), gvalue.data_ptr(),
                                          scratch.data_ptr(), scratch.numel(), stream), "mrca_ppo_loss")

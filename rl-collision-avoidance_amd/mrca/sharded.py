@@ -6,10 +6,10 @@ robots -- the collision pass is sequential in robot order and needs every provis
 on identical inputs keeps the replicas bit-identical, so no pose ever has to travel -- and casts the 512-beam lidar only
 for its own slice (``mrca_step_slice``).
 
-The replicated move phase is what bounds the speed-up (Amdahl): at 50 000 robots it is 69 us of a 579 us tick on one
-MI355X, so 8 GPUs can give at most 4.4x on this design and one rank's share of 8 measures 3.85x
-(``tools/bigworld_bench.py --shards 8``, profiles/r03/r03_f_bigworld_shards8.jsonl).  Sharding the move phase
-too would need a halo exchange of provisional poses inside the ordered collision pass -- not built.
+The replicated move phase is what bounds the speed-up (Amdahl; DESIGN.md 5.4 / 7 carry the current figures): at 50 000
+robots it was 43.5 us of a 144 us tick on one MI355X in round 4 -- at most 2.6x on 8 GPUs, 2.2x projected from one rank's
+measured share (``tools/bigworld_bench.py --shards 8``, profiles/r04_u_bigworld_shards8.jsonl).  Sharding the move phase too
+would need the transitive closure of every slice's lower-indexed neighbours inside the ordered collision pass -- not built.
 """
 import torch
 

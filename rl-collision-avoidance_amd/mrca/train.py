@@ -113,7 +113,11 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
         if not a.no_gemm_choices:       # recorded TunableOp choices for the learner's plain library GEMMs
             from . import gemm_tuning
-            gemm_tuning.use_recorded_choices(tune_missing=a.tune_gemms)
+            accepted = gemm_tuning.use_recorded_choices(tune_missing=a.tune_gemms)
+            if rank == 0:       # (the record is ignored on another ROCm / hipBLASLt version: say which kernels this run uses)
+                print("[train] learner GEMMs: " + ("recorded TunableOp choices (mrca/data/gemm_choices_gfx950_rocm72.csv)"
+                                                   if accepted else "library default heuristic (no record accepted)") +
+                      ("; timing the shapes the record does not list" if a.tune_gemms else ""), file=sys.stderr)
     dist = None
     if world_size > 1:
         import torch.distributed as dist

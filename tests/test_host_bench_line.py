@@ -1,0 +1,105 @@
+"""bench.py's ONE JSON line, assembled on the host from what a run measured (bench.assemble_line: a pure function) -- so that
+the first 8-GPU run cannot lose its curve to a formatting bug: a fake 8-rank run goes through the same code the real one
+will, and the driver's contract keys, the SCALE evidence (rccl_ranks_seen, eight devices, per-rank rates, the gradient
+bucket of the train side figure) and the side figures are checked on the parsed line.  No GPU, no oracle."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "rl-collision-avoidance_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import bench  # noqa: E402
+from mrca import scenario as S  # noqa: E402
+
+CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def _args(**kw):
+    a = argparse.Namespace(mode="env", steps=20, warmup=5, scenario="stage1", worlds=128, robots_per_world=32, fidelity=False,
+                           no_graph=False, no_cpu_baseline=False, policy_dtype="f32", policy_path="fused", update_dtype="f32",
+                           update_path="fused")
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _line(world_size, extra, **kw):
+    sc = S.stage1(num_worlds=128, robots_per_world=32, seed=1000)
+    N = sc.num_robots
+    elapsed = 20 * 31.3e-6
+    per_rank = [N * 20 / (elapsed * (1 + 0.01 * r)) for r in range(world_size)] if world_size > 1 else None
+    return bench.assemble_line(
+        args=_args(**kw), sc=sc, N=N, world_size=world_size, value=N * world_size * 20 / elapsed, elapsed=elapsed,
+        ray_ms=64 * 20.6e-3, mv_ms=64 * 10.8e-3, launches=64, kernel_timing_note="test",
+        sched={"graph": False, "native": True, "chains": 2}, extra=extra, per_rank=per_rank,
+        ranks_seen=world_size if world_size > 1 else None,
+        devices=[f"rank {r}: cuda:{r} AMD Instinct MI355X (gfx950:sramecc+:xnack-, 256 CUs)" for r in range(world_size)]
+        if world_size > 1 else None, backend="nccl" if world_size > 1 else None,
+        cpu_baseline_fn=lambda *a, **k: {"value": 97.3e3, "unit": "agent-steps/s", "cores": 16, "kind": "port", "sample": "test"})
+
+
+def test_single_gpu_line_has_the_contract_keys_roofline_and_cpu_baseline():
+    extra = {"graph_prime_ticks": 0, "rollout_side_figure": {"value": 16e6, "unit": "agent-steps/s"},
+             "stage2_side_figure": {"value": 2.0e8, "unit": "agent-steps/s", "robots": 8228},
+             "fidelity_side_figure": {"value": 8.0e7, "unit": "agent-steps/s"},
+             "reference_shaped_obs_side_figure": {"value": 1.0e8, "unit": "agent-steps/s"}}
+    d = json.loads(json.dumps(_line(1, extra)))            # through JSON: what the driver parses
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["unit"] == "agent-steps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert abs(d["value"] - 4096 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1.0
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["chains"] == 2
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["kernel_avg_us"] - 20.6) < 1e-6 and abs(r["kernel_sum_us"] - 31.4) < 1e-6
+    assert "traffic" in r                                   # null or bytes: bench.pmc_traffic refuses a stale file
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] == 16 and "reference_structural_cap" in c
+    for k in extra:
+        assert k in d, k
+    assert "per_rank_agent_steps_per_s" not in d and "rccl_ranks_seen" not in d
+
+
+def test_eight_rank_line_carries_the_scale_evidence():
+    extra = {"train_side_figure": {"value": 1.5e7, "unit": "agent-steps/s",
+                                   "collective": {"backend": "nccl", "world_size": 8, "gradient_bucket_bytes": 2172101 * 4,
+                                                  "optimizer_steps": 8}},
+             "stage2_side_figure": {"value": 8 * 1.9e8, "per_rank_value": 1.9e8, "robots": 8228, "robots_all_ranks": 65824,
+                                    "unit": "agent-steps/s"}}
+    d = json.loads(json.dumps(_line(8, extra)))
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["rccl_ranks_seen"] == 8 and d["collective_backend"] == "nccl"
+    assert len(d["devices"]) == 8 and all("MI355X" in x for x in d["devices"]) and len(set(d["devices"])) == 8
+    assert len(d["per_rank_agent_steps_per_s"]) == 8 and all(v > 0 for v in d["per_rank_agent_steps_per_s"])
+    assert abs(d["value"] - 8 * 4096 * 20 / (d["ms_per_step"] * 1e-3 * 20)) < 8.0      # whole job: all ranks' robots / max time
+    assert "cpu_baseline" not in d                          # rank 0 at N = 1 only
+    assert d["train_side_figure"]["collective"]["gradient_bucket_bytes"] == 8688404       # 2 172 101 fp32 parameters = 8.69 MB
+    assert d["stage2_side_figure"]["robots_all_ranks"] >= 65536                              # BASELINE configs[3]
+    assert d["roofline"]["value_at_kernel_sum"] > d["value"] / 2
+
+
+def test_the_gradient_bucket_of_the_policy_is_8_69_MB():
+    """what the train side figure's collective will report at N > 1: one flat fp32 bucket of every parameter of CNNPolicy"""
+    import torch
+    from mrca import ppo
+    from mrca.net import CNNPolicy
+    pol = CNNPolicy(frames=3, action_space=2, beams=512)
+    fg = ppo.FlatGrads(pol.parameters())
+    assert fg.flat.numel() == 2172101 and fg.flat.dtype == torch.float32 and fg.flat.numel() * 4 == 8688404
+
+
+def test_world_ranges_of_the_schedule_cover_every_world_once():
+    class _Env:
+        device = None
+    for W in (1, 2, 5, 128, 187):
+        for P in (1, 2, 3, 4, 8):
+            ranges = [(c * W // min(P, W), (c + 1) * W // min(P, W) - c * W // min(P, W)) for c in range(min(P, W))]
+            assert sum(n for _f, n in ranges) == W and ranges[0][0] == 0
+            assert all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1)) and min(n for _f, n in ranges) >= 1

@@ -42,7 +42,8 @@ for STAGE in "$@"; do
     bench)
       timeout 600 python bench.py ${BENCH_ARGS:---steps 1000 --warmup 100} > "$O/bench_env.json" 2> "$O/bench.err"; echo "rc=$?"
       cut -c1-2200 "$O/bench_env.json"; flt < "$O/bench.err" | tail -3
-      timeout 600 python bench.py --steps 1000 --warmup 100 --no-graph --no-cpu-baseline --no-extra > "$O/bench_env_eager.json" 2>> "$O/bench.err"; echo "eager rc=$?"; cut -c1-260 "$O/bench_env_eager.json"
+      timeout 600 python bench.py --steps 1000 --warmup 100 --chains 1 --no-cpu-baseline --no-extra > "$O/bench_env_one_chain.json" 2>> "$O/bench.err"; echo "one chain rc=$?"; cut -c1-260 "$O/bench_env_one_chain.json"
+      timeout 600 python bench.py --steps 2000 --warmup 200 --chains 3 --no-cpu-baseline --no-extra > "$O/bench_env_three_chains.json" 2>> "$O/bench.err"; echo "three chains rc=$?"; cut -c1-260 "$O/bench_env_three_chains.json"
       timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > "$O/bench_env_20_steps.json" 2>> "$O/bench.err"; echo "20-step rc=$?"; cut -c1-260 "$O/bench_env_20_steps.json" ;;
     bench_modes)
       timeout 600 python bench.py --mode rollout --steps 400 --warmup 40 --no-cpu-baseline --no-graph > "$O/bench_rollout.json" 2>> "$O/bench.err"; echo "rollout rc=$?"; cut -c1-260 "$O/bench_rollout.json"
@@ -58,9 +59,9 @@ for STAGE in "$@"; do
       timeout 600 python tools/ablate.py 2>&1 | flt > "$O/ablate.txt"; echo "rc=$?"; cat "$O/ablate.txt" ;;
     prof)
       cd /tmp
-      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o trace -- python "$R/bench.py" --steps 300 --warmup 30 --no-cpu-baseline --no-extra --no-graph > "$O/prof_trace.log" 2>&1; echo "trace rc=$?"
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o trace -- python "$R/bench.py" --steps 300 --warmup 30 --no-cpu-baseline --no-extra --schedule eager --chains 1 > "$O/prof_trace.log" 2>&1; echo "trace rc=$?"
       for C in FETCH_SIZE WRITE_SIZE; do
-        timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/prof" -o pmc_$C -- python "$R/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extra --no-graph > "$O/prof_pmc_$C.log" 2>&1; echo "pmc $C rc=$?"
+        timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/prof" -o pmc_$C -- python "$R/bench.py" --steps 60 --warmup 10 --no-cpu-baseline --no-extra --schedule eager --chains 1 > "$O/prof_pmc_$C.log" 2>&1; echo "pmc $C rc=$?"
       done
       cd "$R"
       f=$(find "$O/prof" -name "trace_kernel_stats.csv" | head -1); [ -n "$f" ] && head -5 "$f" | cut -c1-200 && cp "$f" "$O/env_kernel_stats.csv"

@@ -17,7 +17,7 @@ for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT" -o "set$i" -- \
-    python "$R/bench.py" --steps 40 --warmup 10 --no-cpu-baseline --no-extra --no-graph ${BENCH_EXTRA:-} > "$OUT/set$i.log" 2>&1
+    python "$R/bench.py" --steps 40 --warmup 10 --no-cpu-baseline --no-extra --schedule eager --chains 1 ${BENCH_EXTRA:-} > "$OUT/set$i.log" 2>&1
   echo "set $i ($SET) rc=$?"
 done
 cd "$R"
