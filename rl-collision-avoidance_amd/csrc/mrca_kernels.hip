@@ -742,7 +742,7 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // twice the instructions for the same instruction cache).  Since round 5 a beam's return from another robot's outline is a
 // closed form over that robot's 16-byte outline record (ray_outline_entry) instead of a walk through a window of LDS bits.
 template <int K, bool BIG, bool SEQ, int RKW = 0>
-__global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_first, int ray_count, int R_,
+__global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int only_fresh, int ray_first, int ray_count, int R_,
                                                        const float* __restrict__ pose_p, const float4* __restrict__ head_p,
                                                        const float* __restrict__ bcos_p, const float* __restrict__ bsin_p,
                                                        uint8_t* ring_head_p, EnvView e) {
@@ -995,12 +995,16 @@ __global__ __launch_bounds__(1024) void raycast_kernel(int only_fresh, int ray_f
                         const float tmax_c = kRangeMax * e.raster_inv;
                         const float inv_dx = dx[k] != 0.0f ? rcp_exact(dx[k]) : kInf;
                         const float inv_dy = dy[k] != 0.0f ? rcp_exact(dy[k]) : kInf;
+                        // (the 4 x 4 form: an axis the ray never steps along gets origin -inf, see ray_outline_entry4)
+                        const float fxe = dx[k] != 0.0f ? fxr : -kInf, fye = dy[k] != 0.0f ? fyr : -kInf;
+                        const bool xpos = dx[k] > 0.0f, ypos = dy[k] > 0.0f;
                         do {
                             const int q = __ffsll((long long)m) - 1;
                             m &= m - 1;
                             const int4 oq = nbo[q];
-                            const float tc = ray_outline_entry<RKW>(fxr, fyr, ixr, iyr, dx[k], dy[k], inv_dx, inv_dy,
-                                                                    OutlineBits{oq.x, oq.y, (uint32_t)oq.z, (uint32_t)oq.w});
+                            const OutlineBits ob{oq.x, oq.y, (uint32_t)oq.z, (uint32_t)oq.w};
+                            const float tc = RKW == 4 ? ray_outline_entry4(fxe, fye, ixr, iyr, xpos, ypos, inv_dx, inv_dy, ob)
+                                                      : ray_outline_entry<RKW>(fxr, fyr, ixr, iyr, dx[k], dy[k], inv_dx, inv_dy, ob);
                             const float t = tc < tmax_c ? tc * e.raster_res : kInf;
                             from_robot[k] = from_robot[k] || t < r;
                             r = t < r ? t : r;

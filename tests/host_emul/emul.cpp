@@ -386,8 +386,11 @@ void emul_ray_outline(int n, int kw, float res, const float* ox, const float* oy
         const float fx = ox[i] * inv, fy = oy[i] * inv;
         const int ix0 = (int)floorf(fx), iy0 = (int)floorf(fy);
         const float inv_dx = dx[i] != 0.0f ? rcp_exact(dx[i]) : kInf, inv_dy = dy[i] != 0.0f ? rcp_exact(dy[i]) : kInf;
-        const float t = kw == 4 ? ray_outline_entry<4>(fx, fy, ix0, iy0, dx[i], dy[i], inv_dx, inv_dy, o)
-                                : ray_outline_entry<8>(fx, fy, ix0, iy0, dx[i], dy[i], inv_dx, inv_dy, o);
+        // kw = 4: the rearranged form the fidelity ray cast runs (mrca_device.h ray_outline_entry4), kw = -4: the plain 4 x 4 form
+        const float fxe = dx[i] != 0.0f ? fx : -kInf, fye = dy[i] != 0.0f ? fy : -kInf;
+        const float t = kw == 4 ? ray_outline_entry4(fxe, fye, ix0, iy0, dx[i] > 0.0f, dy[i] > 0.0f, inv_dx, inv_dy, o)
+                        : kw == -4 ? ray_outline_entry<4>(fx, fy, ix0, iy0, dx[i], dy[i], inv_dx, inv_dy, o)
+                                   : ray_outline_entry<8>(fx, fy, ix0, iy0, dx[i], dy[i], inv_dx, inv_dy, o);
         out_closed[i] = t < tmax * inv ? t * res : tmax;
         std::fill(bits.begin(), bits.end(), 0u);
         const RasterWindow win{bits.data(), ix0 - reach, iy0 - reach, side, wpr};

@@ -124,12 +124,12 @@ def _rays(rng, n, res):
     return ox, oy, dx, dy, nx, ny, nth
 
 
-@pytest.mark.parametrize("res,kw", [(0.2, 4), (0.2, 8), (0.1, 8), (0.25, 4), (0.13, 8), (0.5, 4)])
+@pytest.mark.parametrize("res,kw", [(0.2, 4), (0.2, -4), (0.2, 8), (0.1, 8), (0.25, 4), (0.25, -4), (0.13, 8), (0.5, 4), (0.198, 4)])
 def test_closed_form_return_equals_the_walk_through_marked_cells(res, kw):
     lib = _lib()
-    rng = np.random.default_rng(int(res * 1000) + kw)
+    rng = np.random.default_rng(int(res * 1000) + abs(kw))
     n = 60000
-    assert lib.emul_outline_span(res) <= kw
+    assert lib.emul_outline_span(res) <= abs(kw)        # (kw = 4: the rearranged 4 x 4 form of the kernel, -4: the plain one)
     ox, oy, dx, dy, nx, ny, nth = _rays(rng, n, res)
     ob = np.zeros((n, 4), np.int32)
     for i in range(n):
