@@ -423,7 +423,7 @@ def main():
                     help="env mode: the worlds as this many world ranges, each a chain of (move launch, ray cast) on its own stream "
                          "/ graph branch, half a tick apart, so that one range's move launch runs next to another's ray cast "
                          "(TickSchedule; mrca_move_worlds / mrca_observe_worlds).  1 = every tick as two launches over all worlds "
-                         "(rounds 1-4).  Default: 2")
+                         "(rounds 1-4).  Default: 2 for regions below 200 ticks, 3 above (the pipeline's fill and drain against its width)")
     ap.add_argument("--schedule", default=None, choices=["native", "graph", "eager"],
                     help="env mode: how the timed ticks reach the GPU.  native (default): ONE mrca_step_many call, the library "
                          "enqueues every launch itself; graph: replayed as hipGraphs captured from Python; eager (= --no-graph): "
@@ -515,7 +515,10 @@ def main():
     extra = {}
     sched = None
     if args.chains is None:
-        args.chains = 2
+        # two ranges fill the pipeline in half a tick; three keep more of the chip busy once it is full but cost a 20-tick region
+        # more at its head and tail than they win (measured, profiles/r05_g_*: 131 / 158 M with two, 120 / 167 M with three at
+        # 20 / 2000 steps)
+        args.chains = 2 if args.steps < 200 else 3
     if args.mode == "env":
         # The tick replayed as hipGraphs (default) or launched from the host (--no-graph), as one chain over all worlds or as
         # --chains world ranges half a tick apart: TickSchedule above.
