@@ -423,7 +423,7 @@ def main():
                     help="env mode: the worlds as this many world ranges, each a chain of (move launch, ray cast) on its own stream "
                          "/ graph branch, half a tick apart, so that one range's move launch runs next to another's ray cast "
                          "(TickSchedule; mrca_move_worlds / mrca_observe_worlds).  1 = every tick as two launches over all worlds "
-                         "(rounds 1-4).  Default: 2 for regions below 200 ticks, 3 above (the pipeline's fill and drain against its width)")
+                         "(rounds 1-4).  Default: 2")
     ap.add_argument("--schedule", default=None, choices=["native", "graph", "eager"],
                     help="env mode: how the timed ticks reach the GPU.  native (default): ONE mrca_step_many call, the library "
                          "enqueues every launch itself; graph: replayed as hipGraphs captured from Python; eager (= --no-graph): "
@@ -515,10 +515,10 @@ def main():
     extra = {}
     sched = None
     if args.chains is None:
-        # two ranges fill the pipeline in half a tick; three keep more of the chip busy once it is full but cost a 20-tick region
-        # more at its head and tail than they win (measured, profiles/r05_g_*: 131 / 158 M with two, 120 / 167 M with three at
-        # 20 / 2000 steps)
-        args.chains = 2 if args.steps < 200 else 3
+        # two ranges: one move launch apart IS half a chain's period, whatever the box (158 M over 2000 ticks, 140 M over 20).
+        # Three ranges are one move launch apart as well -- 0.45 of a period where a third is wanted -- and end up between 151
+        # and 168 M depending on how the chains settle (profiles/r05_g_*, r05_k_*, r05_l_region_sweep.txt): `--chains 3` to try
+        args.chains = 2
     if args.mode == "env":
         # The tick replayed as hipGraphs (default) or launched from the host (--no-graph), as one chain over all worlds or as
         # --chains world ranges half a tick apart: TickSchedule above.

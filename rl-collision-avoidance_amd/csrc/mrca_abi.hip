@@ -632,13 +632,12 @@ int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_a
         env->chain_moved.push_back(a);
         env->chain_done.push_back(b);
     }
-    if (!env->chain_fork) HIP_TRY(hipEventCreateWithFlags(&env->chain_fork, hipEventDisableTiming));
     if (num_ticks == 0) return MRCA_OK;
     auto stream_of = [&](int c) { return c == 0 ? s0 : env->chain_stream[c - 1]; };
     auto first_world = [&](int c) { return (int)((int64_t)c * W / P); };
-    // fork: the other ranges' streams start behind everything queued on the caller's
-    HIP_TRY(hipEventRecord(env->chain_fork, s0));
-    for (int c = 1; c < P; ++c) HIP_TRY(hipStreamWaitEvent(stream_of(c), env->chain_fork, 0));
+    // (fork: range c's stream starts behind range c - 1's FIRST move launch -- which sits behind everything queued on the caller's
+    // stream before this call, so that one wait is the fork AND the half tick between the ranges; the first launch of the call
+    // goes out before any event is touched)
     for (int k = 0; k < num_ticks; ++k) {
         const float* a = act(k);
         for (int c = 0; c < P; ++c) {

@@ -245,17 +245,26 @@ class VecStageWorld:
         """``num_ticks`` ticks from ONE call: tick k takes ``actions[(first_tick + k) % len(actions)]`` (a list of f32[N,2]
         device tensors: a scripted scenario, the benchmark's action pool); ``chains`` world ranges tick on streams of their
         own, half a tick apart (mrca_step_many).  Equal to ``num_ticks`` calls of ``step``."""
-        key = tuple(t.data_ptr() for t in actions)
+        # (the pointer table of a list is built once per list object: a 20-tick region is 0.6 ms, sixteen data_ptr() calls and
+        # their checks are 2 % of it)
         cache = self.__dict__.setdefault("_many_ptrs", {})
-        if key not in cache:
-            for t in actions:
-                self._ptr(t, torch.float32, self.N * 2)
+        entry = cache.get(id(actions))
+        if entry is None or entry[0] is not actions or len(actions) != entry[2]:
+            ptrs = [self._ptr(t, torch.float32, self.N * 2).value for t in actions]
             cache.clear()
-            cache[key] = (C.c_void_p * len(actions))(*key)
-        _lib.check(self.lib.mrca_step_many(self._h, cache[key], len(actions), int(first_tick), int(num_ticks), int(chains),
-                                           self._stream()), "mrca_step_many")
+            entry = cache[id(actions)] = (actions, (C.c_void_p * len(actions))(*ptrs), len(actions))
+        rc = self.lib.mrca_step_many(self._h, entry[1], entry[2], int(first_tick), int(num_ticks), int(chains), self._stream())
+        if rc:
+            _lib.check(rc, "mrca_step_many")
         self._views_current = self._eager_views if chains <= 1 else 0
         return self
+
+    def ring_ranges(self):
+        """f32[N,F,B]: a COPY of the scan ring as plain ranges.  ``scan_ring`` itself keeps what every beam hit in the SIGN
+        bit of its entry (set: another robot; -0.0 included), in the default mode as in fidelity mode -- a consumer that reads
+        the field directly (``policy_obs()``, ``mrca_get_field(MRCA_F_SCAN_RING)``) must take |x| like the in-tree readers do
+        (``hit_robot``, the policy's front end, ``mrca_normalize_scans``); this accessor is for the ones that would forget."""
+        return self.scan_ring.abs()
 
     def check(self):
         """Host round trip: raises if a kernel flagged a device-side failure since the last check (mrca_check)."""
