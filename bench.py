@@ -237,7 +237,10 @@ class TickSchedule:
 
     def run(self, first, count):
         if self.native:
-            self.env.step_many(self.pool, first, count, self.chains)
+            # (at most `ticks_per_graph` ticks per call: thousands of launches enqueued at once run the HIP runtime out of its
+            # pools, and the region after such a call was measured 15 % slow, profiles/r05_n_*)
+            for k, m in self.chunks(first, count):
+                self.env.step_many(self.pool, k, m, self.chains)
         elif not self.graph:
             self.issue(first, count)
         else:
@@ -558,6 +561,15 @@ def main():
         # in a 1000-step one nothing.  These are extra untimed ticks (reported as `graph_prime_ticks`); the timed region stays
         # EXACTLY --steps ticks.
         extra["graph_prime_ticks"] = sched.prime(args.warmup, args.steps)
+        if sched.native:
+            # the same for the native schedule: the region's launches are enqueued once, untimed, before the warm-up -- the HIP
+            # runtime grows its kernel-argument and signal pools the first time a stream sees that many launches in flight (a
+            # 20-tick region of two ranges is 80), and a region that pays for that is 8 % slower than the next one of the
+            # same length (tools/region_sweep.py vs a cold run: 140 vs 130 M).  Extra untimed ticks, reported here.
+            reps = max(1, min(8, 256 // max(1, args.steps)))       # a short region a few times over: ~a quarter of a thousand ticks
+            for _ in range(reps):
+                sched.run(args.warmup, args.steps)
+            extra["graph_prime_ticks"] = reps * args.steps
         torch.cuda.synchronize()
         sched.run(0, args.warmup)
         barrier()
