@@ -403,11 +403,15 @@ def test_error_behaviour(hip):
     env.close()
 
 
-@pytest.mark.parametrize("name,worlds,R,steps", [("stage1", 128, 32, 24), ("stage2", 187, 44, 12)])
+@pytest.mark.parametrize("name,worlds,R,steps", [("stage1", 128, 32, 24), ("stage2", 187, 44, 12), ("stage1_fidelity", 128, 32, 16),
+                                                 ("stage2_fidelity", 187, 44, 8)])
 def test_full_batch_bit_exact_vs_c_oracle(hip, name, worlds, R, steps):
     """BASELINE configs[1]/[2] at FULL size, every robot, every field, bit-for-bit against the plain-C
-    restatement of the oracle (itself bit-identical to the NumPy oracle: tests/test_oracle_c.py)."""
-    sc = S.stage1(num_worlds=worlds, robots_per_world=R, seed=123) if name == "stage1" else S.stage2(num_worlds=worlds, seed=123)
+    restatement of the oracle (itself bit-identical to the NumPy oracle: tests/test_oracle_c.py) -- in the default mode and
+    in fidelity mode (Stage's 0.2 m raster: outline bitmaps, the closed-form raster lidar)."""
+    fid = name.endswith("_fidelity")
+    sc = S.stage1(num_worlds=worlds, robots_per_world=R, seed=123, stage_resolution=fid) if name.startswith("stage1") else \
+        S.stage2(num_worlds=worlds, seed=123, stage_resolution=fid)
     env = hip.VecStageWorld(sc)
     ora = U.COracleEnv(sc)
     env.reset()
