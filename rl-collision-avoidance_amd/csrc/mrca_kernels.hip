@@ -84,46 +84,58 @@ __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local
     e.init_pose[n * 3 + 2] = th;
 }
 
-// Wave-parallel rejection sampling: the 64 lanes evaluate 64 consecutive attempts k at once and the
-// lowest acceptable k wins -- the same draw the one-lane loop (sample_pose / sample_goal) returns,
-// without a wavefront waiting on one unlucky robot's long tail.  All arguments are wave-uniform.
 // lane must be wave-uniform: v_readlane_b32
 __device__ __forceinline__ int ibcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float fbcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-__device__ __forceinline__ void wave_sample_pose(int lane, int mode, uint32_t gid, uint32_t ep, uint32_t k0,
-                                                 uint32_t k1, float curx, float cury, float* px, float* py,
-                                                 float* pth) {
-    for (int base = 0; base < kMaxTriesPose; base += kWave) {
+// Wave-parallel rejection sampling for FOUR robots at once: the wave as four groups of 16 lanes, group g sampling for "its"
+// robot (all arguments uniform within a group; `need` false = the group has nothing to sample), 16 consecutive attempts k per
+// step, the lowest acceptable k wins -- the same draw the one-lane loop (sample_pose / sample_goal) returns, without a
+// wavefront waiting on one unlucky robot's long tail.  (Rounds 2-4: the whole wave sampled 64 attempts for ONE robot at a time;
+// a world's restarts took turns, 2 700 ticks each,
+// and a launch lasts as long as its slowest world: with 0.5 restarts per world and tick on the Stage-1 worlds some world of
+// every launch has three (profiles/r05_k_*: mean workgroup 13 100 ticks, launch 22 300), and a Stage-2 group of ten
+// region-sampled robots restarts together.)
+__device__ __forceinline__ void group_sample_pose(int g, int sub, bool need, int mode, uint32_t gid, uint32_t ep, uint32_t k0,
+                                                  uint32_t k1, float curx, float cury, float* px, float* py, float* pth) {
+    bool done = !need;
+    for (int base = 0; base < kMaxTriesPose; base += 16) {
         float x, y, th;
-        const bool ok = pose_try(mode, gid, ep, (uint32_t)(base + lane), k0, k1, curx, cury, &x, &y, &th);
-        const bool last = base + kWave >= kMaxTriesPose;
-        const unsigned long long m = __ballot(ok || (last && lane == kMaxTriesPose - 1 - base));
-        if (m) {
-            const int w = __ffsll((long long)m) - 1;
-            *px = fbcast(x, w);
-            *py = fbcast(y, w);
-            *pth = fbcast(th, w);
-            return;
+        const bool ok = pose_try(mode, gid, ep, (uint32_t)(base + sub), k0, k1, curx, cury, &x, &y, &th);
+        const bool last = base + 16 >= kMaxTriesPose;
+        const unsigned long long m = __ballot(!done && (ok || (last && sub == kMaxTriesPose - 1 - base)));
+        const uint32_t m16 = (uint32_t)(m >> (16 * g)) & 0xFFFFu;
+        const int w = 16 * g + (m16 ? __ffs((int)m16) - 1 : 0);
+        const float wx = __shfl(x, w, kWave), wy = __shfl(y, w, kWave), wth = __shfl(th, w, kWave);
+        if (!done && m16) {
+            *px = wx;
+            *py = wy;
+            *pth = wth;
+            done = true;
         }
+        if (__ballot(!done) == 0ull) break;
     }
 }
 
-__device__ __forceinline__ void wave_sample_goal(int lane, int mode, uint32_t gid, uint32_t ep, uint32_t k0,
-                                                 uint32_t k1, float curx, float cury, float* gx, float* gy) {
-    for (int base = 0; base < kMaxTriesGoal; base += kWave) {
+__device__ __forceinline__ void group_sample_goal(int g, int sub, bool need, int mode, uint32_t gid, uint32_t ep, uint32_t k0,
+                                                  uint32_t k1, float curx, float cury, float* gx, float* gy) {
+    bool done = !need;
+    for (int base = 0; base < kMaxTriesGoal; base += 16) {
         float x, y;
-        const bool ok = goal_try(mode, gid, ep, (uint32_t)(base + lane), k0, k1, curx, cury, &x, &y);
-        const bool last = base + kWave >= kMaxTriesGoal;
-        const unsigned long long m = __ballot(ok || (last && lane == kMaxTriesGoal - 1 - base));
-        if (m) {
-            const int w = __ffsll((long long)m) - 1;
-            *gx = fbcast(x, w);
-            *gy = fbcast(y, w);
-            return;
+        const bool ok = goal_try(mode, gid, ep, (uint32_t)(base + sub), k0, k1, curx, cury, &x, &y);
+        const bool last = base + 16 >= kMaxTriesGoal;
+        const unsigned long long m = __ballot(!done && (ok || (last && sub == kMaxTriesGoal - 1 - base)));
+        const uint32_t m16 = (uint32_t)(m >> (16 * g)) & 0xFFFFu;
+        const int w = 16 * g + (m16 ? __ffs((int)m16) - 1 : 0);
+        const float wx = __shfl(x, w, kWave), wy = __shfl(y, w, kWave);
+        if (!done && m16) {
+            *gx = wx;
+            *gy = wy;
+            done = true;
         }
+        if (__ballot(!done) == 0ull) break;
     }
 }
 
@@ -566,42 +578,48 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int wo
     float spv = v, spw = w, ovgt = vgt, owgt = wgt;
     if (MRCA_DBG(e, 32)) fresh = false;
     MRCA_STAMP(6);      // reward / terminal / group ballots done
-    // new episodes, one robot at a time with the whole wave sampling for it
+    // new episodes, FOUR robots per round: group g = lane / 16 samples for the g-th lowest restarting robot of the round
     unsigned long long pending = __ballot(fresh);
     while (pending) {
-        const int src = __ffsll((long long)pending) - 1;
-        pending &= pending - 1;
-        const int nsrc = world * e.R + src;
-        const uint32_t eps = (uint32_t)(ibcast(ep, src) + 1);
-        const int rm = ibcast(rmode, src), gm = ibcast(gmode, src);
-        float px, py, pth, qx, qy;
-        if (rm == 0) {
-            px = fbcast(tix, src);
-            py = fbcast(tiy, src);
-            pth = wrap_angle(fbcast(tith, src));
-        } else {
-            wave_sample_pose(lane, rm, (uint32_t)nsrc, eps, e.key0, e.key1, fbcast(x, src), fbcast(y, src), &px, &py,
-                             &pth);
+        int sel[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sel[q] = pending ? __ffsll((long long)pending) - 1 : -1;
+            pending &= pending - 1;        // (0 & anything = 0: stays empty once it is)
         }
-        if (gm == 0) {
-            qx = fbcast(tgx, src);
-            qy = fbcast(tgy, src);
-        } else {
-            wave_sample_goal(lane, gm, (uint32_t)nsrc, eps, e.key0, e.key1, px, py, &qx, &qy);
-        }
-        if (lane == src) {
-            ep = (int)eps;
-            x = px;
-            y = py;
-            th = pth;
-            gx = qx;
-            gy = qy;
-            const float ex = qx - px, ey = qy - py;
+        const int g = lane >> 4, sub = lane & 15;
+        const int src = g == 0 ? sel[0] : g == 1 ? sel[1] : g == 2 ? sel[2] : sel[3];      // uniform within a group
+        const bool act = src >= 0;
+        const int srcl = act ? src : 0;
+        // the robot's values come out of its lane (every lane of the wave takes part in the shuffles)
+        const uint32_t nsrc = (uint32_t)(world * e.R + srcl);
+        const uint32_t eps = (uint32_t)(__shfl(ep, srcl, kWave) + 1);
+        const int rm = __shfl(rmode, srcl, kWave), gm = __shfl(gmode, srcl, kWave);
+        const float cx_ = __shfl(x, srcl, kWave), cy_ = __shfl(y, srcl, kWave);
+        const float six = __shfl(tix, srcl, kWave), siy = __shfl(tiy, srcl, kWave), sith = __shfl(tith, srcl, kWave);
+        const float sgx = __shfl(tgx, srcl, kWave), sgy = __shfl(tgy, srcl, kWave);
+        float px = six, py = siy, pth = wrap_angle(sith);      // table rows (mode 0) unless sampled
+        group_sample_pose(g, sub, act && rm != 0, rm, nsrc, eps, e.key0, e.key1, cx_, cy_, &px, &py, &pth);
+        float qx = sgx, qy = sgy;
+        group_sample_goal(g, sub, act && gm != 0, gm, nsrc, eps, e.key0, e.key1, px, py, &qx, &qy);
+        // ... and go back to it: the robot's own lane reads its group's results from the group's first lane
+        const int gi = lane == sel[0] ? 0 : lane == sel[1] ? 1 : lane == sel[2] ? 2 : lane == sel[3] ? 3 : -1;
+        const int from = 16 * (gi < 0 ? 0 : gi);
+        const float rpx = __shfl(px, from, kWave), rpy = __shfl(py, from, kWave), rpth = __shfl(pth, from, kWave);
+        const float rqx = __shfl(qx, from, kWave), rqy = __shfl(qy, from, kWave);
+        if (gi >= 0) {
+            ep = ep + 1;
+            x = rpx;
+            y = rpy;
+            th = rpth;
+            gx = rqx;
+            gy = rqy;
+            const float ex = rqx - rpx, ey = rqy - rpy;
             const float d0 = sqrtf(ex * ex + ey * ey);
             pdist = e.pre_dist_zero ? 0.0f : d0;
-            e.init_pose[n * 3 + 0] = px;
-            e.init_pose[n * 3 + 1] = py;
-            e.init_pose[n * 3 + 2] = pth;
+            e.init_pose[n * 3 + 0] = rpx;
+            e.init_pose[n * 3 + 1] = rpy;
+            e.init_pose[n * 3 + 2] = rpth;
             t = 1;
             crashed = 0;
             lv = 1;
