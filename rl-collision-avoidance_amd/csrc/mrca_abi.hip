@@ -805,6 +805,20 @@ int mrca_debug_move_stamps(mrca_env* env, double* avg_ticks_out /* [9]: 8 deltas
 #endif
 
 #if defined(MRCA_PROFILING)
+// Profiling build only: the raw stamps of the LAST move launch, out[k * worlds + w] = stamp k (0..8) of world w -- for the
+// DISTRIBUTION over worlds (a launch lasts as long as its slowest world): tools/move_tail.py
+int mrca_debug_move_stamps_raw(mrca_env* env, unsigned long long* out /* [10 * worlds] */, int32_t* worlds_out) {
+    if (!env || !out || !worlds_out) return fail(MRCA_ERR_INVALID, "NULL argument");
+    DeviceGuard guard(env->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    const int W = env->view.W < 4096 ? env->view.W : 4096;
+    mrca::read_move_stamps(out, W);
+    *worlds_out = W;
+    return MRCA_OK;
+}
+#endif
+
+#if defined(MRCA_PROFILING)
 // Profiling build only: s_memtime stamps of the LAST ray-cast launch (synchronises the device).  out[w * 7 + k], w = 0, 1
 // (wave 0 prepares the neighbour list, wave 1 only marches), k = 0..6: mean over workgroups of stamp k minus the
 // workgroup's entry stamp; out[14..16] = 0 (reserved).

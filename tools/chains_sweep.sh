@@ -14,7 +14,7 @@ print('chains %s %-6s steps %5d  value %7.2f M  tick %6.2f us  (kernels over all
 }
 for _ in $(seq "$reps"); do
   for C in 1 2 3 4 8; do
-    python bench.py --steps 2000 --warmup 200 --chains $C --no-cpu-baseline --no-extra "$@" 2>>"$O/chains_sweep.err" | line $C graph
+    python bench.py --steps 2000 --warmup 200 --chains $C --schedule graph --no-cpu-baseline --no-extra "$@" 2>>"$O/chains_sweep.err" | line $C graph
     python bench.py --steps 2000 --warmup 200 --chains $C --no-graph --no-cpu-baseline --no-extra "$@" 2>>"$O/chains_sweep.err" | line $C eager
     python bench.py --steps 20 --warmup 5 --chains $C --no-cpu-baseline --no-extra "$@" 2>>"$O/chains_sweep.err" | line $C graph
   done
