@@ -436,6 +436,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.key0 = (uint32_t)(cfg->seed & 0xFFFFFFFFull);
     v.key1 = (uint32_t)(cfg->seed >> 32);
     v.foot_hc = (int32_t)std::ceil(0.2907 * (double)v.g.inv_cell) + 1;
+    v.edge_slots = mrca::edge_event_slots(v.g.inv_cell);
     v.raster_inv = cfg->collision_raster > 0.0f ? 1.0f / cfg->collision_raster : 0.0f;
     v.raster_res = cfg->collision_raster;
     // the ray cast tests 4 x 4 cells of a neighbour's outline window where that covers every outline (Stage's 0.2 m), else 8 x 8

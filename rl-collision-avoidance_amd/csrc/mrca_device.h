@@ -505,6 +505,75 @@ MRCA_HD bool static_edge_hit(const Occ& occ, const GridGeom& g, float x, float y
     return grid_march(occ, g, cx, cy, ex, ey, el) < el;
 }
 
+// ------------------------------------------------------------------------------------------
+// The same edge test WITHOUT walking (round 5).  grid_march's walk is a merge of the x crossings and the y crossings of
+// the edge; every crossing that happens within the walk (its time t < tmax in cell units -- crossings are taken in time
+// order, so those are exactly the ones taken) enters one cell, and WHICH cell follows from a count: after the i-th x
+// crossing the ray is in column ix0 + sx * i and in the row it has reached by then -- the y crossings with ty <= tx_i are
+// behind it (ties step in y first) -- and after the j-th y crossing in row iy0 + sy * j and the column given by the x
+// crossings with tx < ty_j.  The count is grid_march_skip's settlement: an arithmetic estimate of the pending boundary,
+// within one of the truth, settled with the same closed-form times.  So one lane can take ONE event -- q = 0 the start
+// cell, 1..Q the x crossings, Q + 1..2Q the y crossings -- and an edge is 2Q + 1 independent lanes instead of a chain of
+// ~13 dependent steps of one (move_kernel: 6 000 of a workgroup's 13 000 - 22 000 ticks whenever a robot of the world is
+// near a wall, profiles/r05_r_move_tail.txt).  The edge hits iff some event enters an occupied cell at t * cell < tmax:
+// entry times never decrease along the walk, so if the FIRST occupied cell fails that test every later one does, and if it
+// passes the OR is true -- grid_march(...) < tmax exactly.  Q = edge_event_slots(): crossings per axis an edge can have.
+MRCA_HD int edge_event_slots(float inv_cell) { return (int)ceilf(2.0f * kHalfLen * inv_cell) + 1; }
+
+template <class Occ>
+MRCA_HD bool walk_event_hits(const Occ& occ, const GridGeom& g, float ox, float oy, float dx, float dy, float tmax, int q,
+                             int Q) {
+    const float fx = (ox - g.x0) * g.inv_cell;
+    const float fy = (oy - g.y0) * g.inv_cell;
+    const int ix0 = (int)floorf(fx);
+    const int iy0 = (int)floorf(fy);
+    if (q == 0) return occ(ix0, iy0);                  // grid_march: an occupied start cell is a hit at distance 0
+    const float tmax_c = tmax * g.inv_cell;
+    if (!(tmax_c > 0.0f)) return false;
+    const bool isx = q <= Q;                           // an x crossing (the primary axis P = x), else a y crossing (P = y)
+    const int i = isx ? q : q - Q;                     // the i-th crossing of the primary axis, 1-based
+    const float fP = isx ? fx : fy, dP = isx ? dx : dy;
+    const float fS = isx ? fy : fx, dS = isx ? dy : dx;
+    const int iP0 = isx ? ix0 : iy0, iS0 = isx ? iy0 : ix0;
+    if (!(dP != 0.0f)) return false;                   // an axis the edge does not move along is never crossed
+    const float invP = rcp_exact(dP);
+    const int sP = dP > 0.0f ? 1 : -1, uP = dP > 0.0f ? 1 : 0;
+    const float t = ((float)(iP0 + uP + sP * (i - 1)) - fP) * invP;        // grid_march's tx / ty of that boundary
+    if (!(t < tmax_c)) return false;                   // the walk ends at the first crossing with t >= tmax
+    // the other axis: its first pending boundary once every crossing that the merge takes BEFORE this event is consumed
+    // (before an x crossing: ty <= t; before a y crossing: tx < t) -- grid_march_skip's settlement
+    const int sS = dS > 0.0f ? 1 : -1, uS = dS > 0.0f ? 1 : 0;
+    const int bS0 = iS0 + uS;
+    int bS = bS0;
+    if (dS != 0.0f) {
+        const float invS = rcp_exact(dS);
+        const float pT = fS + dS * t;
+        const int b = med3_i32((int)floorf(pT) + uS, bS0, dS > 0.0f ? 0x3FFFFFFF : -0x3FFFFFFF);
+        const int bprev = b - sS;
+        const float tp = ((float)bprev - fS) * invS;
+        const float tc = ((float)b - fS) * invS;
+        const bool cons_p = (tp < t) | ((tp == t) & isx);
+        const bool cons_c = (tc < t) | ((tc == t) & isx);
+        bS = cons_c ? b + sS : b;
+        bS = ((b != bS0) & !cons_p) ? bprev : bS;
+    }
+    const int cP = iP0 + sP * i, cS = bS - uS;
+    return occ(isx ? cP : cS, isx ? cS : cP) && (t * g.cell < tmax);
+}
+
+// event q of edge k of the footprint at (x, y, sin, cos): the OR over q = 0 .. 2Q is static_edge_hit(..., k)
+template <class Occ>
+MRCA_HD bool static_edge_event_hits(const Occ& occ, const GridGeom& g, float x, float y, float s, float c, int k, int q, int Q) {
+    const float hx = (k == 0 || k == 3) ? kHalfLen : -kHalfLen;
+    const float hy = (k < 2) ? kHalfWid : -kHalfWid;
+    const float ex = (k == 0) ? -c : (k == 1) ? s : (k == 2) ? c : -s;
+    const float ey = (k == 0) ? -s : (k == 1) ? -c : (k == 2) ? s : c;
+    const float el = (k & 1) ? 2.0f * kHalfWid : 2.0f * kHalfLen;
+    const float cx = x + (hx * c - hy * s);
+    const float cy = y + (hx * s + hy * c);
+    return walk_event_hits(occ, g, cx, cy, ex, ey, el, q, Q);
+}
+
 template <class Occ>
 MRCA_HD bool static_hit(const Occ& occ, const GridGeom& g, float x, float y, float s, float c) {
     bool hit = false;

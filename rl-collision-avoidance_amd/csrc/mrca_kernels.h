@@ -90,6 +90,7 @@ struct EnvView {
     float lidar_radius, lidar_near, lidar_reach2;
     float collide_reach2; // squared centre distance beyond which two robots cannot collide (broad phase)
     int32_t foot_hc;      // half extent (cells) of the move kernel's per-robot mini tile
+    int32_t edge_slots;   // crossings per axis a footprint edge can have on this map (mrca_device.h edge_event_slots)
     int32_t ray_shift;    // raycast_kernel marches 1 << ray_shift beams per thread in lock step
     int32_t ray_sequential; // 1 (with ray_shift 1): the two beams of a thread are marched one after the other
     int32_t ray_prep_wave;  // 1: a dedicated wave prepares the neighbour list (blockDim = beams >> ray_shift + 64)

@@ -38,6 +38,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kPatchLoads = 6;   // independent patch-word loads a thread of move_kernel keeps in flight
 constexpr int kMoveWaves = 4;    // wavefronts per world in move_kernel
+constexpr int kEventOutlineTasks = 3 * kWave * kMoveWaves;   // outline test by events up to three passes of the block's threads, else by walks
 
 __device__ __forceinline__ void begin_episode(const EnvView& e, int n, int local, float curx, float cury, float* px,
                                               float* py, float* pth, float* gx, float* gy, float* pdist,
@@ -432,18 +433,50 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int wo
     }
     __syncthreads();
     MRCA_STAMP(3);      // patches in LDS
-    // outline walks, four lanes per robot (one per edge): a walk is a chain of dependent LDS reads, so spreading the
-    // edges over lanes cuts the chain by four; 64 robots per pass over the block's threads
-    for (int base = 0; base < n_need; base += kWave * kMoveWaves / 4) {
-        const int q = base + (tid >> 2);
-        const bool act = q < n_need;
-        const int src = act ? need_list[q] : 0;
-        const float sx_ = __shfl(nx, src, kWave), sy_ = __shfl(ny, src, kWave);
-        const float ss_ = __shfl(ns, src, kWave), sc_ = __shfl(nc, src, kWave);
-        const int sy0 = __shfl(py0, src, kWave), sw0 = __shfl(pw0, src, kWave);
-        if (act) {
-            const MiniGrid mg{mini + src * psize, sy0, sw0, pwords};
-            if (static_edge_hit(mg, e.g, sx_, sy_, ss_, sc_, tid & 3)) hit_flag[src] = 1;
+    // the outline test, one lane per crossing EVENT of an edge's walk (the start cell, every x crossing, every y crossing: which
+    // cell an event enters is a closed form, mrca_device.h walk_event_hits) -- rounds 1-4 walked: four lanes per robot, ~13
+    // dependent steps of ~25 instructions each on a wave that issues one instruction per 4.2 cycles: 6 000 ticks whenever
+    // any robot of the world was near a wall.  Tasks (robot in need, edge, event) are dealt to the block's threads in order.
+    // (An edge has 2Q + 1 event slots -- 21 at 0.05 m cells -- and uses ~14: beyond ~20 robots near walls, a Stage-2 world, the
+    // events are more work than the walks are long; measured 14.4 vs 12.7 us per Stage-2 launch, profiles/r05_s_*.  Such a world
+    // walks, four lanes per robot, as before.)
+    if (n_need * 4 * (2 * e.edge_slots + 1) <= kEventOutlineTasks) {
+        const int Q = e.edge_slots, per_edge = 2 * Q + 1, per_robot = 4 * per_edge;
+        const int total = n_need * per_robot;
+        const float inv_per_robot = 1.0f / (float)per_robot, inv_per_edge = 1.0f / (float)per_edge;
+        for (int base = 0; base < total; base += kWave * kMoveWaves) {
+            const int task = base + tid;
+            const bool act = task < total;
+            // task / per_robot and rem / per_edge by float reciprocal + one correction step (all operands < 2^24)
+            int rq = act ? (int)((float)task * inv_per_robot) : 0;
+            rq -= (rq * per_robot > task) ? 1 : 0;
+            rq += ((rq + 1) * per_robot <= task && act) ? 1 : 0;
+            const int rem = act ? task - rq * per_robot : 0;
+            int k = (int)((float)rem * inv_per_edge);
+            k -= (k * per_edge > rem) ? 1 : 0;
+            k += ((k + 1) * per_edge <= rem) ? 1 : 0;
+            const int ev = rem - k * per_edge;
+            const int src = need_list[rq];
+            const float sx_ = __shfl(nx, src, kWave), sy_ = __shfl(ny, src, kWave);
+            const float ss_ = __shfl(ns, src, kWave), sc_ = __shfl(nc, src, kWave);
+            const int sy0 = __shfl(py0, src, kWave), sw0 = __shfl(pw0, src, kWave);
+            if (act) {
+                const MiniGrid mg{mini + src * psize, sy0, sw0, pwords};
+                if (static_edge_event_hits(mg, e.g, sx_, sy_, ss_, sc_, k, ev, Q)) hit_flag[src] = 1;
+            }
+        }
+    } else {
+        for (int base = 0; base < n_need; base += kWave * kMoveWaves / 4) {
+            const int q = base + (tid >> 2);
+            const bool act = q < n_need;
+            const int src = act ? need_list[q] : 0;
+            const float sx_ = __shfl(nx, src, kWave), sy_ = __shfl(ny, src, kWave);
+            const float ss_ = __shfl(ns, src, kWave), sc_ = __shfl(nc, src, kWave);
+            const int sy0 = __shfl(py0, src, kWave), sw0 = __shfl(pw0, src, kWave);
+            if (act) {
+                const MiniGrid mg{mini + src * psize, sy0, sw0, pwords};
+                if (static_edge_hit(mg, e.g, sx_, sy_, ss_, sc_, tid & 3)) hit_flag[src] = 1;
+            }
         }
     }
     // fidelity mode: the outline of every PROVISIONAL pose, four lanes per robot (one per edge: a walk of ~5 raster cells),

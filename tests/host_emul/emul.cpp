@@ -336,6 +336,28 @@ void emul_ray_box(int n, const float* ox, const float* oy, const float* dx, cons
     for (int i = 0; i < n; ++i) t[i] = ray_box(ox[i], oy[i], dx[i], dy[i], xj[i], yj[i], sj[i], cj[i]);
 }
 
+// the move kernel's outline test in both forms: grid_march with its early exit (the specification) and the OR over the walk's
+// independent crossing events (walk_event_hits: one lane per event on the device) -- out[i] = 4 bits per pose, one per edge
+int emul_outline_hits(const EmulEnv* e, int n, const float* x, const float* y, const float* th, int* out_march, int* out_events) {
+    const GridGeom g = geom(e);
+    const GlobalGrid occ{e->map_bits, e->width, e->height, e->wpr};
+    const int Q = edge_event_slots(g.inv_cell);
+    for (int i = 0; i < n; ++i) {
+        float s, c;
+        sincos_det(th[i], &s, &c);
+        int a = 0, b = 0;
+        for (int k = 0; k < 4; ++k) {
+            a |= (static_edge_hit(occ, g, x[i], y[i], s, c, k) ? 1 : 0) << k;
+            bool hit = false;
+            for (int q = 0; q <= 2 * Q; ++q) hit = static_edge_event_hits(occ, g, x[i], y[i], s, c, k, q, Q) || hit;
+            b |= (hit ? 1 : 0) << k;
+        }
+        out_march[i] = a;
+        out_events[i] = b;
+    }
+    return Q;
+}
+
 int emul_obb(float xi, float yi, float si, float ci, float xj, float yj, float sj, float cj) {
     return obb_overlap(xi, yi, si, ci, xj, yj, sj, cj) ? 1 : 0;
 }

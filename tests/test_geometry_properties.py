@@ -146,3 +146,45 @@ def test_norm_obs_equals_ieee_division():
     lib.emul_norm_obs(C.c_void_p(x.ctypes.data), C.c_int(x.size), C.c_void_p(got.ctypes.data))
     want = (x / np.float32(6.0) - np.float32(0.5)).astype(np.float32)
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_outline_edge_as_independent_crossing_events_equals_the_walk():
+    """move_kernel tests a footprint edge against its LDS patch with one lane per crossing EVENT of the walk (the start cell,
+    every x crossing, every y crossing: walk_event_hits) instead of one lane walking ~13 dependent steps; the oracle and the
+    specification (grid_march) walk.  Edge by edge the OR over the events must equal the walk's answer: on the shipped maps at
+    both cell sizes, on the circle world's 0.1 m map and on a synthetic map with boxes, for poses scattered over the map,
+    poses hugging occupied cells, headings along the raster and centres on raster lines."""
+    import ctypes as C
+    from util import S
+    maps = {"stage1": S.stage1(num_worlds=1, robots_per_world=4).grid, "stage2": S.stage2(num_worlds=1).grid,
+            "stage1 r0.2": S.stage1(num_worlds=1, robots_per_world=4, stage_resolution=True).grid,
+            "circle": S.circle(num_worlds=1).grid,
+            "boxes": U.small_grid(cell=0.1, size=16.0, ring_radius=7.0, blocks=[(-1.0, -1.0, 1.0, 0.5), (3.0, 2.0, 3.3, 2.2)]),
+            "fine": U.small_grid(cell=0.025, size=8.0, ring_radius=3.2, blocks=[(0.5, 0.5, 1.5, 1.0)])}
+    rng = np.random.default_rng(17)
+    for name, grid in maps.items():
+        sc = S.stage1(num_worlds=1, robots_per_world=4, grid=grid)
+        env = U.EmulEnv(sc)
+        env.lib.emul_outline_hits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        n = 60000
+        half = 0.5 * min(grid.width, grid.height) * grid.cell
+        x = rng.uniform(-half - 0.5, half + 0.5, n).astype(np.float32)
+        y = rng.uniform(-half - 0.5, half + 0.5, n).astype(np.float32)
+        th = rng.uniform(-np.pi, np.pi, n).astype(np.float32)
+        # a third of the poses next to occupied cells: centre within 0.45 m of a random occupied cell
+        occ = np.argwhere(grid.dense())
+        m = n // 3
+        pick = occ[rng.integers(0, len(occ), m)]
+        x[:m] = (grid.x0 + (pick[:, 1] + 0.5) * grid.cell + rng.uniform(-0.45, 0.45, m)).astype(np.float32)
+        y[:m] = (grid.y0 + (pick[:, 0] + 0.5) * grid.cell + rng.uniform(-0.45, 0.45, m)).astype(np.float32)
+        th[: n // 8] = rng.choice(np.array([0.0, np.pi / 2, -np.pi / 2, np.pi], np.float32), n // 8)     # edges along the raster
+        k = n // 6
+        x[m: m + k] = (np.round(x[m: m + k] / grid.cell) * grid.cell).astype(np.float32)                  # centres on raster lines
+        y[m + k // 2: m + k] = (np.round(y[m + k // 2: m + k] / grid.cell) * grid.cell).astype(np.float32)
+        a = np.zeros(n, np.int32)
+        b = np.zeros(n, np.int32)
+        Q = env.lib.emul_outline_hits(C.byref(env._st), n, x.ctypes.data, y.ctypes.data, th.ctypes.data, a.ctypes.data, b.ctypes.data)
+        assert Q == int(np.ceil(np.float32(0.44) * np.float32(1.0 / grid.cell))) + 1 or Q >= 3
+        bad = np.nonzero(a != b)[0]
+        assert bad.size == 0, (name, bad.size, x[bad[:3]], y[bad[:3]], th[bad[:3]], a[bad[:3]], b[bad[:3]])
+        assert 0.03 * n < (a != 0).sum() < 0.9 * n, name           # both outcomes occur
