@@ -226,6 +226,40 @@ def test_bench_schedule_leaves_the_world_where_the_c_oracle_leaves_it(hip, name,
     env.close()
 
 
+@pytest.mark.parametrize("chains", [1, 2])
+def test_step_many_inside_a_graph_capture(hip, chains):
+    """mrca_step_many is "capturable like any other call" (include/mrca_env.h): eight ticks of two world ranges captured into
+    one hipGraph from the caller's stream (the env's own streams join the capture through the stagger event and leave it through
+    the join), replayed three times -- the world must stand where the C oracle stands after the same 24 ticks."""
+    import bench
+    sc = S.stage1(num_worlds=6, robots_per_world=12, seed=17)
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    pool = bench.action_pool(sc.num_robots, env.device, 9, depth=8)
+    host_pool = [a.cpu().numpy() for a in pool]
+    env.reset()
+    ora.reset()
+    env.step_many(pool, 0, 8, chains)          # (creates the env's streams and events outside the capture)
+    for k in range(8):
+        ora.step(host_pool[k])
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        env.step_many(pool, 0, 8, chains)
+    torch.cuda.synchronize()
+    U.assert_state_equal(U.HostView(env), ora, what="a capture must not move the world")
+    for rep in range(3):
+        g.replay()
+        for k in range(8):
+            ora.step(host_pool[k])
+    torch.cuda.synchronize()
+    env.invalidate_views()
+    U.assert_state_equal(U.HostView(env), ora, what=f"three replays of a captured mrca_step_many, chains={chains}")
+    env.check()
+    env.close()
+
+
 def test_world_range_calls_leave_the_other_worlds_alone(hip):
     """mrca_step_worlds / mrca_move_worlds / mrca_observe_worlds: only the worlds of the range tick; a world stepped alone
     ends where the same world of a fully stepped env ends."""
