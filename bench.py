@@ -165,13 +165,24 @@ class TickSchedule:
         self.chains = max(1, min(int(chains), env.W))
         W, P = env.W, self.chains
         self.ranges = [(c * W // P, (c + 1) * W // P - c * W // P) for c in range(P)]
-        self.side = torch.cuda.Stream(device=env.device)
-        self.extra_streams = [torch.cuda.Stream(device=env.device) for _ in range(P - 1)]
+        self._side, self._extra = None, None       # streams of the graph / eager schedules, made when first needed
         self.graphs = {}
         self.sync_every_tick = os.environ.get("MRCA_CHAIN_SYNC", "first") == "every"
         # ticks per hipGraph: a graph forks into the chains at its head and joins them at its end, and the chains are set half
         # a tick apart once per graph -- the longer the graph, the less of a tick that is
         self.ticks_per_graph = int(os.environ.get("MRCA_TICKS_PER_GRAPH", "64"))
+
+    @property
+    def side(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.env.device)
+        return self._side
+
+    @property
+    def extra_streams(self):
+        if self._extra is None:
+            self._extra = [torch.cuda.Stream(device=self.env.device) for _ in range(self.chains - 1)]
+        return self._extra
 
     def chunks(self, first, count):
         """(start, length) pieces of ticks [first, first + count): at most `ticks_per_graph` ticks each (a graph may run round the

@@ -95,11 +95,36 @@ def test_the_gradient_bucket_of_the_policy_is_8_69_MB():
     assert fg.flat.numel() == 2172101 and fg.flat.dtype == torch.float32 and fg.flat.numel() * 4 == 8688404
 
 
+class _FakeEnv:
+    """what TickSchedule touches of an env when the native schedule runs: W, device, step_many"""
+    device = None
+
+    def __init__(self, W):
+        self.W, self.calls = W, []
+
+    def step_many(self, pool, first, count, chains):
+        self.calls.append((first, count, chains))
+
+
 def test_world_ranges_of_the_schedule_cover_every_world_once():
-    class _Env:
-        device = None
     for W in (1, 2, 5, 128, 187):
         for P in (1, 2, 3, 4, 8):
-            ranges = [(c * W // min(P, W), (c + 1) * W // min(P, W) - c * W // min(P, W)) for c in range(min(P, W))]
+            sched = bench.TickSchedule(_FakeEnv(W), list(range(16)), chains=P, native=True)
+            ranges = sched.ranges
+            assert sched.chains == min(P, W) == len(ranges)
             assert sum(n for _f, n in ranges) == W and ranges[0][0] == 0
             assert all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1)) and min(n for _f, n in ranges) >= 1
+
+
+def test_the_schedule_runs_exactly_the_ticks_it_is_asked_for():
+    """chunks(): pieces of at most ticks_per_graph ticks that tile [first, first + count) in order -- the timed region is EXACTLY
+    --steps ticks whatever the chunking -- and the native schedule hands each piece to ONE mrca_step_many call"""
+    for first, count in ((0, 5), (5, 20), (100, 1000), (0, 64), (63, 2), (7, 129), (0, 0)):
+        env = _FakeEnv(128)
+        sched = bench.TickSchedule(env, list(range(16)), chains=2, native=True)
+        pieces = list(sched.chunks(first, count))
+        assert sum(m for _k, m in pieces) == count and all(0 < m <= sched.ticks_per_graph for _k, m in pieces)
+        assert all(pieces[i][0] + pieces[i][1] == pieces[i + 1][0] for i in range(len(pieces) - 1))
+        assert not pieces or (pieces[0][0] == first and pieces[-1][0] + pieces[-1][1] == first + count)
+        sched.run(first, count)
+        assert env.calls == [(k, m, 2) for k, m in pieces]
