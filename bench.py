@@ -642,18 +642,22 @@ def main():
     # side figure (single GPU, env mode only, outside the timed region above): the same world driven by the
     # fp32 policy instead of the action pool -- SURVEY 8d (ii).  `--mode rollout|train` time these properly.
     if args.mode == "env" and world_size == 1 and not args.no_extra:
+        from mrca import gemm_tuning
         from mrca.trainer import make_bench_step
+        # (as `--mode rollout` does: the recorded kernel choice for the fc1 GEMM -- switched on here, behind the timed region)
+        recorded = (not args.no_gemm_choices) and gemm_tuning.use_recorded_choices()
         roll = make_bench_step(env, "rollout", None, fused=True, graph=True)
-        roll.run_ticks(10)
+        roll.run_ticks(16)
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
-        n_roll = 100
+        n_roll = 104
         roll.run_ticks(n_roll)
         torch.cuda.synchronize()
         extra["rollout_side_figure"] = {"value": N * n_roll / (time.perf_counter() - tr0), "unit": "agent-steps/s",
-                                        "note": "env + fp32 CNNPolicy inference per tick (HIP conv front end + batched "
-                                                "GEMMs, ticks replayed as hipGraphs of eight), 100 ticks after 10 warm-up ticks; not "
-                                                "part of `value`"}
+                                        "note": "env + fp32 CNNPolicy inference per tick (HIP conv front end, fc1 as a batched "
+                                                "GEMM -- " + ("recorded TunableOp choice" if recorded else "library default heuristic") +
+                                                " --, tail kernel; ticks replayed as hipGraphs of eight), 104 ticks after 16 "
+                                                "warm-up ticks; not part of `value`"}
 
     # Side figures of the OTHER configurations DESIGN.md / README quote (each a fresh env, a few hundred ticks after the timed
     # region, same schedule as `value`; a failure is reported in its place and never costs the run its line):

@@ -270,7 +270,8 @@ int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32
 /* The rest of the rollout inference behind fc1 in one kernel (model/net.py:41-55,61-70: ReLU, cat with goal and speed,
  * fc2 + ReLU of both towers, actor1 / actor2 / critic heads with sigmoid / tanh; model/ppo.py:57-82 generate_action:
  * a = mean + exp(logstd) * noise, log-density, clip to the action bounds).  fp32, exact-fp32 MFMA for fc2.
- *   h1_dev    f32[2,N,256]  act_fc1 / crt_fc1 outputs INCLUDING their bias, before the ReLU (tower-major)
+ *   h1_dev    f32[2,N,256]  act_fc1 / crt_fc1 outputs before the ReLU (tower-major)
+ *   fc1_b_dev f32[2,256]    act_fc1.bias, crt_fc1.bias: added while h1 is staged -- or NULL when h1 already includes them
  *   goal_dev  f32[N,2]  speed_dev f32[N,2]          MRCA_F_LOCAL_GOAL, MRCA_F_SPEED
  *   fc2_w_dev f32[2,260,128] (input-major: act_fc2.weight^T, crt_fc2.weight^T)   fc2_b_dev f32[2,128]
  *   head_w_dev f32[128,2] (columns actor1.weight, actor2.weight)  head_b_dev f32[2]  critic_w_dev f32[128]  critic_b_dev f32[1]
@@ -279,7 +280,7 @@ int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32
  *   lo_dev, hi_dev f32[2]   the action bounds (ppo_stage1.py:170)
  *   out: value_dev f32[N], action_dev f32[N,2] (UNclipped sample: what the rollout buffer stores), logprob_dev f32[N],
  *        scaled_dev f32[N,2] (clipped: what drives the robot), mean_dev f32[N,2] */
-int mrca_policy_tail(const float* h1_dev, const float* goal_dev, const float* speed_dev, int32_t n_robots,
+int mrca_policy_tail(const float* h1_dev, const float* fc1_b_dev, const float* goal_dev, const float* speed_dev, int32_t n_robots,
                      const float* fc2_w_dev, const float* fc2_b_dev, const float* head_w_dev, const float* head_b_dev,
                      const float* critic_w_dev, const float* critic_b_dev, const float* logstd_dev, const float* noise_dev,
                      const float* lo_dev, const float* hi_dev, float* value_dev, float* action_dev, float* logprob_dev,

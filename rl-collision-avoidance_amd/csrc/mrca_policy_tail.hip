@@ -5,7 +5,9 @@
 // robots (profiles/r02/r02_e_rollout_kernel_stats.csv); fc1 itself stays a library GEMM (137 TFLOP/s in hipBLASLt).
 //
 // One workgroup of 4 wavefronts owns 32 robots of ONE tower (blockIdx & 1): the robots' 260 inputs are staged in LDS
-// transposed (H[k][robot], ReLU applied on the way), wave q computes units [32q, 32q + 32) of fc2 as
+// transposed (H[k][robot]; fc1's bias -- when the GEMM left it out: a plain bmm instead of a baddbmm, whose broadcast of
+// the bias into its output is a 7 us copy of its own per tick -- and the ReLU applied on the way), wave q computes units
+// [32q, 32q + 32) of fc2 as
 //     C[32 units][32 robots] = W2^T[32 units][260] x H[260][32 robots]        130 x v_mfma_f32_32x32x2_f32 (exact fp32)
 // with the weights as A fragments in registers, then bias + ReLU, its share of the head dot products, a reduction over
 // the four waves through LDS, and lane = robot finishes: sigmoid / tanh, a = mean + exp(logstd) * noise, logprob, clip.
@@ -28,9 +30,9 @@ constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 __device__ __forceinline__ int rowmap(int reg, int hl) { return (reg & 3) + 8 * (reg >> 2) + 4 * hl; }
 
 __global__ __launch_bounds__(256) void policy_tail_kernel(
-    const float* __restrict__ h1, const float* __restrict__ goal, const float* __restrict__ speed, int n_robots,
-    const float* __restrict__ fc2_w, const float* __restrict__ fc2_b, const float* __restrict__ head_w,
-    const float* __restrict__ head_b, const float* __restrict__ critic_w, const float* __restrict__ critic_b,
+    const float* __restrict__ h1, const float* __restrict__ fc1_b, const float* __restrict__ goal,
+    const float* __restrict__ speed, int n_robots, const float* __restrict__ fc2_w, const float* __restrict__ fc2_b,
+    const float* __restrict__ head_w, const float* __restrict__ head_b, const float* __restrict__ critic_w, const float* __restrict__ critic_b,
     const float* __restrict__ logstd, const float* __restrict__ noise, const float* __restrict__ lo,
     const float* __restrict__ hi, float* __restrict__ value, float* __restrict__ action, float* __restrict__ logprob,
     float* __restrict__ scaled, float* __restrict__ mean_out) {
@@ -53,6 +55,9 @@ __global__ __launch_bounds__(256) void policy_tail_kernel(
     // their results are never stored)
     float4 hv[kTile * kFc1 / 4 / 256];                            // 8 float4 per thread
     const int last = n_robots - 1 - n0;
+    // (a thread stages the same four inputs of every robot row it touches: one bias quad)
+    const float4 bq = fc1_b ? *reinterpret_cast<const float4*>(fc1_b + tower * kFc1 + (tid & 63) * 4)
+                            : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
     for (int q = 0; q < kTile * kFc1 / 4 / 256; ++q) {
         const int idx = q * 256 + tid;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void policy_tail_kernel(
     for (int q = 0; q < kTile * kFc1 / 4 / 256; ++q) {
         const int idx = q * 256 + tid;
         const int j = idx >> 6, k4 = (idx & 63) * 4;
-        const float4 v = hv[q];
+        const float4 v = make_float4(hv[q].x + bq.x, hv[q].y + bq.y, hv[q].z + bq.z, hv[q].w + bq.w);
         H[(k4 + 0) * kHPitch + j] = v.x > 0.0f ? v.x : 0.0f;
         H[(k4 + 1) * kHPitch + j] = v.y > 0.0f ? v.y : 0.0f;
         H[(k4 + 2) * kHPitch + j] = v.z > 0.0f ? v.z : 0.0f;
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(256) void policy_tail_kernel(
 
 }  // namespace mrca_ptail
 
-extern "C" int mrca_policy_tail(const float* h1_dev, const float* goal_dev, const float* speed_dev, int32_t n_robots,
+extern "C" int mrca_policy_tail(const float* h1_dev, const float* fc1_b_dev, const float* goal_dev, const float* speed_dev,
+                                int32_t n_robots,
                                 const float* fc2_w_dev, const float* fc2_b_dev, const float* head_w_dev,
                                 const float* head_b_dev, const float* critic_w_dev, const float* critic_b_dev,
                                 const float* logstd_dev, const float* noise_dev, const float* lo_dev, const float* hi_dev,
@@ -170,8 +176,8 @@ extern "C" int mrca_policy_tail(const float* h1_dev, const float* goal_dev, cons
     if (n_robots < 1) return mrca::set_error(MRCA_ERR_INVALID, "mrca_policy_tail: n_robots %d", n_robots);
     mrca::DeviceGuard guard(mrca::device_of(h1_dev));
     const int tiles = (n_robots + kTile - 1) / kTile;
-    hipLaunchKernelGGL(policy_tail_kernel, dim3(2 * tiles), dim3(256), 0, static_cast<hipStream_t>(stream), h1_dev, goal_dev,
-                       speed_dev, n_robots, fc2_w_dev, fc2_b_dev, head_w_dev, head_b_dev, critic_w_dev, critic_b_dev,
+    hipLaunchKernelGGL(policy_tail_kernel, dim3(2 * tiles), dim3(256), 0, static_cast<hipStream_t>(stream), h1_dev, fc1_b_dev,
+                       goal_dev, speed_dev, n_robots, fc2_w_dev, fc2_b_dev, head_w_dev, head_b_dev, critic_w_dev, critic_b_dev,
                        logstd_dev, noise_dev, lo_dev, hi_dev, value_dev, action_dev, logprob_dev, scaled_dev, mean_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_policy_tail launch: %s", hipGetErrorString(e));

@@ -83,7 +83,7 @@ def load(path=None):
     lib.mrca_lidar_features_backward_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + \
         [C.c_size_t, C.c_void_p]
-    lib.mrca_policy_tail.argtypes = [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 16
+    lib.mrca_policy_tail.argtypes = [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 16
     lib.mrca_ppo_loss_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_ppo_loss.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4 + \
         [C.c_size_t, C.c_void_p]

@@ -75,9 +75,10 @@ def lidar_features(obs, w1, b1, w2, b2, out=None, head=None):
     return out
 
 
-def policy_tail(h1, goal, speed, fc2_w, fc2_b, head_w, head_b, critic_w, critic_b, logstd, noise, lo, hi):
+def policy_tail(h1, goal, speed, fc2_w, fc2_b, head_w, head_b, critic_w, critic_b, logstd, noise, lo, hi, fc1_b=None):
     """Everything of the rollout inference behind fc1 in one launch (include/mrca_env.h: mrca_policy_tail).
-    h1 f32[2,N,256] = fc1 outputs with bias, before the ReLU.  noise f32[N,2] or None (deterministic mean action).
+    h1 f32[2,N,256] = fc1 outputs before the ReLU -- with their bias, or without it and ``fc1_b`` f32[2,256] (any shape
+    of 512 elements) given: the kernel adds it while it stages h1.  noise f32[N,2] or None (deterministic mean action).
     -> value [N,1], action [N,2], logprob [N,1], scaled [N,2], mean [N,2]"""
     lib = _lib.load()
     N = h1.shape[1]
@@ -89,6 +90,9 @@ def policy_tail(h1, goal, speed, fc2_w, fc2_b, head_w, head_b, critic_w, critic_
             raise ValueError(f"policy_tail: expected a contiguous cuda float32 tensor of shape {shp}, got {tuple(t.shape)} {t.dtype}")
     if fc2_b.numel() != 256 or critic_w.numel() != 128 or critic_b.numel() != 1:
         raise ValueError("policy_tail: fc2_b / critic_w / critic_b sizes")
+    if fc1_b is not None and not (fc1_b.is_cuda and fc1_b.dtype == torch.float32 and fc1_b.is_contiguous() and fc1_b.numel() == 512
+                                  and fc1_b.device == dev):
+        raise ValueError("policy_tail: fc1_b must be a contiguous cuda float32 tensor of 2 x 256 elements on h1's device")
     value = torch.empty(N, 1, dtype=torch.float32, device=dev)
     action = torch.empty(N, 2, dtype=torch.float32, device=dev)
     logprob = torch.empty(N, 1, dtype=torch.float32, device=dev)
@@ -96,7 +100,7 @@ def policy_tail(h1, goal, speed, fc2_w, fc2_b, head_w, head_b, critic_w, critic_
     mean = torch.empty(N, 2, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.mrca_policy_tail(h1.data_ptr(), goal.data_ptr(), speed.data_ptr(), N, fc2_w.data_ptr(), fc2_b.data_ptr(),
+        _lib.check(lib.mrca_policy_tail(h1.data_ptr(), None if fc1_b is None else fc1_b.data_ptr(), goal.data_ptr(), speed.data_ptr(), N, fc2_w.data_ptr(), fc2_b.data_ptr(),
                                         head_w.data_ptr(), head_b.data_ptr(), critic_w.data_ptr(), critic_b.data_ptr(),
                                         logstd.data_ptr(), None if noise is None else noise.data_ptr(), lo.data_ptr(),
                                         hi.data_ptr(), value.data_ptr(), action.data_ptr(), logprob.data_ptr(),

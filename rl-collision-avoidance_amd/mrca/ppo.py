@@ -24,18 +24,21 @@ def _bounds(action_bound, device, dtype):
 
 # ---------------------------------------------------------------------------------------------
 def generate_action(policy, obs, goal, speed, action_bound, generator=None, autocast_dtype=None, fused=False,
-                    obs_head=None):
+                    obs_head=None, noise=None):
     """model/ppo.py:57-82: sample a ~ N(mean, std); the UNclipped action and its logprob are what
     the buffer stores, the clipped one drives the robot.  ``fused=True`` evaluates the policy through its fp32
     rollout path (HIP conv front end + batched GEMMs, net.CNNPolicy.mean_value_fused; same numbers to 1e-5);
     ``autocast_dtype=torch.bfloat16`` runs the stock towers on the bf16 MFMA path (opt-in).  ``obs_head`` (fused
-    only): ``obs`` is the env's frame ring, see ``policy_input``."""
+    only): ``obs`` is the env's frame ring, see ``policy_input``.  ``noise`` f32[N,2]: standard normal draws made by the
+    caller (a rollout replayed as a hipGraph of several ticks draws all of them in one launch) instead of a ``randn``
+    here."""
     from .net import gaussian_logprob
     if obs_head is not None and not fused:
         raise ValueError("a frame ring (obs_head) can only be read by the fused policy path")
     if fused and hasattr(policy, "act_fused"):
         lo, hi = _bounds(action_bound, goal.device, torch.float32)
-        noise = torch.randn((goal.shape[0], 2), device=goal.device, dtype=torch.float32, generator=generator)
+        if noise is None:
+            noise = torch.randn((goal.shape[0], 2), device=goal.device, dtype=torch.float32, generator=generator)
         v, a, logprob, scaled, _mean = policy.act_fused(obs, goal, speed, noise, lo, hi, head=obs_head)
         return v, a, logprob, scaled
     with torch.no_grad():
@@ -48,7 +51,8 @@ def generate_action(policy, obs, goal, speed, action_bound, generator=None, auto
         else:
             mean, v = policy.mean_value(obs, goal, speed)
         logstd = policy.logstd.expand_as(mean)
-        noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        if noise is None:
+            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
         a = mean + torch.exp(logstd) * noise
         logprob = gaussian_logprob(a, mean, logstd)
         lo, hi = _bounds(action_bound, a.device, a.dtype)

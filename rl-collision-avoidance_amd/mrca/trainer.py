@@ -215,10 +215,10 @@ def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, upd
         if fused:
             tr.policy.refresh_rollout_cache()
 
-        def body():
+        def body(noise=None):
             obs, head = ppo.policy_input(env, hp.rollout_fused)
-            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, obs, env.local_goal, env.speed,
-                                                      hp.action_bound, tr.gen, hp.inference_dtype, hp.rollout_fused, head)
+            _v, _a, _lp, scaled = ppo.generate_action(tr.policy, obs, env.local_goal, env.speed, hp.action_bound, tr.gen,
+                                                      hp.inference_dtype, hp.rollout_fused, head, noise=noise)
             env.step(scaled.contiguous())
         env.enable_timing(False)
         side = torch.cuda.Stream(device=env.device)
@@ -230,12 +230,15 @@ def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, upd
         # one graph of ONE tick and one of EIGHT: a replay has a start-up of its own (a few us the eager path hides behind
         # the previous tick's kernels: 265 vs 256 us per tick with one tick per replay, profiles/r04_v_bench_rollout*.json),
         # so a run of n ticks replays the long graph n // 8 times and the short one for the remainder
+        # the sampling noise of all the ticks of a replay is drawn by ONE launch at its head (a randn of 8192 numbers is a
+        # 5 us launch of its own in a 250 us tick; the draws are the generator's next ticks x N x 2 normals either way)
         def capture(ticks):
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(tr.gen)
             with torch.cuda.graph(g, stream=side):
-                for _ in range(ticks):
-                    body()
+                noise = torch.randn((ticks, env.N, 2), device=env.device, dtype=torch.float32, generator=tr.gen)
+                for i in range(ticks):
+                    body(noise[i])
             return g
         g1, g8 = capture(1), capture(8)
 

@@ -217,3 +217,25 @@ def test_act_fused_equals_the_stock_generate_action(pol, n):
     with torch.no_grad():
         pol.logstd.zero_()
     pol.refresh_rollout_cache()
+
+
+@pytest.mark.parametrize("n", [1, 33, 4096])
+def test_policy_tail_adds_the_fc1_bias_itself(pol, n):
+    """mrca_policy_tail(h1 without bias, fc1_b) == mrca_policy_tail(h1 + bias, NULL), every output, bit for bit: the kernel
+    adds the bias to the fp32 value the GEMM stored, which is what the separate add does."""
+    from mrca import policy_ops
+    g = torch.Generator(device="cuda").manual_seed(100 + n)
+    rc = pol.refresh_rollout_cache()
+    h1 = torch.randn(2, n, 256, device="cuda", generator=g)
+    goal = torch.rand(n, 2, device="cuda", generator=g) * 20 - 10
+    speed = torch.rand(n, 2, device="cuda", generator=g)
+    noise = torch.randn(n, 2, device="cuda", generator=g)
+    lo, hi = torch.tensor([0.0, -1.0], device="cuda"), torch.tensor([1.0, 1.0], device="cuda")
+    rest = (goal, speed, rc["fc2_w"], rc["fc2_b"], rc["head_w"], rc["head_b"], rc["critic_w"], rc["critic_b"], rc["logstd"], noise, lo, hi)
+    assert float(rc["fc1_b"].abs().min()) >= 0.0 and float(rc["fc1_b"].abs().max()) > 0.01
+    with_bias = policy_ops.policy_tail((h1 + rc["fc1_b"]).contiguous(), *rest)
+    in_kernel = policy_ops.policy_tail(h1, *rest, fc1_b=rc["fc1_b"])
+    for a, b in zip(with_bias, in_kernel):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        policy_ops.policy_tail(h1, *rest, fc1_b=rc["fc1_b"][:, :, :128].contiguous())
