@@ -319,6 +319,16 @@ int mrca_ppo_loss(const float* mean_dev, const float* value_dev, const float* lo
                   float value_coef, float coeff_entropy, float* out_dev, float* gmean_dev, float* gvalue_dev,
                   void* scratch_dev, size_t scratch_bytes, void* stream);
 
+/* One optimiser step of the PPO update on flat buffers, one launch: torch.optim.Adam's rule (ppo_stage1.py:176 Adam(lr);
+ * one step per minibatch, model/ppo.py:187-189) with no weight decay and no amsgrad --
+ *     m <- m + (g - m)(1 - beta1),  v <- v beta2 + (1 - beta2) g g,
+ *     p <- p - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * in fp32, the bias corrections formed in double.
+ *   param_dev, exp_avg_dev, exp_avg_sq_dev  f32[n]  updated in place;  grad_dev f32[n];  all four 16-byte aligned
+ *   step  the number of THIS step, starting at 1 */
+int mrca_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
+                   double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
+
 #ifdef MRCA_PROFILING
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product
  * library neither exports this symbol nor contains the switches.  Results are WRONG while any of bits 0-5 is

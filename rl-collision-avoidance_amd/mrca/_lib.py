@@ -24,7 +24,7 @@ EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_crea
            "mrca_step", "mrca_step_slice", "mrca_step_worlds", "mrca_move_worlds", "mrca_observe_worlds", "mrca_step_many", "mrca_materialize", "mrca_newest_obs", "mrca_sparse_obs", "mrca_normalize_scans", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
            "mrca_event_pair_overhead",
            "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
-           "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch"]
+           "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch", "mrca_adam_step"]
 
 
 class MrcaConfig(C.Structure):
@@ -87,6 +87,7 @@ def load(path=None):
     lib.mrca_ppo_loss_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_ppo_loss.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4 + \
         [C.c_size_t, C.c_void_p]
+    lib.mrca_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 4 + [C.c_int32, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only
         lib.mrca_set_debug_flags.argtypes = [C.c_void_p, C.c_int32]

@@ -235,3 +235,19 @@ def ppo_loss(mean, value, logstd, action, old_logprob, adv, target, clip_value, 
     """-> (loss, stats): ``loss`` differentiable with respect to mean [n,2], value [n,1] and logstd [2]; ``stats`` f32[8] =
     loss, policy loss, value loss, entropy, k3 KL(old || new), dloss/dlogstd[0], dloss/dlogstd[1], 0."""
     return _PPOLoss.apply(mean, value, logstd, action, old_logprob, adv, target, clip_value, value_coef, coeff_entropy)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """One Adam step on flat CUDA buffers in ONE launch (include/mrca_env.h: mrca_adam_step; torch.optim.Adam's rule, no
+    weight decay, no amsgrad).  ``param``, ``exp_avg``, ``exp_avg_sq`` are updated in place; ``step`` counts from 1."""
+    lib = _lib.load()
+    n = param.numel()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 1 and t.numel() == n
+                and t.device == param.device):
+            raise ValueError(f"adam_step: expected four flat contiguous cuda float32 tensors of {n} elements on one device, "
+                             f"got {tuple(t.shape)} {t.dtype} {t.device}")
+    with torch.cuda.device(param.device):
+        stream = C.c_void_p(torch.cuda.current_stream(param.device).cuda_stream)
+        _lib.check(lib.mrca_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                                      float(lr), float(beta1), float(beta2), float(eps), int(step), stream), "mrca_adam_step")

@@ -4,6 +4,8 @@ Same names and argument meaning as the reference's ``model/ppo.py`` so the call 
 but every tensor lives on the GPU (no pickling, no host round trips) and the update optionally
 all-reduces gradients over RCCL (one flat bucket) for data parallelism over robots.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -246,10 +248,111 @@ class FlatGrads:
     def zero(self):
         self.flat.zero_()
 
+    def backward(self, loss):
+        """d loss / d parameters straight into the bucket: ``torch.autograd.grad`` and ONE cat launch.  (``loss.backward()``
+        into ``.grad`` tensors that are views of the bucket is a zero-fill plus one AccumulateGrad add launch per parameter
+        tensor -- 22 adds of ~5 us per minibatch, 3 % of an update, profiles/r05_z_train_kernel_stats.csv.)  The ``.grad``
+        views keep showing the bucket, i.e. the new gradients."""
+        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        torch.cat([(torch.zeros_like(p) if g is None else g).reshape(-1) for g, p in zip(grads, self.params)], out=self.flat)
+
     def all_reduce_mean(self, dist):
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat)
             self.flat.div_(dist.get_world_size())
+
+
+class FlatAdam:
+    """``torch.optim.Adam(params, lr)`` (the reference's optimiser, ppo_stage1.py:176: betas 0.9 / 0.999, eps 1e-8, no weight
+    decay, no amsgrad) for parameters whose gradients live in a ``FlatGrads`` bucket: the parameters are re-seated as views
+    of ONE buffer laid out like the bucket, the two moment estimates are flat as well, and a step is one element-wise pass
+    -- on the GPU one launch of csrc/mrca_adam.hip (PyTorch's fused multi-tensor step walks the tensor list on 34
+    workgroups: 102 us per step against 61 MB of traffic), on the CPU the same expressions as five torch calls.
+
+    The parts of the ``torch.optim.Optimizer`` surface the learner uses: ``param_groups`` (one group; the KL controller
+    and ``--lr`` write its ``"lr"``), ``step()``, ``zero_grad()``, ``state_dict()`` / ``load_state_dict()`` -- both in
+    ``torch.optim.Adam``'s own format, so optimiser states saved by either load into the other."""
+
+    def __init__(self, flat_grads, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.grads = flat_grads
+        self.params = flat_grads.params
+        self.flat = torch.empty_like(flat_grads.flat)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                view = self.flat[off: off + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view                       # same values, new storage: the parameter IS this slice from now on
+                off += p.numel()
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.steps = 0
+        self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False,
+                              "params": self.params}]
+
+    def _check_seating(self):
+        off = 0
+        for p in self.params:
+            if p.data_ptr() != self.flat.data_ptr() + 4 * off or p.device != self.flat.device:
+                raise RuntimeError("FlatAdam: a parameter no longer lives in the optimiser's buffer (the module was moved "
+                                   "or re-created after the optimiser was built): build the optimiser last")
+            off += p.numel()
+
+    def zero_grad(self, set_to_none=False):
+        self.grads.zero()
+
+    @torch.no_grad()
+    def step(self):
+        g = self.param_groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False):
+            raise NotImplementedError("FlatAdam: weight decay / amsgrad are not part of the reference's optimiser")
+        self._check_seating()
+        self.steps += 1
+        (b1, b2), lr, eps, t = g["betas"], g["lr"], g["eps"], self.steps
+        p, grad, m, v = self.flat, self.grads.flat, self.exp_avg, self.exp_avg_sq
+        if p.is_cuda:
+            from . import policy_ops
+            policy_ops.adam_step(p, grad, m, v, lr, b1, b2, eps, t)
+            return
+        # torch/optim/adam.py, _single_tensor_adam, expression for expression
+        m.lerp_(grad, 1 - b1)
+        v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+        p.addcdiv_(m, denom, value=-(lr / (1 - b1 ** t)))
+
+    def state_dict(self):
+        state, off = {}, 0
+        for i, p in enumerate(self.params):
+            sl = slice(off, off + p.numel())
+            if self.steps:
+                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.exp_avg[sl].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
+            off += p.numel()
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group.update({"maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                      "decoupled_weight_decay": False, "params": list(range(len(self.params)))})
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FlatAdam.load_state_dict: expected one parameter group of %d tensors" % len(self.params))
+        for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+            if k in groups[0]:
+                self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
+        state, off, steps = sd["state"], 0, set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, p in enumerate(self.params):
+            st = state.get(i, state.get(str(i)))
+            if st is not None:
+                self.exp_avg[off: off + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off: off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            off += p.numel()
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdam.load_state_dict: the tensors are at different steps {sorted(steps)}")
+        self.steps = steps.pop() if steps else 0
 
 
 def _global_mean_std(x, dist):
@@ -307,6 +410,48 @@ class KLAdaptiveLR:
         return kl
 
 
+_side_streams = {}
+
+
+class _ObsPrefetch:
+    """The observation stacks of minibatch k + 1 gathered on a side stream while minibatch k computes.  The gather is the
+    one memory-bound step of a minibatch (three 2 kB frame rows per sample: 100 MB read and written for 16 384 rows, 90 us,
+    profiles/r05_z_train_kernel_stats.csv) between MFMA-bound ones, and depends on nothing the minibatch before it
+    produces.  Same kernels, same values: only where they run.  On the CPU: a plain ``obss[index]``."""
+
+    def __init__(self, obss, batches):
+        self.obss, self.batches = obss, batches
+        dev = batches[0].device if len(batches) else None
+        self.on = dev is not None and dev.type == "cuda"
+        self.ready = {}
+        if self.on:
+            self.main = torch.cuda.current_stream(dev)
+            key = (dev.index, )
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device=dev)
+            self.side = _side_streams[key]
+            self._issue(0)
+
+    def _issue(self, k):
+        if k >= len(self.batches) or k in self.ready:
+            return
+        # behind everything the main stream holds so far (the permutation, the buffer, the minibatch before the one that
+        # is about to start): the gather runs NEXT TO that minibatch, and the host cannot queue gathers without bound
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            self.ready[k] = self.obss[self.batches[k]]
+
+    def take(self, k):
+        if not self.on:
+            return self.obss[self.batches[k]]
+        self._issue(k)                               # (only if a caller skipped ahead)
+        x = self.ready.pop(k)
+        self.main.wait_stream(self.side)
+        x.record_stream(self.main)                   # allocated on the side stream, consumed on the main one
+        self._issue(k + 1)
+        return x
+
+
 def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, drop_last, value_coef,
                 index_batches, dist, flat_grads, log, autocast_dtype=None, kl_ctl=None, max_grad_norm=0.0,
                 logstd_min=None):
@@ -343,7 +488,9 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
             batches = batches[:int(s.item())]
         kl_sum = torch.zeros((), device=advs.device)
         n_done, stop = 0, False
+        fetch = _ObsPrefetch(obss, batches)
         for k, index in enumerate(batches):
+            mb_obs = fetch.take(k)
             if rows is None:
                 mb_goal, mb_speed, mb_action, mb_logprob, mb_target, adv = (x[index] for x in small)
             else:
@@ -351,13 +498,13 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
                 mb_goal, mb_speed, mb_action, mb_logprob, mb_target, adv = (x[lo_:hi_] for x in rows)
             if fused_loss:
                 from . import policy_ops
-                mean, new_value = policy.mean_value(obss[index], mb_goal, mb_speed)
+                mean, new_value = policy.mean_value(mb_obs, mb_goal, mb_speed)
                 loss, stats = policy_ops.ppo_loss(mean, new_value, policy.logstd, mb_action, mb_logprob, adv, mb_target,
                                                   clip_value, value_coef, coeff_entropy)
                 policy_loss, value_loss, dist_entropy, kl_mb = stats[1], stats[2], stats[3], stats[4]
             else:
                 with torch.autocast(advs.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
-                    new_value, new_logprob, dist_entropy = policy.evaluate_actions(obss[index], mb_goal, mb_speed, mb_action)
+                    new_value, new_logprob, dist_entropy = policy.evaluate_actions(mb_obs, mb_goal, mb_speed, mb_action)
                 new_value, new_logprob = new_value.float(), new_logprob.float()
                 log_ratio = new_logprob - mb_logprob
                 ratio = torch.exp(log_ratio)
@@ -368,12 +515,11 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
                 loss = policy_loss + value_coef * value_loss - coeff_entropy * dist_entropy
                 kl_mb = None
             if flat_grads is not None:
-                flat_grads.zero()
+                flat_grads.backward(loss)
+                flat_grads.all_reduce_mean(dist)
             else:
                 optimizer.zero_grad()
-            loss.backward()
-            if flat_grads is not None:
-                flat_grads.all_reduce_mean(dist)
+                loss.backward()
             if max_grad_norm > 0:       # opt-in (not in the reference): global-norm clipping of the (averaged) gradient
                 if flat_grads is not None:
                     flat_grads.flat.mul_(torch.clamp(max_grad_norm / (flat_grads.flat.norm() + 1e-6), max=1.0))

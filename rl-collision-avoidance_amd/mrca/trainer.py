@@ -60,6 +60,8 @@ def broadcast_parameters(module, dist):
 
 
 class Stage1Trainer:
+    GRAPH_RUN = 8       # ticks per replay of the long graph of ``run`` (hp.graph_tick)
+
     def __init__(self, env, policy=None, hp=None, dist=None, seed=0, stage2=False):
         self.env, self.dist, self.stage2 = env, dist, stage2
         self.hp = hp or HParams()
@@ -71,11 +73,15 @@ class Stage1Trainer:
         if self.hp.update_fused:
             self.policy.fused_train = True
         broadcast_parameters(self.policy, dist)
-        # the reference's optimiser (ppo_stage1.py:176: Adam, lr 5e-5); on the GPU as ONE multi-tensor launch per step
-        # (fused=True: the same update rule; the default "foreach" form is a dozen launches per step)
-        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate,
-                                          **({"fused": True} if dev.type == "cuda" else {}))
+        # the reference's optimiser (ppo_stage1.py:176: Adam, lr 5e-5).  On the GPU the parameters, their gradients and the
+        # moment estimates are flat buffers and a step is ONE element-wise launch (ppo.FlatAdam, csrc/mrca_adam.hip;
+        # PyTorch's fused multi-tensor step is 102 us on 34 workgroups, its default "foreach" form a dozen launches); on the
+        # CPU torch.optim.Adam itself.  Built LAST: it re-seats the parameters (after .to(dev) and the broadcast).
         self.flat_grads = ppo.FlatGrads(self.policy.parameters())
+        if dev.type == "cuda":
+            self.optimizer = ppo.FlatAdam(self.flat_grads, lr=self.hp.learning_rate)
+        else:
+            self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=self.hp.learning_rate)
         self.kl_ctl = ppo.KLAdaptiveLR(self.hp.kl_target, lr_max=self.hp.lr_max, stop_factor=self.hp.kl_stop) \
             if self.hp.kl_target > 0 else None
         self.buffer = ppo.RolloutBuffer(self.hp.horizon, env.N, self.hp.laser_hist, self.hp.obs_size, dev,
@@ -88,19 +94,21 @@ class Stage1Trainer:
         self.loss_log = []
         self.started = False
         self._graph = None
+        self._graph_run = None
         self._t_idx = torch.zeros(1, dtype=torch.int64, device=dev)     # buffer row of the next tick, on the device
 
     def start(self):
         self.env.reset()
         self.started = True
 
-    def _tick_body(self):
+    def _tick_body(self, noise=None):
         """The device work of one tick with the buffer row taken from ``self._t_idx`` (a device tensor): nothing in
-        here depends on a host value, so it can be captured as a hipGraph."""
+        here depends on a host value, so it can be captured as a hipGraph.  ``noise``: this tick's sampling draws when
+        the caller made them (a replay of several ticks draws all of them in one launch)."""
         env, hp, buf = self.env, self.hp, self.buffer
         obs, head = ppo.policy_input(env, hp.rollout_fused)
-        v, a, logprob, scaled = ppo.generate_action(self.policy, obs, env.local_goal, env.speed,
-                                                    hp.action_bound, self.gen, hp.inference_dtype, hp.rollout_fused, head)
+        v, a, logprob, scaled = ppo.generate_action(self.policy, obs, env.local_goal, env.speed, hp.action_bound, self.gen,
+                                                    hp.inference_dtype, hp.rollout_fused, head, noise=noise)
         so, sn = self._stored_obs()
         buf.store_state_at(self._t_idx, so, env.local_goal, env.speed, a, logprob, v, env.fresh, newest=sn)
         env.step(scaled.contiguous())
@@ -138,6 +146,17 @@ class Stage1Trainer:
         with torch.cuda.graph(g, stream=side):
             self._tick_body()
         self._graph = g
+        # ... and EIGHT ticks as one graph for ``run``: a replay has a start-up of its own (a few us the eager path hides
+        # behind the previous tick's kernels) and the eight ticks' sampling noise is one launch instead of eight
+        if self.hp.horizon >= self.GRAPH_RUN:
+            g8 = torch.cuda.CUDAGraph()
+            g8.register_generator_state(self.gen)
+            with torch.cuda.graph(g8, stream=side):
+                noise = torch.randn((self.GRAPH_RUN, self.env.N, 2), device=self.env.device, dtype=torch.float32,
+                                    generator=self.gen)
+                for i in range(self.GRAPH_RUN):
+                    self._tick_body(noise[i])
+            self._graph_run = g8
 
     def tick(self):
         """One pass of the while-loop body of ppo_stage1.py:64-118 for all robots."""
@@ -199,8 +218,27 @@ class Stage1Trainer:
     def run(self, ticks):
         if not self.started:
             self.start()
-        for _ in range(ticks):
-            self.tick()
+        env, hp = self.env, self.hp
+        while ticks > 0:
+            if hp.graph_tick and self._graph is None:
+                self._capture()
+            n = self.GRAPH_RUN
+            if hp.graph_tick and self._graph_run is not None and ticks >= n and hp.horizon - self.t >= n:
+                # eight ticks in one replay (never across the end of a horizon: the update runs between two replays)
+                if self.t == 0:
+                    self.buffer.begin_horizon(env.obs)
+                self._graph_run.replay()
+                if hasattr(env, "invalidate_views"):
+                    env.invalidate_views()
+                self.t += n
+                ticks -= n
+                if self.t == hp.horizon:
+                    self.update()
+                    self.t = 0
+                    self._t_idx.zero_()
+            else:
+                self.tick()
+                ticks -= 1
 
 
 def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, update_dtype=None, fused=False,
@@ -262,4 +300,5 @@ def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, upd
 
     def train_fn(_k):
         tr.tick()
+    train_fn.run_ticks = tr.run          # (with the rollout's ticks as hipGraphs: eight ticks per replay where they fit)
     return train_fn

@@ -104,22 +104,28 @@ def test_train_cli_checkpoint_and_resume(hip, tmp_path, monkeypatch):
     assert os.path.exists(tmp_path / "policy" / "Stage1_3")      # global_update continued from 2
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_graph_captured_tick_fills_the_buffer_consistently(hip, fused):
+@pytest.mark.parametrize("fused,via_run", [(False, False), (True, False), (True, True)])
+def test_graph_captured_tick_fills_the_buffer_consistently(hip, fused, via_run):
     """The rollout tick replayed as a hipGraph (device-side buffer row, registered noise generator): every stored row
     must be self-consistent -- the stored log-probability is the policy's density of the stored action at the stored
-    state, the stored value its value -- and rows, rewards and done flags must line up with the env's own fields."""
+    state, the stored value its value -- and rows, rewards and done flags must line up with the env's own fields.
+    ``via_run``: through ``Stage1Trainer.run`` -- one replay of the eight-tick graph (its noise drawn in one launch) and
+    three of the one-tick graph."""
     from mrca.trainer import HParams, Stage1Trainer
     sc = S.stage1(num_worlds=4, robots_per_world=8, seed=5)
     env = hip.VecStageWorld(sc)
     hp = HParams(horizon=12, batch_size=128, epoch=1, graph_tick=True, rollout_fused=fused)
     tr = Stage1Trainer(env, hp=hp, seed=2)
     tr.start()
-    for _ in range(11):
-        tr.tick()
+    if via_run:
+        tr.run(11)
+        assert tr._graph_run is not None
+    else:
+        for _ in range(11):
+            tr.tick()
     torch.cuda.synchronize()
     buf = tr.buffer
-    assert tr.global_update == 0 and int(tr._t_idx) == 11
+    assert tr.global_update == 0 and int(tr._t_idx) == 11 and tr.t == 11
     stacks = buf.obs_rows().materialise()
     with torch.no_grad():
         for t in range(11):
