@@ -329,6 +329,37 @@ int mrca_ppo_loss(const float* mean_dev, const float* value_dev, const float* lo
 int mrca_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
                    double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
 
+/* The learner's rollout buffer, written by the library: what the reference appends to `buff` every step and turns into arrays
+ * before the update (ppo_stage1.py:102-103; model/ppo.py:22-54 transform_buffer), kept on the device with ONE lidar frame per
+ * tick (the stack at tick t shares F - 1 frames with the stack at t - 1) plus, per tick and robot, the rows of `frames` that
+ * make up its stack (a robot that restarted: F times its fresh scan, ppo_stage1.py:59-60).  All pointers are device memory of
+ * the caller (mrca/ppo.py RolloutBuffer); T = horizon, N / F / B = the env's robots / frames / beams. */
+typedef struct mrca_rollout_rows {
+    float* frames;     /* f32[T + F - 1][N][B]   rows 0 .. F-2: the older frames of the first tick's stacks (the caller's) */
+    int64_t* fidx;     /* i64[T][N][F]           rows of `frames` that are the stack of (tick, robot), oldest first */
+    int64_t* cur;      /* i64[N][F]              the same for the tick being stored (carried from tick to tick) */
+    float* goal;       /* f32[T][N][2]  MRCA_F_LOCAL_GOAL */
+    float* speed;      /* f32[T][N][2]  MRCA_F_SPEED */
+    float* action;     /* f32[T][N][2]  the UNclipped sample (model/ppo.py:75) */
+    float* logprob;    /* f32[T][N] */
+    float* value;      /* f32[T][N] */
+    float* reward;     /* f32[T][N] */
+    uint8_t* done;     /* u8[T][N] */
+    int32_t horizon;   /* T */
+} mrca_rollout_rows;
+
+/* Row *tick_dev of the buffer BEFORE the env steps, one launch: the newest observation frame x / 6 - 0.5 from the env's scan
+ * ring into frames[t + F - 1], the stack's row indices (tick 0: rows 0 .. F-1), the env's local goal and speed, and the
+ * policy's action_dev f32[N,2] / logprob_dev f32[N] / value_dev f32[N].  The row comes from DEVICE memory (int64[1]): no host
+ * value enters the launch, a captured tick replays for every row of the horizon.  A counter outside [0, T) stores nothing and
+ * sets a sticky status bit (mrca_check). */
+int mrca_rollout_store_state(mrca_env* env, const mrca_rollout_rows* rows, const int64_t* tick_dev, const float* action_dev,
+                             const float* logprob_dev, const float* value_dev, void* stream);
+/* ... and AFTER the env stepped, one launch: MRCA_F_REWARD / MRCA_F_DONE into row *tick_dev, then *tick_dev += 1 (by the last
+ * workgroup to finish).  ticket_dev: uint32[1] of the caller, zero before the first call (every call leaves it at zero). */
+int mrca_rollout_store_outcome(mrca_env* env, const mrca_rollout_rows* rows, int64_t* tick_dev, uint32_t* ticket_dev,
+                               void* stream);
+
 #ifdef MRCA_PROFILING
 /* PROFILING BUILD ONLY (csrc/build.sh --profiling -> libmrca_env_prof.so, used by tools/ablate.py); the product
  * library neither exports this symbol nor contains the switches.  Results are WRONG while any of bits 0-5 is

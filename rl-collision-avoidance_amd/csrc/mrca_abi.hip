@@ -15,6 +15,7 @@
 #include "mrca_host.h"
 #include "mrca_hostutil.h"
 #include "mrca_kernels.h"
+#include "mrca_rollout_store.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -676,10 +677,50 @@ int mrca_check(mrca_env* env, void* stream) {
         return fail(MRCA_ERR_HIP, "fidelity mode: a cell of a robot's outline fell outside the 8 x 8 window of its bitmap since the "
                                   "last check (coordinates beyond the supported range?); collisions and lidar returns of that "
                                   "robot are not to be trusted");
+    if (bits & mrca::kStatusBadRolloutRow)
+        return fail(MRCA_ERR_INVALID, "mrca_rollout_store_*: the device-side tick counter was outside [0, horizon) since the last "
+                                      "check (that launch stored nothing)");
     if (bits & mrca::kStatusBadBeamIndex)
         return fail(MRCA_ERR_INVALID, "mrca_sparse_obs: the beam table held an index outside [0, beams) since the last check "
                                       "(clamped to the nearest beam)");
     return fail(MRCA_ERR_HIP, "device status word 0x%x", bits);
+}
+
+static int check_rows(const mrca_rollout_rows* r) {
+    if (!r) return fail(MRCA_ERR_INVALID, "rows is NULL");
+    if (!r->frames || !r->fidx || !r->cur || !r->goal || !r->speed || !r->action || !r->logprob || !r->value || !r->reward ||
+        !r->done)
+        return fail(MRCA_ERR_INVALID, "mrca_rollout_rows: NULL pointer");
+    if (r->horizon < 1) return fail(MRCA_ERR_INVALID, "mrca_rollout_rows: horizon %d", r->horizon);
+    if ((reinterpret_cast<uintptr_t>(r->frames) % 16) || (reinterpret_cast<uintptr_t>(r->goal) % 8) ||
+        (reinterpret_cast<uintptr_t>(r->speed) % 8) || (reinterpret_cast<uintptr_t>(r->action) % 8))
+        return fail(MRCA_ERR_INVALID, "mrca_rollout_rows: frames must be 16-byte, goal / speed / action 8-byte aligned");
+    return MRCA_OK;
+}
+
+int mrca_rollout_store_state(mrca_env* env, const mrca_rollout_rows* rows, const int64_t* tick_dev, const float* action_dev,
+                             const float* logprob_dev, const float* value_dev, void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (int rc = check_rows(rows)) return rc;
+    if (!tick_dev || !action_dev || !logprob_dev || !value_dev)
+        return fail(MRCA_ERR_INVALID, "mrca_rollout_store_state: NULL pointer");
+    if (reinterpret_cast<uintptr_t>(action_dev) % 8)
+        return fail(MRCA_ERR_INVALID, "mrca_rollout_store_state: action_dev must be 8-byte aligned");
+    DeviceGuard guard(env->cfg.device);
+    mrca::launch_rollout_store_state(env->view, *rows, tick_dev, action_dev, logprob_dev, value_dev, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
+int mrca_rollout_store_outcome(mrca_env* env, const mrca_rollout_rows* rows, int64_t* tick_dev, uint32_t* ticket_dev,
+                               void* stream) {
+    if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
+    if (int rc = check_rows(rows)) return rc;
+    if (!tick_dev || !ticket_dev) return fail(MRCA_ERR_INVALID, "mrca_rollout_store_outcome: NULL pointer");
+    DeviceGuard guard(env->cfg.device);
+    mrca::launch_rollout_store_outcome(env->view, *rows, tick_dev, ticket_dev, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
 }
 
 int mrca_normalize_scans(const float* in_dev, float* out_dev, size_t count, void* stream) {

@@ -24,7 +24,14 @@ EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_crea
            "mrca_step", "mrca_step_slice", "mrca_step_worlds", "mrca_move_worlds", "mrca_observe_worlds", "mrca_step_many", "mrca_materialize", "mrca_newest_obs", "mrca_sparse_obs", "mrca_normalize_scans", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
            "mrca_event_pair_overhead",
            "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
-           "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch", "mrca_adam_step"]
+           "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch", "mrca_adam_step",
+           "mrca_rollout_store_state", "mrca_rollout_store_outcome"]
+
+
+class RolloutRows(C.Structure):
+    """include/mrca_env.h: mrca_rollout_rows"""
+    _fields_ = [(k, C.c_void_p) for k in ("frames", "fidx", "cur", "goal", "speed", "action", "logprob", "value", "reward",
+                                          "done")] + [("horizon", C.c_int32)]
 
 
 class MrcaConfig(C.Structure):
@@ -87,6 +94,8 @@ def load(path=None):
     lib.mrca_ppo_loss_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_ppo_loss.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4 + \
         [C.c_size_t, C.c_void_p]
+    lib.mrca_rollout_store_state.argtypes = [C.c_void_p, C.POINTER(RolloutRows)] + [C.c_void_p] * 5
+    lib.mrca_rollout_store_outcome.argtypes = [C.c_void_p, C.POINTER(RolloutRows)] + [C.c_void_p] * 3
     lib.mrca_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 4 + [C.c_int32, C.c_void_p]
     lib.mrca_enable_timing.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(lib, "mrca_set_debug_flags"):      # profiling build only

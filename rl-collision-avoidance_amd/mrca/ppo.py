@@ -128,7 +128,7 @@ class RolloutBuffer:
         f32 = dict(dtype=torch.float32, device=device)
         self.single_frame = single_frame
         if single_frame:
-            self.frames = torch.empty(T + 2, N, beams, **f32)
+            self.frames = torch.empty(T + frames - 1, N, beams, **f32)
             self.fidx = torch.zeros(T, N, frames, dtype=torch.int64, device=device)
             self._cur = torch.zeros(N, frames, dtype=torch.int64, device=device)
             self._first = torch.arange(frames, dtype=torch.int64, device=device).view(1, frames)
@@ -145,6 +145,22 @@ class RolloutBuffer:
         self.logprob = torch.empty(T, N, 1, **f32)
         self.value = torch.empty(T, N, **f32)
         self.horizon, self.num_env, self.nframes = T, N, frames
+        self._env, self._rows, self._ticket = None, None, None
+
+    # ---- the per-tick stores as two launches of the env's library (csrc/mrca_rollout_store.hip) instead of ~20 of PyTorch's
+    def bind_env(self, env):
+        """Let ``env`` (a VecStageWorld on this buffer's device, same N / frames / beams) write the rows itself:
+        ``store_state_at`` then takes the newest frame, the goal and the speed from the env's arena, ``store_outcome_at``
+        its reward and done flags AND moves the device-side row counter on.  One-frame buffers only."""
+        if not self.single_frame:
+            raise ValueError("bind_env: only the one-frame-per-tick buffer is written by the library")
+        self._rows = env.rollout_rows(self)
+        self._env = env
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=self.goal.device)
+
+    @property
+    def env_bound(self):
+        return self._env is not None
 
     # ---- observation stacks
     def begin_horizon(self, obs):
@@ -193,6 +209,9 @@ class RolloutBuffer:
     # the same two stores with the row given as a DEVICE index tensor (int64[1]): no host value enters the launch, so a
     # whole tick can be captured once as a hipGraph and replayed for every row of the horizon
     def store_state_at(self, t_idx, obs, goal, speed, action, logprob, value, fresh=None, newest=None):
+        if self._env is not None:       # (obs / goal / speed / fresh / newest: the bound env's own fields, read by the library)
+            self._env.rollout_store_state(self._rows, t_idx, action.contiguous(), logprob.contiguous(), value.contiguous())
+            return
         self._store_obs_at(t_idx, obs, fresh, newest)
         self.goal.index_copy_(0, t_idx, goal.unsqueeze(0))
         self.speed.index_copy_(0, t_idx, speed.unsqueeze(0))
@@ -201,8 +220,14 @@ class RolloutBuffer:
         self.value.index_copy_(0, t_idx, value.view(1, -1))
 
     def store_outcome_at(self, t_idx, reward, done):
+        """-> True when the row counter ``t_idx`` was moved on by the store itself (a bound env), False when that is left
+        to the caller."""
+        if self._env is not None:
+            self._env.rollout_store_outcome(self._rows, t_idx, self._ticket)
+            return True
         self.reward.index_copy_(0, t_idx, reward.unsqueeze(0))
         self.done.index_copy_(0, t_idx, done.unsqueeze(0))
+        return False
 
 
 def generate_train_data(rewards, gamma, values, last_value, dones, lam):

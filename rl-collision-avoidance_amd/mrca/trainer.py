@@ -86,6 +86,8 @@ class Stage1Trainer:
             if self.hp.kl_target > 0 else None
         self.buffer = ppo.RolloutBuffer(self.hp.horizon, env.N, self.hp.laser_hist, self.hp.obs_size, dev,
                                         self.hp.act_size, single_frame=self.hp.single_frame_buffer)
+        if self.hp.single_frame_buffer and hasattr(env, "rollout_rows") and self.hp.act_size == 2:
+            self.buffer.bind_env(env)       # the per-tick stores as two launches of the env's library
         self.gen = torch.Generator(device=dev)
         rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
         self.gen.manual_seed(seed * 1000 + rank)
@@ -109,11 +111,11 @@ class Stage1Trainer:
         obs, head = ppo.policy_input(env, hp.rollout_fused)
         v, a, logprob, scaled = ppo.generate_action(self.policy, obs, env.local_goal, env.speed, hp.action_bound, self.gen,
                                                     hp.inference_dtype, hp.rollout_fused, head, noise=noise)
-        so, sn = self._stored_obs()
+        so, sn = (None, None) if buf.env_bound else self._stored_obs()
         buf.store_state_at(self._t_idx, so, env.local_goal, env.speed, a, logprob, v, env.fresh, newest=sn)
         env.step(scaled.contiguous())
-        buf.store_outcome_at(self._t_idx, env.reward, env.done)
-        self._t_idx.add_(1)
+        if not buf.store_outcome_at(self._t_idx, env.reward, env.done):
+            self._t_idx.add_(1)
 
     def _stored_obs(self):
         """-> (obs, newest) for the rollout buffer: with the one-frame store and an env that keeps its stacks as a ring

@@ -156,6 +156,44 @@ class VecStageWorld:
         _lib.check(self.lib.mrca_newest_obs(self._h, out.data_ptr(), self._stream()), "mrca_newest_obs")
         return out
 
+    # ---- the learner's rollout buffer written by the library (include/mrca_env.h: mrca_rollout_rows)
+    def rollout_rows(self, buf):
+        """The C view of a one-frame-per-tick ``ppo.RolloutBuffer`` of this env's shape (checked here, once): hand it to
+        ``rollout_store_state`` / ``rollout_store_outcome``.  Keeps the buffer's tensors alive."""
+        T, N, F, B = buf.horizon, self.N, self.F, self.B
+        want = {"frames": (torch.float32, (T + F - 1, N, B)), "fidx": (torch.int64, (T, N, F)), "_cur": (torch.int64, (N, F)),
+                "goal": (torch.float32, (T, N, 2)), "speed": (torch.float32, (T, N, 2)), "action": (torch.float32, (T, N, 2)),
+                "logprob": (torch.float32, (T, N, 1)), "value": (torch.float32, (T, N)), "reward": (torch.float32, (T, N)),
+                "done": (torch.uint8, (T, N))}
+        rows = _lib.RolloutRows()
+        for name, (dtype, shape) in want.items():
+            t = getattr(buf, name, None)
+            if not (torch.is_tensor(t) and t.device == self.device and t.dtype == dtype and tuple(t.shape) == shape and t.is_contiguous()):
+                raise ValueError(f"rollout_rows: buffer.{name} must be a contiguous {dtype} tensor of shape {shape} on {self.device}"
+                                 + (f", got {tuple(t.shape)} {t.dtype} {t.device}" if torch.is_tensor(t) else ""))
+            setattr(rows, name.lstrip("_"), t.data_ptr())
+        rows.horizon = T
+        rows._keep = buf
+        return rows
+
+    def rollout_store_state(self, rows, tick, action, logprob, value):
+        """Row ``tick`` (int64[1] on the device) of the buffer before the env steps: newest frame, stack rows, goal, speed and
+        the policy's ``action`` f32[N,2] / ``logprob`` / ``value`` (N elements each) -- one launch."""
+        if not (tick.is_cuda and tick.dtype == torch.int64 and tick.numel() == 1):
+            raise ValueError("rollout_store_state: tick must be an int64[1] cuda tensor")
+        _lib.check(self.lib.mrca_rollout_store_state(self._h, C.byref(rows), tick.data_ptr(), self._ptr(action, torch.float32, 2 * self.N),
+                                                     self._ptr(logprob, torch.float32, self.N), self._ptr(value, torch.float32, self.N),
+                                                     self._stream()), "mrca_rollout_store_state")
+
+    def rollout_store_outcome(self, rows, tick, ticket):
+        """... and after it stepped: reward / done into row ``tick``, then ``tick += 1`` on the device -- one launch.
+        ``ticket``: a zeroed int32[1] cuda tensor of the caller's, the same one for every call."""
+        if not (tick.is_cuda and tick.dtype == torch.int64 and tick.numel() == 1 and ticket.is_cuda and ticket.dtype == torch.int32
+                and ticket.numel() == 1):
+            raise ValueError("rollout_store_outcome: tick int64[1] and ticket int32[1] cuda tensors")
+        _lib.check(self.lib.mrca_rollout_store_outcome(self._h, C.byref(rows), tick.data_ptr(), ticket.data_ptr(), self._stream()),
+                   "mrca_rollout_store_outcome")
+
     def sparse_obs(self, beam_num):
         """f32[N,F,beam_num]: the observation stacks a ``StageWorld(beam_num, ...)`` with beam_num != 512 would build
         (stage_world1.py:126-140), formed on the device from the ring."""

@@ -172,3 +172,40 @@ def test_single_frame_buffer_equals_the_stack_buffer(hip):
     assert torch.equal(b.obs_rows()[keep][sub], a.obs_rows()[keep][sub])
     for e in envs:
         e.close()
+
+
+def test_library_stores_fill_the_buffer_exactly_as_the_torch_stores(hip):
+    """Two trainers on identical envs and seeds, ticks replayed as hipGraphs: one buffer written by the env's library
+    (mrca_rollout_store_state / _outcome: two launches per tick, the row counter moved on by the second), the other through
+    PyTorch's index_copy_ / cat / where chain.  Every tensor of the buffer must be identical, restarts included; a counter
+    outside the horizon stores nothing and is reported by env.check()."""
+    from mrca.trainer import HParams, Stage1Trainer
+    sc = S.stage1(num_worlds=4, robots_per_world=16, seed=8)
+    envs = [hip.VecStageWorld(sc) for _ in range(2)]
+    trs = [Stage1Trainer(e, hp=HParams(horizon=40, batch_size=512, epoch=1, graph_tick=True, rollout_fused=True), seed=4) for e in envs]
+    assert trs[0].buffer.env_bound and trs[1].buffer.env_bound
+    trs[1].buffer._env = None                                            # this one: the torch stores
+    for tr in trs:
+        tr.start()
+    for _ in range(39):                # (one tick per replay on both sides: a replay of eight draws its noise differently)
+        for tr in trs:
+            tr.tick()
+    torch.cuda.synchronize()
+    a, b = trs[0].buffer, trs[1].buffer
+    assert int(trs[0]._t_idx) == int(trs[1]._t_idx) == 39
+    assert int(a.done[:39].sum()) > 0                                    # robots did restart inside the horizon
+    for name in ("goal", "speed", "action", "logprob", "value", "reward", "done", "fidx"):
+        assert torch.equal(getattr(a, name)[:39], getattr(b, name)[:39]), name
+    assert torch.equal(a.frames[:41], b.frames[:41]) and torch.equal(a._cur, b._cur)
+    assert torch.equal(a.obs_rows().materialise()[:39], b.obs_rows().materialise()[:39])
+    # a row counter outside [0, horizon): nothing is stored, the env's status word says so
+    before = a.value.clone()
+    bad = torch.tensor([40], dtype=torch.int64, device="cuda")
+    envs[0].rollout_store_state(a._rows, bad, a.action[0], a.logprob[0], a.value[0])
+    torch.cuda.synchronize()
+    assert torch.equal(a.value, before) and int(bad) == 40
+    with pytest.raises(RuntimeError, match="tick counter"):
+        envs[0].check()
+    envs[0].check()                                                      # cleared by the failed check
+    for e in envs:
+        e.close()
