@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define MRCA_ABI_VERSION 4
+/* 5 (round 5): mrca_policy_tail takes fc1_b_dev (may be NULL) after h1_dev; added since 4, all additive: mrca_step_worlds,
+ * mrca_move_worlds, mrca_observe_worlds, mrca_step_many, mrca_adam_step, mrca_rollout_rows + mrca_rollout_store_state /
+ * _outcome, status bits for mrca_check.  4: the frame history became a ring of raw scans (MRCA_F_SCAN_RING, MRCA_F_RING_HEAD). */
+#define MRCA_ABI_VERSION 5
 
 typedef struct mrca_env mrca_env; /* opaque */
 

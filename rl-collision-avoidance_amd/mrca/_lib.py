@@ -9,7 +9,7 @@ PROFILING_LIB_PATH = os.path.join(_HERE, "libmrca_env_prof.so")
 # libmrca_env_prof.so); whichever it is, it must exist -- there is no fallback
 LIB_PATH = os.environ.get("MRCA_ENV_LIB") or os.path.join(_HERE, "libmrca_env.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 VIEW_SCAN, VIEW_OBS = 1, 2        # enum mrca_view
 
 FIELDS = [  # order = enum mrca_field
