@@ -647,16 +647,16 @@ def main():
         # (as `--mode rollout` does: the recorded kernel choice for the fc1 GEMM -- switched on here, behind the timed region)
         recorded = (not args.no_gemm_choices) and gemm_tuning.use_recorded_choices()
         roll = make_bench_step(env, "rollout", None, fused=True, graph=True)
-        roll.run_ticks(16)
+        roll.run_ticks(40)
         torch.cuda.synchronize()
         tr0 = time.perf_counter()
-        n_roll = 104
+        n_roll = 400                        # (the region `--mode rollout` times by default: 40 warm-up ticks, 400 timed)
         roll.run_ticks(n_roll)
         torch.cuda.synchronize()
         extra["rollout_side_figure"] = {"value": N * n_roll / (time.perf_counter() - tr0), "unit": "agent-steps/s",
                                         "note": "env + fp32 CNNPolicy inference per tick (HIP conv front end, fc1 as a batched "
                                                 "GEMM -- " + ("recorded TunableOp choice" if recorded else "library default heuristic") +
-                                                " --, tail kernel; ticks replayed as hipGraphs of eight), 104 ticks after 16 "
+                                                " --, tail kernel; ticks replayed as hipGraphs of eight), 400 ticks after 40 "
                                                 "warm-up ticks; not part of `value`"}
 
     # Side figures of the OTHER configurations DESIGN.md / README quote (each a fresh env, a few hundred ticks after the timed
