@@ -171,6 +171,10 @@ class Stage1Trainer:
             self._graph.replay()
             if hasattr(env, "invalidate_views"):
                 env.invalidate_views()          # the replayed tick advanced the ring behind the binding's back
+        elif buf.env_bound:
+            # launched kernel by kernel, the same body the graph captures: the row's stores are the library's two launches
+            # and the row comes from the device-side counter (which the second of them moves on)
+            self._tick_body()
         else:
             obs, head = ppo.policy_input(env, hp.rollout_fused)
             v, a, logprob, scaled = ppo.generate_action(self.policy, obs, env.local_goal, env.speed,
