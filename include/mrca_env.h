@@ -34,8 +34,8 @@ extern "C" {
 #endif
 
 /* 5 (round 5): mrca_policy_tail takes fc1_b_dev (may be NULL) after h1_dev; added since 4, all additive: mrca_step_worlds,
- * mrca_move_worlds, mrca_observe_worlds, mrca_step_many, mrca_adam_step, mrca_rollout_rows + mrca_rollout_store_state /
- * _outcome, status bits for mrca_check.  4: the frame history became a ring of raw scans (MRCA_F_SCAN_RING, MRCA_F_RING_HEAD). */
+ * mrca_move_worlds, mrca_observe_worlds, mrca_step_many, mrca_adam_step, mrca_policy_heads(_backward), mrca_rollout_rows +
+ * mrca_rollout_store_state / _outcome, status bits for mrca_check.  4: the frame history became a ring of raw scans (MRCA_F_SCAN_RING, MRCA_F_RING_HEAD). */
 #define MRCA_ABI_VERSION 5
 
 typedef struct mrca_env mrca_env; /* opaque */
@@ -331,6 +331,25 @@ int mrca_ppo_loss(const float* mean_dev, const float* value_dev, const float* lo
  *   step  the number of THIS step, starting at 1 */
 int mrca_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
                    double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
+
+/* The three output heads of the actor-critic in the PPO update (model/net.py:47-55,61-63: mean = [sigmoid(actor1(a)),
+ * tanh(actor2(a))], value = critic(c); three Linear(128, 1)), forward and backward, as row operations instead of ~25 library
+ * launches per minibatch.
+ *   a_dev, c_dev  f32[n,128]  the actor / critic tower's features (act_fc2 / crt_fc2 outputs after their ReLU), 16-byte aligned
+ *   w_*_dev f32[128], b_*_dev f32[1]   actor1 / actor2 / critic weight rows and biases (any 4-byte alignment)
+ *   out: mean_dev f32[n,2], value_dev f32[n] */
+int mrca_policy_heads(const float* a_dev, const float* c_dev, int32_t n, const float* w_actor1_dev, const float* b_actor1_dev,
+                      const float* w_actor2_dev, const float* b_actor2_dev, const float* w_critic_dev, const float* b_critic_dev,
+                      float* mean_dev, float* value_dev, void* stream);
+/* ... and its backward pass: given dLoss/dmean (gmean_dev f32[n,2] or NULL = zero) and dLoss/dvalue (gvalue_dev f32[n] or
+ * NULL) and the forward's mean_dev, the feature gradients da_dev, dc_dev f32[n,128] and dw_dev f32[387] = dW actor1[128],
+ * dW actor2[128], dW critic[128], db actor1, db actor2, db critic (per-wave partial sums added in a fixed order in float64:
+ * deterministic).  scratch_dev: caller-owned, at least mrca_policy_heads_backward_scratch() bytes, 16-byte aligned. */
+int mrca_policy_heads_backward_scratch(size_t* bytes_out);
+int mrca_policy_heads_backward(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
+                               const float* gvalue_dev, int32_t n, const float* w_actor1_dev, const float* w_actor2_dev,
+                               const float* w_critic_dev, float* da_dev, float* dc_dev, float* dw_dev, void* scratch_dev,
+                               size_t scratch_bytes, void* stream);
 
 /* The learner's rollout buffer, written by the library: what the reference appends to `buff` every step and turns into arrays
  * before the update (ppo_stage1.py:102-103; model/ppo.py:22-54 transform_buffer), kept on the device with ONE lidar frame per

@@ -24,7 +24,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC
 pids=()
 obj="$(mktemp -d)"
 trap 'rm -rf "${obj}"' EXIT
-for src in mrca_kernels mrca_abi mrca_policy mrca_policy_bwd mrca_policy_tail mrca_ppo_loss mrca_adam mrca_rollout_store; do
+for src in mrca_kernels mrca_abi mrca_policy mrca_policy_bwd mrca_policy_tail mrca_ppo_loss mrca_adam mrca_rollout_store mrca_policy_heads; do
     per=()
     [[ "${src}" == "mrca_policy" ]] && per=(-mllvm --amdgpu-mfma-vgpr-form)
     # the env kernels: the first 14 dwords of a kernel's arguments arrive in SGPRs (gfx950's kernarg preload) -- move_kernel and

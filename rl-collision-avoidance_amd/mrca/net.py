@@ -79,6 +79,10 @@ class CNNPolicy(nn.Module):
                 st(self.act_fea_cv2.weight, self.crt_fea_cv2.weight), st(self.act_fea_cv2.bias, self.crt_fea_cv2.bias))
             a = self._tail("act", fa, goal, speed)
             c = self._tail("crt", fc, goal, speed)
+            # the three Linear(128, 1) heads with their activations, forward and backward, as row kernels (as library GEMMs
+            # they are ~25 launches and ~200 us of a 16 384-row minibatch: csrc/mrca_policy_heads.hip)
+            return policy_ops.policy_heads(a, c, self.actor1.weight, self.actor1.bias, self.actor2.weight, self.actor2.bias,
+                                           self.critic.weight, self.critic.bias)
         else:
             a = self._tower("act", x, goal, speed)
             c = self._tower("crt", x, goal, speed)

@@ -251,3 +251,68 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
         stream = C.c_void_p(torch.cuda.current_stream(param.device).cuda_stream)
         _lib.check(lib.mrca_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
                                       float(lr), float(beta1), float(beta2), float(eps), int(step), stream), "mrca_adam_step")
+
+
+_heads_scratch = {}
+
+
+def _heads_backward_scratch(device):
+    key = (device.type, device.index)
+    if key not in _heads_scratch:
+        lib = _lib.load()
+        n = C.c_size_t()
+        _lib.check(lib.mrca_policy_heads_backward_scratch(C.byref(n)), "mrca_policy_heads_backward_scratch")
+        _heads_scratch[key] = torch.empty(n.value, dtype=torch.uint8, device=device)
+    return _heads_scratch[key]
+
+
+class _PolicyHeads(torch.autograd.Function):
+    """mean = [sigmoid(actor1(a)), tanh(actor2(a))], value = critic(c) (model/net.py:47-55,61-63) and their gradients as
+    row kernels (csrc/mrca_policy_heads.hip) instead of three skinny GEMMs forward and six backward."""
+
+    @staticmethod
+    def forward(ctx, a, c, w1, b1, w2, b2, wc, bc):
+        lib = _lib.load()
+        n = a.shape[0]
+        a, c = a.detach().contiguous(), c.detach().contiguous()
+        ws = [t.detach().contiguous().view(-1) for t in (w1, b1, w2, b2, wc, bc)]
+        for t, numel in zip([a, c] + ws, (n * 128, n * 128, 128, 1, 128, 1, 128, 1)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.numel() == numel and t.device == a.device):
+                raise ValueError("policy_heads: expected cuda float32 tensors a, c [n,128], three weight rows [1,128] and biases [1] "
+                                 "on one device")
+        mean = torch.empty(n, 2, dtype=torch.float32, device=a.device)
+        value = torch.empty(n, 1, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+            _lib.check(lib.mrca_policy_heads(a.data_ptr(), c.data_ptr(), n, *[t.data_ptr() for t in ws], mean.data_ptr(),
+                                             value.data_ptr(), stream), "mrca_policy_heads")
+        ctx.save_for_backward(a, c, mean, ws[0], ws[2], ws[4])
+        ctx.shapes = (w1.shape, b1.shape, w2.shape, b2.shape, wc.shape, bc.shape)
+        return mean, value
+
+    @staticmethod
+    def backward(ctx, gmean, gvalue):
+        lib = _lib.load()
+        a, c, mean, w1, w2, wc = ctx.saved_tensors
+        n, dev = a.shape[0], a.device
+        gmean = None if gmean is None else gmean.contiguous()
+        gvalue = None if gvalue is None else gvalue.contiguous()
+        da, dc = torch.empty_like(a), torch.empty_like(c)
+        dw = torch.empty(3 * 128 + 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            scratch = _heads_backward_scratch(dev)
+            _lib.check(lib.mrca_policy_heads_backward(a.data_ptr(), c.data_ptr(), mean.data_ptr(),
+                                                      None if gmean is None else gmean.data_ptr(),
+                                                      None if gvalue is None else gvalue.data_ptr(), n, w1.data_ptr(), w2.data_ptr(),
+                                                      wc.data_ptr(), da.data_ptr(), dc.data_ptr(), dw.data_ptr(), scratch.data_ptr(),
+                                                      scratch.numel(), stream), "mrca_policy_heads_backward")
+        s = ctx.shapes
+        return (da, dc, dw[0:128].view(s[0]), dw[384:385].view(s[1]), dw[128:256].view(s[2]), dw[385:386].view(s[3]),
+                dw[256:384].view(s[4]), dw[386:387].view(s[5]))
+
+
+def policy_heads(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic):
+    """-> (mean [n,2], value [n,1]) of the three output heads, differentiable with respect to all eight arguments (include/
+    mrca_env.h: mrca_policy_heads / _backward)."""
+    return _PolicyHeads.apply(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic)
