@@ -38,7 +38,8 @@ def test_policy_heads_forward_and_backward_against_float64(built, n):
     assert mean.shape == (n, 2) and value.shape == (n, 1)
     args64 = [t.detach().double().requires_grad_(True) for t in (a, c, w1, b1, w2, b2, wc, bc)]
     m64, v64 = _reference(*args64)
-    assert float((mean.double() - m64).abs().max()) < 5e-7 and float((value.double() - v64).abs().max()) < 5e-6
+    assert float((mean.detach().double() - m64.detach()).abs().max()) < 5e-7
+    assert float((value.detach().double() - v64.detach()).abs().max()) < 5e-6
     (mean * gm).sum().add((value * gv).sum()).backward()
     ((m64 * gm.double()).sum() + (v64 * gv.double()).sum()).backward()
     names = ("a", "c", "w_actor1", "b_actor1", "w_actor2", "b_actor2", "w_critic", "b_critic")
