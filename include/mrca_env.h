@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 /* 5 (round 5): mrca_policy_tail takes fc1_b_dev (may be NULL) after h1_dev; added since 4, all additive: mrca_step_worlds,
- * mrca_move_worlds, mrca_observe_worlds, mrca_step_many, mrca_adam_step, mrca_policy_heads(_backward), mrca_rollout_rows +
+ * mrca_move_worlds, mrca_observe_worlds, mrca_step_many, mrca_adam_step, mrca_policy_heads(_backward), mrca_relu_cat(_backward), mrca_rollout_rows +
  * mrca_rollout_store_state / _outcome, status bits for mrca_check.  4: the frame history became a ring of raw scans (MRCA_F_SCAN_RING, MRCA_F_RING_HEAD). */
 #define MRCA_ABI_VERSION 5
 
@@ -337,10 +337,12 @@ int mrca_adam_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, 
  * launches per minibatch.
  *   a_dev, c_dev  f32[n,128]  the actor / critic tower's features (act_fc2 / crt_fc2 outputs after their ReLU), 16-byte aligned
  *   w_*_dev f32[128], b_*_dev f32[1]   actor1 / actor2 / critic weight rows and biases (any 4-byte alignment)
+ *   relu_inputs   1: a_dev / c_dev are fc2's outputs BEFORE their ReLU -- it is applied as they are loaded, and its mask to
+ *                 da_dev / dc_dev on the way back (which are then the gradients of those pre-activations); 0: as given
  *   out: mean_dev f32[n,2], value_dev f32[n] */
 int mrca_policy_heads(const float* a_dev, const float* c_dev, int32_t n, const float* w_actor1_dev, const float* b_actor1_dev,
                       const float* w_actor2_dev, const float* b_actor2_dev, const float* w_critic_dev, const float* b_critic_dev,
-                      float* mean_dev, float* value_dev, void* stream);
+                      int32_t relu_inputs, float* mean_dev, float* value_dev, void* stream);
 /* ... and its backward pass: given dLoss/dmean (gmean_dev f32[n,2] or NULL = zero) and dLoss/dvalue (gvalue_dev f32[n] or
  * NULL) and the forward's mean_dev, the feature gradients da_dev, dc_dev f32[n,128] and dw_dev f32[387] = dW actor1[128],
  * dW actor2[128], dW critic[128], db actor1, db actor2, db critic (per-wave partial sums added in a fixed order in float64:
@@ -348,8 +350,14 @@ int mrca_policy_heads(const float* a_dev, const float* c_dev, int32_t n, const f
 int mrca_policy_heads_backward_scratch(size_t* bytes_out);
 int mrca_policy_heads_backward(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
                                const float* gvalue_dev, int32_t n, const float* w_actor1_dev, const float* w_actor2_dev,
-                               const float* w_critic_dev, float* da_dev, float* dc_dev, float* dw_dev, void* scratch_dev,
-                               size_t scratch_bytes, void* stream);
+                               const float* w_critic_dev, int32_t relu_inputs, float* da_dev, float* dc_dev, float* dw_dev,
+                               void* scratch_dev, size_t scratch_bytes, void* stream);
+
+/* out[n,260] = [relu(h1[n,256]), goal[n,2], speed[n,2]]: F.relu(act_fc1(a)) and torch.cat((a, goal, speed), dim=-1) of
+ * model/net.py:43-45 (the critic tower alike, :57-59) in one launch, and its backward dh1[n,256] = gout[:, :256] where h1 > 0
+ * (goal and speed are data).  h1 / out / gout / dh1 16-byte aligned, goal / speed 8-byte. */
+int mrca_relu_cat(const float* h1_dev, const float* goal_dev, const float* speed_dev, int32_t n, float* out_dev, void* stream);
+int mrca_relu_cat_backward(const float* h1_dev, const float* gout_dev, int32_t n, float* dh1_dev, void* stream);
 
 /* The learner's rollout buffer, written by the library: what the reference appends to `buff` every step and turns into arrays
  * before the update (ppo_stage1.py:102-103; model/ppo.py:22-54 transform_buffer), kept on the device with ONE lidar frame per

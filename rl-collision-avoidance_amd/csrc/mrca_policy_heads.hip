@@ -40,6 +40,15 @@ __device__ __forceinline__ float half_sum(float v) {          // over the 32 lan
     return v;
 }
 
+__device__ __forceinline__ float4 relu4(float4 v) {
+    return make_float4(v.x > 0.0f ? v.x : 0.0f, v.y > 0.0f ? v.y : 0.0f, v.z > 0.0f ? v.z : 0.0f, v.w > 0.0f ? v.w : 0.0f);
+}
+__device__ __forceinline__ float4 mask4(float4 g, float4 z) {     // threshold_backward: the gradient where the input was > 0
+    return make_float4(z.x > 0.0f ? g.x : 0.0f, z.y > 0.0f ? g.y : 0.0f, z.z > 0.0f ? g.z : 0.0f, z.w > 0.0f ? g.w : 0.0f);
+}
+
+// RELU: a and c are fc2's outputs BEFORE their ReLU; it is applied as they are loaded (and its mask to da, dc on the way back)
+template <bool RELU>
 __global__ __launch_bounds__(kThreads) void heads_forward_kernel(
     const float* __restrict__ a, const float* __restrict__ c, int n, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ wc, const float* __restrict__ bc,
@@ -66,6 +75,10 @@ __global__ __launch_bounds__(kThreads) void heads_forward_kernel(
 #pragma unroll
         for (int j = 0; j < kRowsInFlight; ++j) {
             const int row = 2 * (p0 + j) + half;
+            if (RELU) {
+                aq[j] = relu4(aq[j]);
+                cq[j] = relu4(cq[j]);
+            }
             const float s0 = half_sum(dot4(aq[j], w1q)), s1 = half_sum(dot4(aq[j], w2q)), s2 = half_sum(dot4(cq[j], wcq));
             if (q == 0 && p0 + j < last && row < n) {
                 mean[(size_t)row * 2 + 0] = 1.0f / (1.0f + expf(-(s0 + bias1)));
@@ -76,6 +89,7 @@ __global__ __launch_bounds__(kThreads) void heads_forward_kernel(
     }
 }
 
+template <bool RELU>
 __global__ __launch_bounds__(kThreads) void heads_backward_kernel(
     const float* __restrict__ a, const float* __restrict__ c, const float* __restrict__ mean, const float* __restrict__ gmean,
     const float* __restrict__ gvalue, int n, const float* __restrict__ w1, const float* __restrict__ w2,
@@ -106,15 +120,26 @@ __global__ __launch_bounds__(kThreads) void heads_backward_kernel(
             g0[j] = valid ? u0 * (1.0f - m0) * m0 : 0.0f;           // sigmoid_backward: g (1 - y) y
             g1[j] = valid ? u1 * (1.0f - m1 * m1) : 0.0f;           // tanh_backward:    g (1 - y y)
             gv[j] = valid ? uv : 0.0f;
+            if (!valid) aq[j] = cq[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // (0 x a non-finite stand-in row would be NaN)
         }
 #pragma unroll
         for (int j = 0; j < kRowsInFlight; ++j) {                   // ... then the arithmetic and the two stores per row
             const int row = 2 * (p0 + j) + half;
             if (p0 + j < last && row < n) {
                 const size_t r = (size_t)row * (kFeat / 4) + q;
-                reinterpret_cast<float4*>(da)[r] = make_float4(g0[j] * w1q.x + g1[j] * w2q.x, g0[j] * w1q.y + g1[j] * w2q.y,
-                                                               g0[j] * w1q.z + g1[j] * w2q.z, g0[j] * w1q.w + g1[j] * w2q.w);
-                reinterpret_cast<float4*>(dc)[r] = make_float4(gv[j] * wcq.x, gv[j] * wcq.y, gv[j] * wcq.z, gv[j] * wcq.w);
+                float4 dav = make_float4(g0[j] * w1q.x + g1[j] * w2q.x, g0[j] * w1q.y + g1[j] * w2q.y,
+                                         g0[j] * w1q.z + g1[j] * w2q.z, g0[j] * w1q.w + g1[j] * w2q.w);
+                float4 dcv = make_float4(gv[j] * wcq.x, gv[j] * wcq.y, gv[j] * wcq.z, gv[j] * wcq.w);
+                if (RELU) {
+                    dav = mask4(dav, aq[j]);
+                    dcv = mask4(dcv, cq[j]);
+                }
+                reinterpret_cast<float4*>(da)[r] = dav;
+                reinterpret_cast<float4*>(dc)[r] = dcv;
+            }
+            if (RELU) {
+                aq[j] = relu4(aq[j]);
+                cq[j] = relu4(cq[j]);
             }
             acc1.x += g0[j] * aq[j].x; acc1.y += g0[j] * aq[j].y; acc1.z += g0[j] * aq[j].z; acc1.w += g0[j] * aq[j].w;
             acc2.x += g1[j] * aq[j].x; acc2.y += g1[j] * aq[j].y; acc2.z += g1[j] * aq[j].z; acc2.w += g1[j] * aq[j].w;
@@ -172,6 +197,38 @@ __global__ __launch_bounds__(kFinK * kFinGroups) void heads_finalize_kernel(cons
     }
 }
 
+// x2[n][260] = [relu(h1[n][256]), goal[n][2], speed[n][2]]  (model/net.py:43-45: F.relu(act_fc1(a)); torch.cat((a, goal,
+// speed), dim=-1)) and its backward dh1 = gout[:, :256] where h1 > 0 -- one launch each instead of clamp_min + cat and
+// narrow + copy + threshold_backward.  A thread owns one float4 of the output row (65 per row) / of h1 (64 per row).
+constexpr int kFc1 = 256, kCat = 260;
+
+__global__ __launch_bounds__(kThreads) void relu_cat_kernel(const float4* __restrict__ h1, const float2* __restrict__ goal,
+                                                            const float2* __restrict__ speed, long n, float4* __restrict__ out) {
+    const long total = n * (kCat / 4);
+    const long stride = (long)gridDim.x * kThreads;
+    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < total; k += stride) {
+        const long row = k / (kCat / 4);
+        const int c4 = (int)(k - row * (kCat / 4));
+        if (c4 < kFc1 / 4) {
+            out[k] = relu4(h1[row * (kFc1 / 4) + c4]);
+        } else {
+            const float2 g = goal[row], v = speed[row];
+            out[k] = make_float4(g.x, g.y, v.x, v.y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void relu_cat_backward_kernel(const float4* __restrict__ h1, const float4* __restrict__ gout,
+                                                                     long n, float4* __restrict__ dh1) {
+    const long total = n * (kFc1 / 4);
+    const long stride = (long)gridDim.x * kThreads;
+    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < total; k += stride) {
+        const long row = k / (kFc1 / 4);
+        const int c4 = (int)(k - row * (kFc1 / 4));
+        dh1[k] = mask4(gout[row * (kCat / 4) + c4], h1[k]);
+    }
+}
+
 static int blocks_for(int n) {
     int rows_pairs = (n + 1) / 2;
     int b = (rows_pairs + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -184,8 +241,8 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int mrca_policy_heads(const float* a_dev, const float* c_dev, int32_t n, const float* w_actor1_dev,
                                  const float* b_actor1_dev, const float* w_actor2_dev, const float* b_actor2_dev,
-                                 const float* w_critic_dev, const float* b_critic_dev, float* mean_dev, float* value_dev,
-                                 void* stream) {
+                                 const float* w_critic_dev, const float* b_critic_dev, int32_t relu_inputs, float* mean_dev,
+                                 float* value_dev, void* stream) {
     using namespace mrca_heads;
     if (!a_dev || !c_dev || !w_actor1_dev || !b_actor1_dev || !w_actor2_dev || !b_actor2_dev || !w_critic_dev || !b_critic_dev ||
         !mean_dev || !value_dev)
@@ -194,8 +251,14 @@ extern "C" int mrca_policy_heads(const float* a_dev, const float* c_dev, int32_t
     if (!aligned16(a_dev) || !aligned16(c_dev))
         return mrca::set_error(MRCA_ERR_INVALID, "mrca_policy_heads: the feature matrices must be 16-byte aligned");
     mrca::DeviceGuard guard(mrca::device_of(a_dev));
-    hipLaunchKernelGGL(heads_forward_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a_dev, c_dev,
-                       n, w_actor1_dev, b_actor1_dev, w_actor2_dev, b_actor2_dev, w_critic_dev, b_critic_dev, mean_dev, value_dev);
+    if (relu_inputs)
+        hipLaunchKernelGGL(heads_forward_kernel<true>, dim3(blocks_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                           a_dev, c_dev, n, w_actor1_dev, b_actor1_dev, w_actor2_dev, b_actor2_dev, w_critic_dev, b_critic_dev,
+                           mean_dev, value_dev);
+    else
+        hipLaunchKernelGGL(heads_forward_kernel<false>, dim3(blocks_for(n)), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                           a_dev, c_dev, n, w_actor1_dev, b_actor1_dev, w_actor2_dev, b_actor2_dev, w_critic_dev, b_critic_dev,
+                           mean_dev, value_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_policy_heads launch: %s", hipGetErrorString(e));
     return MRCA_OK;
@@ -209,8 +272,9 @@ extern "C" int mrca_policy_heads_backward_scratch(size_t* bytes_out) {
 
 extern "C" int mrca_policy_heads_backward(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
                                           const float* gvalue_dev, int32_t n, const float* w_actor1_dev,
-                                          const float* w_actor2_dev, const float* w_critic_dev, float* da_dev, float* dc_dev,
-                                          float* dw_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+                                          const float* w_actor2_dev, const float* w_critic_dev, int32_t relu_inputs,
+                                          float* da_dev, float* dc_dev, float* dw_dev, void* scratch_dev, size_t scratch_bytes,
+                                          void* stream) {
     using namespace mrca_heads;
     if (!a_dev || !c_dev || !mean_dev || !w_actor1_dev || !w_actor2_dev || !w_critic_dev || !da_dev || !dc_dev || !dw_dev ||
         !scratch_dev)
@@ -224,11 +288,50 @@ extern "C" int mrca_policy_heads_backward(const float* a_dev, const float* c_dev
     mrca::DeviceGuard guard(mrca::device_of(a_dev));
     const int blocks = blocks_for(n);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(heads_backward_kernel, dim3(blocks), dim3(kThreads), 0, s, a_dev, c_dev, mean_dev, gmean_dev, gvalue_dev, n,
-                       w_actor1_dev, w_actor2_dev, w_critic_dev, da_dev, dc_dev, static_cast<float*>(scratch_dev));
+    if (relu_inputs)
+        hipLaunchKernelGGL(heads_backward_kernel<true>, dim3(blocks), dim3(kThreads), 0, s, a_dev, c_dev, mean_dev, gmean_dev,
+                           gvalue_dev, n, w_actor1_dev, w_actor2_dev, w_critic_dev, da_dev, dc_dev, static_cast<float*>(scratch_dev));
+    else
+        hipLaunchKernelGGL(heads_backward_kernel<false>, dim3(blocks), dim3(kThreads), 0, s, a_dev, c_dev, mean_dev, gmean_dev,
+                           gvalue_dev, n, w_actor1_dev, w_actor2_dev, w_critic_dev, da_dev, dc_dev, static_cast<float*>(scratch_dev));
     hipLaunchKernelGGL(heads_finalize_kernel, dim3((kOut + kFinK - 1) / kFinK), dim3(kFinK * kFinGroups), 0, s,
                        static_cast<const float*>(scratch_dev), blocks, dw_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_policy_heads_backward launch: %s", hipGetErrorString(e));
+    return MRCA_OK;
+}
+
+extern "C" int mrca_relu_cat(const float* h1_dev, const float* goal_dev, const float* speed_dev, int32_t n, float* out_dev,
+                             void* stream) {
+    using namespace mrca_heads;
+    if (!h1_dev || !goal_dev || !speed_dev || !out_dev) return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat: NULL pointer");
+    if (n < 1) return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat: n = %d", n);
+    if (!aligned16(h1_dev) || !aligned16(out_dev) || (reinterpret_cast<uintptr_t>(goal_dev) & 7) || (reinterpret_cast<uintptr_t>(speed_dev) & 7))
+        return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat: h1 / out must be 16-byte, goal / speed 8-byte aligned");
+    mrca::DeviceGuard guard(mrca::device_of(h1_dev));
+    long blocks = ((long)n * (kCat / 4) + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(relu_cat_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(h1_dev), reinterpret_cast<const float2*>(goal_dev),
+                       reinterpret_cast<const float2*>(speed_dev), (long)n, reinterpret_cast<float4*>(out_dev));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_relu_cat launch: %s", hipGetErrorString(e));
+    return MRCA_OK;
+}
+
+extern "C" int mrca_relu_cat_backward(const float* h1_dev, const float* gout_dev, int32_t n, float* dh1_dev, void* stream) {
+    using namespace mrca_heads;
+    if (!h1_dev || !gout_dev || !dh1_dev) return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat_backward: NULL pointer");
+    if (n < 1) return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat_backward: n = %d", n);
+    if (!aligned16(h1_dev) || !aligned16(gout_dev) || !aligned16(dh1_dev))
+        return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat_backward: the three buffers must be 16-byte aligned");
+    mrca::DeviceGuard guard(mrca::device_of(h1_dev));
+    long blocks = ((long)n * (kFc1 / 4) + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(relu_cat_backward_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(h1_dev), reinterpret_cast<const float4*>(gout_dev), (long)n,
+                       reinterpret_cast<float4*>(dh1_dev));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_relu_cat_backward launch: %s", hipGetErrorString(e));
     return MRCA_OK;
 }

@@ -77,12 +77,16 @@ class CNNPolicy(nn.Module):
             fa, fc = policy_ops.lidar_features_fn(
                 x.float(), st(self.act_fea_cv1.weight, self.crt_fea_cv1.weight), st(self.act_fea_cv1.bias, self.crt_fea_cv1.bias),
                 st(self.act_fea_cv2.weight, self.crt_fea_cv2.weight), st(self.act_fea_cv2.bias, self.crt_fea_cv2.bias))
-            a = self._tail("act", fa, goal, speed)
-            c = self._tail("crt", fc, goal, speed)
-            # the three Linear(128, 1) heads with their activations, forward and backward, as row kernels (as library GEMMs
-            # they are ~25 launches and ~200 us of a 16 384-row minibatch: csrc/mrca_policy_heads.hip)
-            return policy_ops.policy_heads(a, c, self.actor1.weight, self.actor1.bias, self.actor2.weight, self.actor2.bias,
-                                           self.critic.weight, self.critic.bias)
+            # behind the front end the layers are the module's own Linear layers (library GEMMs); what sits BETWEEN them runs
+            # as row kernels (csrc/mrca_policy_heads.hip): relu + cat with goal and speed in one launch, fc2's ReLU applied
+            # by the head kernels as they load, the three Linear(128, 1) heads with sigmoid / tanh forward and backward (as
+            # library GEMMs the heads alone are ~25 launches per minibatch)
+            z = []
+            for tw, f in (("act", fa), ("crt", fc)):
+                x2 = policy_ops.relu_cat(getattr(self, f"{tw}_fc1")(f), goal, speed)
+                z.append(getattr(self, f"{tw}_fc2")(x2))
+            return policy_ops.policy_heads(z[0], z[1], self.actor1.weight, self.actor1.bias, self.actor2.weight,
+                                           self.actor2.bias, self.critic.weight, self.critic.bias, relu_inputs=True)
         else:
             a = self._tower("act", x, goal, speed)
             c = self._tower("crt", x, goal, speed)

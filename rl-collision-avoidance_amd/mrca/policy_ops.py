@@ -271,7 +271,7 @@ class _PolicyHeads(torch.autograd.Function):
     row kernels (csrc/mrca_policy_heads.hip) instead of three skinny GEMMs forward and six backward."""
 
     @staticmethod
-    def forward(ctx, a, c, w1, b1, w2, b2, wc, bc):
+    def forward(ctx, a, c, w1, b1, w2, b2, wc, bc, relu_inputs=False):
         lib = _lib.load()
         n = a.shape[0]
         a, c = a.detach().contiguous(), c.detach().contiguous()
@@ -284,10 +284,11 @@ class _PolicyHeads(torch.autograd.Function):
         value = torch.empty(n, 1, dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device):
             stream = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
-            _lib.check(lib.mrca_policy_heads(a.data_ptr(), c.data_ptr(), n, *[t.data_ptr() for t in ws], mean.data_ptr(),
-                                             value.data_ptr(), stream), "mrca_policy_heads")
+            _lib.check(lib.mrca_policy_heads(a.data_ptr(), c.data_ptr(), n, *[t.data_ptr() for t in ws], int(bool(relu_inputs)),
+                                             mean.data_ptr(), value.data_ptr(), stream), "mrca_policy_heads")
         ctx.save_for_backward(a, c, mean, ws[0], ws[2], ws[4])
         ctx.shapes = (w1.shape, b1.shape, w2.shape, b2.shape, wc.shape, bc.shape)
+        ctx.relu_inputs = bool(relu_inputs)
         return mean, value
 
     @staticmethod
@@ -305,14 +306,51 @@ class _PolicyHeads(torch.autograd.Function):
             _lib.check(lib.mrca_policy_heads_backward(a.data_ptr(), c.data_ptr(), mean.data_ptr(),
                                                       None if gmean is None else gmean.data_ptr(),
                                                       None if gvalue is None else gvalue.data_ptr(), n, w1.data_ptr(), w2.data_ptr(),
-                                                      wc.data_ptr(), da.data_ptr(), dc.data_ptr(), dw.data_ptr(), scratch.data_ptr(),
-                                                      scratch.numel(), stream), "mrca_policy_heads_backward")
+                                                      wc.data_ptr(), int(ctx.relu_inputs), da.data_ptr(), dc.data_ptr(), dw.data_ptr(),
+                                                      scratch.data_ptr(), scratch.numel(), stream), "mrca_policy_heads_backward")
         s = ctx.shapes
         return (da, dc, dw[0:128].view(s[0]), dw[384:385].view(s[1]), dw[128:256].view(s[2]), dw[385:386].view(s[3]),
-                dw[256:384].view(s[4]), dw[386:387].view(s[5]))
+                dw[256:384].view(s[4]), dw[386:387].view(s[5]), None)
 
 
-def policy_heads(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic):
-    """-> (mean [n,2], value [n,1]) of the three output heads, differentiable with respect to all eight arguments (include/
-    mrca_env.h: mrca_policy_heads / _backward)."""
-    return _PolicyHeads.apply(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic)
+def policy_heads(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic, relu_inputs=False):
+    """-> (mean [n,2], value [n,1]) of the three output heads, differentiable with respect to the first eight arguments
+    (include/mrca_env.h: mrca_policy_heads / _backward).  ``relu_inputs``: ``a`` / ``c`` are fc2's outputs BEFORE their ReLU --
+    the kernels apply it (and its mask on the way back)."""
+    return _PolicyHeads.apply(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic, relu_inputs)
+
+
+class _ReluCat(torch.autograd.Function):
+    """[relu(h1), goal, speed] (model/net.py:43-45) and dh1 = gout[:, :256] where h1 > 0, one launch each."""
+
+    @staticmethod
+    def forward(ctx, h1, goal, speed):
+        lib = _lib.load()
+        n = h1.shape[0]
+        h1, goal, speed = h1.detach().contiguous(), goal.detach().contiguous(), speed.detach().contiguous()
+        for t, shape in ((h1, (n, 256)), (goal, (n, 2)), (speed, (n, 2))):
+            if not (t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == shape and t.device == h1.device):
+                raise ValueError("relu_cat: expected cuda float32 tensors h1 [n,256], goal [n,2], speed [n,2] on one device")
+        out = torch.empty(n, 260, dtype=torch.float32, device=h1.device)
+        with torch.cuda.device(h1.device):
+            stream = C.c_void_p(torch.cuda.current_stream(h1.device).cuda_stream)
+            _lib.check(lib.mrca_relu_cat(h1.data_ptr(), goal.data_ptr(), speed.data_ptr(), n, out.data_ptr(), stream), "mrca_relu_cat")
+        ctx.save_for_backward(h1)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (h1,) = ctx.saved_tensors
+        gout = gout.contiguous()
+        dh1 = torch.empty_like(h1)
+        with torch.cuda.device(h1.device):
+            stream = C.c_void_p(torch.cuda.current_stream(h1.device).cuda_stream)
+            _lib.check(lib.mrca_relu_cat_backward(h1.data_ptr(), gout.data_ptr(), h1.shape[0], dh1.data_ptr(), stream),
+                       "mrca_relu_cat_backward")
+        return dh1, None, None
+
+
+def relu_cat(h1, goal, speed):
+    """-> f32[n,260] = cat(relu(h1), goal, speed); differentiable with respect to ``h1`` (goal and speed are data)."""
+    return _ReluCat.apply(h1, goal, speed)

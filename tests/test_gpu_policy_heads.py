@@ -91,3 +91,46 @@ def test_mean_value_with_the_head_kernels_equals_the_stock_layers(built):
     for k, gref in grads[False][2].items():
         gf = grads[True][2][k]
         assert float((gf - gref).norm()) <= 2e-3 * float(gref.norm()) + 1e-6, k
+
+
+@pytest.mark.parametrize("n", [1, 3, 257, 16384])
+def test_heads_that_apply_fc2s_relu_themselves(built, n):
+    """relu_inputs = 1: policy_heads(z_a, z_c) == policy_heads(relu(z_a), relu(z_c)) forward, and backward the gradients with
+    respect to the PRE-activations (the ReLU's mask applied inside), bit for bit against the two-step form."""
+    from mrca import policy_ops
+    g = torch.Generator(device="cuda").manual_seed(7 * n)
+    ws = [torch.randn(1, 128, device="cuda", generator=g) * 0.2 for _ in range(3)]
+    bs = [torch.randn(1, device="cuda", generator=g) for _ in range(3)]
+    za, zc = torch.randn(n, 128, device="cuda", generator=g), torch.randn(n, 128, device="cuda", generator=g)
+    za[0, :4] = 0.0                                                  # relu'(0) = 0, as threshold_backward has it
+    gm, gv = torch.randn(n, 2, device="cuda", generator=g), torch.randn(n, 1, device="cuda", generator=g)
+    res = []
+    for inside in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (za, zc, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])]
+        a, c = (leaves[0], leaves[1]) if inside else (torch.relu(leaves[0]), torch.relu(leaves[1]))
+        mean, value = policy_ops.policy_heads(a, c, *leaves[2:], relu_inputs=inside)
+        ((mean * gm).sum() + (value * gv).sum()).backward()
+        res.append((mean.detach(), value.detach(), [t.grad for t in leaves]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for p, q in zip(res[0][2], res[1][2]):
+        assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("n", [1, 5, 16384])
+def test_relu_cat_equals_relu_then_cat(built, n):
+    from mrca import policy_ops
+    g = torch.Generator(device="cuda").manual_seed(n)
+    h1 = torch.randn(n, 256, device="cuda", generator=g)
+    h1[0, :3] = 0.0
+    goal, speed = torch.randn(n, 2, device="cuda", generator=g), torch.rand(n, 2, device="cuda", generator=g)
+    gout = torch.randn(n, 260, device="cuda", generator=g)
+    a = h1.clone().requires_grad_(True)
+    b = h1.clone().requires_grad_(True)
+    out = policy_ops.relu_cat(a, goal, speed)
+    ref = torch.cat((torch.relu(b), goal, speed), dim=-1)
+    assert out.shape == (n, 260) and torch.equal(out, ref)
+    (out * gout).sum().backward()
+    (ref * gout).sum().backward()
+    assert torch.equal(a.grad, b.grad)
+    with pytest.raises(ValueError):
+        policy_ops.relu_cat(h1[:, :128], goal, speed)
