@@ -152,3 +152,39 @@ def test_recorded_gemm_choices_are_a_no_op_without_a_gpu(monkeypatch):
     assert gemm_tuning.use_recorded_choices() is False
     rows = [ln.split(",") for ln in open(gemm_tuning.DEFAULT_FILE) if ln.startswith("Gemm")]
     assert len(rows) >= 10 and all(len(r) == 4 and float(r[3]) > 0 for r in rows)
+
+
+def test_one_frame_buffer_row_indices_follow_the_deque_rule():
+    """The rule the one-frame buffer's row indices follow -- and that csrc/mrca_rollout_store.hip restates on the device
+    (tests/test_gpu_trainer.py holds the two bit-identical): the newest frame of tick t lives in row t + F - 1; tick 0 of a
+    horizon sees rows 0 .. F-1; a robot that restarted sees F times its fresh scan (ppo_stage1.py:59-60: the deque is refilled
+    with the first observation); everybody else drops its oldest row and appends the new one (ppo_stage1.py:87-89)."""
+    from mrca import ppo
+    T, N, F, B = 9, 5, 3, 8
+    rng = np.random.default_rng(3)
+    buf = ppo.RolloutBuffer(T, N, F, B, torch.device("cpu"), single_frame=True)
+    first = torch.arange(N * F * B, dtype=torch.float32).view(N, F, B)
+    buf.begin_horizon(first)
+    want = np.zeros((T, N, F), dtype=np.int64)
+    cur = np.tile(np.arange(F), (N, 1))
+    fresh_log = []
+    for t in range(T):
+        fresh = rng.random(N) < 0.3
+        fresh_log.append(fresh)
+        row = t + F - 1
+        if t == 0:
+            cur = np.tile(np.arange(F), (N, 1))
+        else:
+            shifted = np.concatenate([cur[:, 1:], np.full((N, 1), row)], axis=1)
+            cur = np.where(fresh[:, None], row, shifted)
+        want[t] = cur
+        newest = torch.full((N, B), float(100 + t))
+        z2, z1 = torch.zeros(N, 2), torch.zeros(N, 1)
+        buf.store_state_at(torch.tensor([t]), None, z2, z2, z2, z1, z1, torch.from_numpy(fresh.astype(np.uint8)), newest=newest)
+    assert np.array_equal(buf.fidx.numpy(), want)
+    assert torch.equal(buf.frames[:F - 1], first[:, :F - 1].transpose(0, 1))          # the older frames of the first tick's stack
+    assert all(float(buf.frames[t + F - 1, 0, 0]) == 100 + t for t in range(T))
+    stacks = buf.obs_rows().materialise()                                            # [T, N, F, B]
+    t, n = 4, int(np.argmax(fresh_log[4])) if fresh_log[4].any() else 0
+    if fresh_log[4].any():
+        assert float(stacks[t, n, 0, 0]) == float(stacks[t, n, F - 1, 0]) == 104.0    # restarted: F copies of its fresh scan
