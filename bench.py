@@ -44,6 +44,46 @@ B_ENV_STRICT = 4 * 512 + 92                    # SURVEY 8(d) B_env: ONE 2 kB row
 RAY_BYTES_PER_AGENT_STEP = 4 * 512 + 48        # per LAUNCH: the scan row written; pose / head / goal / flags read, local goal
 MOVE_BYTES_PER_AGENT_STEP = 140                # per LAUNCH: pose, speeds, goal, counters, flags, head record read + written
 BYTES_PER_AGENT_STEP = RAY_BYTES_PER_AGENT_STEP + MOVE_BYTES_PER_AGENT_STEP    # both launches of the tick = 2236
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (the reference's precision: model/net.py is fp32)
+
+
+def policy_flops(beams=512, frames=3, act=2):
+    """FLOPs (2 per multiply-add) of ONE forward pass of CNNPolicy for one sample, both towers, counted from the layer shapes of
+    model/net.py:19-33: conv1 (frames -> 32, k 5, s 2, p 1), conv2 (32 -> 32, k 3, s 2, p 1), fc1 (32 x L2 -> 256), fc2
+    (256 + 2 + 2 -> 128), heads (128 -> 1 twice for the actor, 128 -> 1 for the critic).  512 beams: 6.39 MFLOP (6.4)."""
+    l1 = (beams + 2 - 5) // 2 + 1           # 255
+    l2 = (l1 + 2 - 3) // 2 + 1              # 128
+    tower = 2 * (frames * 5 * 32 * l1 + 32 * 3 * 32 * l2 + 32 * l2 * 256 + (256 + 2 + act) * 128)
+    return 2 * tower + 2 * 128 * (act + 1)
+
+
+def flop_roofline(value, flop_per_agent_step, what, kernels=None):
+    """The `roofline` block of a figure whose work is the policy's matrix arithmetic: fp32 on the MFMA pipes (the reference
+    trains and acts in fp32, so the roof is the fp32 matrix peak, not bf16's).  `achieved` = model FLOPs of the WHOLE figure
+    (env kernels, sampling, gathers, optimiser and launch gaps all inside the measured time) -- a lower bound on what the
+    matrix kernels themselves reach; `kernels`: the heaviest kernels' own rates from the committed rocprofv3 summaries."""
+    tf = value * flop_per_agent_step / 1e12
+    out = {"bound": "fp32_mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+           "flop_per_agent_step": flop_per_agent_step, "what": what}
+    if kernels:
+        out["kernels"] = kernels
+    return out
+
+
+# the heaviest kernels of the rollout tick / of one PPO minibatch, from the committed rocprofv3 --kernel-trace --stats
+# summaries (average duration per call at 4096 robots / 16 384-row minibatches; FLOPs from policy_flops()'s layer terms)
+def _kernel_rates():
+    l1, l2 = 255, 128
+    conv = 2 * 2 * (3 * 5 * 32 * l1 + 32 * 3 * 32 * l2)       # both towers, per sample
+    fc1 = 2 * 2 * 32 * l2 * 256
+
+    def row(name, us, flop, n, src):
+        tf = flop * n / (us * 1e-6) / 1e12
+        return {"kernel": name, "avg_us": us, "tflops": tf, "frac": tf / FP32_MFMA_PEAK_TFLOPS, "source": src}
+    roll = [row("fc1 GEMM (hipBLASLt, both towers batched)", 123.4, fc1, 4096, "profiles/r05_y_rollout_kernel_stats.csv"),
+            row("lidar_features_kernel<true> (conv1 + conv2, fp32 MFMA)", 86.9, conv, 4096, "profiles/r05_y_rollout_kernel_stats.csv")]
+    train = [row("lidar_features_bwd_kernel (conv1 + conv2 backward)", 748.0, 2 * conv, 16384, "profiles/r05_final6_train_kernel_stats.csv")]
+    return roll, train
 
 
 def code_only(src):
@@ -262,6 +302,9 @@ class TickSchedule:
 
 
 def action_pool(N, dev, seed, depth=16):
+    """`depth` action batches v~U(0,1), w~U(-1,1) (the clipped range, ppo_stage1.py:170); tick k of a schedule takes entry
+    k % depth.  bench.py makes the pool as deep as the region it times (<= 1024), so the actions are i.i.d. per tick as
+    SURVEY 8(d) says; 32 kB per entry at 4096 robots."""
     gen = torch.Generator(device=dev).manual_seed(seed)
     return [torch.stack([torch.rand(N, generator=gen, device=dev),
                          torch.rand(N, generator=gen, device=dev) * 2 - 1], 1).contiguous() for _ in range(depth)]
@@ -274,7 +317,7 @@ def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note="", schedule=
     from mrca.vec_env import VecStageWorld
     env = VecStageWorld(sc, lazy_obs=lazy_obs)
     try:
-        pool = action_pool(sc.num_robots, env.device, seed)
+        pool = action_pool(sc.num_robots, env.device, seed, depth=max(16, min(1024, 32 + ticks)) if schedule != "graph" else 16)
         sched = TickSchedule(env, pool, chains=chains, graph=schedule == "graph", native=schedule == "native")
         env.reset()
         for k in range(3):
@@ -519,7 +562,8 @@ def main():
     env = VecStageWorld(sc)
     N = sc.num_robots
     dev = env.device
-    pool = action_pool(N, dev, 1 + rank)
+    # one entry per tick of warm-up + timed region (<= 1024): the actions are i.i.d. per tick, not a 16-deep loop
+    pool = action_pool(N, dev, 1 + rank, depth=max(16, min(1024, args.warmup + args.steps)) if args.mode == "env" else 16)
 
     def barrier():
         if dist is not None:
@@ -653,7 +697,10 @@ def main():
         n_roll = 400                        # (the region `--mode rollout` times by default: 40 warm-up ticks, 400 timed)
         roll.run_ticks(n_roll)
         torch.cuda.synchronize()
-        extra["rollout_side_figure"] = {"value": N * n_roll / (time.perf_counter() - tr0), "unit": "agent-steps/s",
+        v_roll = N * n_roll / (time.perf_counter() - tr0)
+        extra["rollout_side_figure"] = {"value": v_roll, "unit": "agent-steps/s",
+                                        "roofline": flop_roofline(v_roll, policy_flops(), "one fp32 CNNPolicy forward per agent-step "
+                                                                  "(SURVEY 8d (ii))", _kernel_rates()[0]),
                                         "note": "env + fp32 CNNPolicy inference per tick (HIP conv front end, fc1 as a batched "
                                                 "GEMM -- " + ("recorded TunableOp choice" if recorded else "library default heuristic") +
                                                 " --, tail kernel; ticks replayed as hipGraphs of eight), 400 ticks after 40 "
@@ -747,9 +794,11 @@ def main():
                              backend=dist.get_backend() if dist is not None else None, cpu_baseline_fn=cpu_baseline)
         print(json.dumps(line))
 
-    # multi-GPU side figure: a few PPO updates with the flat-bucket gradient all-reduce on the measured path
-    # (the env tick itself needs no collective, so `value` alone would never touch RCCL)
-    if world_size > 1 and args.mode == "env" and not args.no_extra:
+    # SURVEY 8d (iii), the full training loop, as a side figure at EVERY N (at N > 1 it is also what puts RCCL on the measured
+    # path: the env tick itself needs no collective, so `value` alone would never touch it): `--mode train`'s configuration --
+    # horizon 128 (ppo_stage1.py:24), two epochs (:30), minibatches of 16 384 rows per rank, fp32, the rollout tick as a
+    # hipGraph, the update through the HIP front end / loss / heads / Adam kernels -- one warm-up update, then two timed.
+    if args.mode == "env" and not args.no_extra and not args.fidelity:
         # (the first time RCCL runs on this code is the driver's SCALE run: a collective that never answers must not cost
         # the run its line -- after SIDE_FIGURE_TIMEOUT_S rank 0 prints the line without the side figure and every rank
         # leaves; `value` and the per-rank rates above are final before this starts)
@@ -768,26 +817,38 @@ def main():
                     emit()
                 sys.stdout.flush()
             os._exit(0)      # every rank's own watchdog does the same at the same time: nobody is left in a collective
-        threading.Thread(target=give_up, daemon=True).start()
+        if world_size > 1:
+            threading.Thread(target=give_up, daemon=True).start()
         try:
+            from mrca import gemm_tuning
             from mrca.trainer import HParams, Stage1Trainer
-            hp = HParams(horizon=16, batch_size=16384, epoch=1)
+            recorded = (not args.no_gemm_choices) and gemm_tuning.use_recorded_choices()
+            hp = HParams(batch_size=16384, rollout_fused=True, graph_tick=True, update_fused=True)
             tr = Stage1Trainer(env, hp=hp, dist=dist, seed=0, stage2=False)
             tr.started = True
-            tr.run(hp.horizon)                       # one warm-up update (MIOpen / allocator / RCCL set-up)
+            tr.run(hp.horizon)                       # one warm-up update (MIOpen / allocator / RCCL set-up, graph captures)
             barrier()
             tt0 = time.perf_counter()
             n_upd = 2
             tr.run(n_upd * hp.horizon)
             barrier()
             dt_tr = time.perf_counter() - tt0
+            v_tr = N * world_size * n_upd * hp.horizon / dt_tr
+            # model FLOPs per agent-step: the rollout's forward + per epoch a forward and a backward (2 x forward) of the update
+            f_step = policy_flops() * (1 + 3 * hp.epoch)
             side = {
-                "value": N * world_size * n_upd * hp.horizon / dt_tr, "unit": "agent-steps/s",
-                "collective": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                               "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
-                               "optimizer_steps": len(tr.loss_log) - len(tr.loss_log) // (n_upd + 1)},
-                "note": "env + fp32 policy + GAE + PPO update (horizon 16, one epoch, minibatch 16384 per rank), every "
-                        "optimiser step all-reduces the flat gradient bucket; not part of `value`"}
+                "value": v_tr, "unit": "agent-steps/s",
+                "roofline": flop_roofline(v_tr / world_size, f_step, f"per GPU: rollout forward + {hp.epoch} epochs x (forward + backward) "
+                                          "of the PPO update (SURVEY 8d (iii)); the last-value forward per horizon is not counted",
+                                          _kernel_rates()[1]),
+                "hparams": {"horizon": hp.horizon, "epoch": hp.epoch, "minibatch_per_rank": hp.batch_size, "dtype": "f32",
+                            "gemm_choices": "recorded TunableOp choices" if recorded else "library default heuristic"},
+                "collective": (None if dist is None else
+                               {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                "gradient_bucket_bytes": int(tr.flat_grads.flat.numel() * 4),
+                                "optimizer_steps": len(tr.loss_log) - len(tr.loss_log) // (n_upd + 1)}),
+                "note": "env + fp32 policy + GAE + PPO update (ppo_stage1.py's horizon and epochs, minibatch 16384 per rank); at "
+                        "N > 1 every optimiser step all-reduces the flat gradient bucket; not part of `value`"}
         except Exception as exc:      # a failure every rank shares (set-up, memory) must not cost the run its line
             side = {"error": f"{type(exc).__name__}: {exc}"[:400]}
         with emit_lock:               # timeout versus done is decided under the lock the line is printed under

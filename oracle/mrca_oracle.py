@@ -13,6 +13,14 @@ PARITY STATUS
     The four qualitative rostest assertions the reference does hold
     (stage_ros-add_pose_and_crash/test/cmdpose_tests.py:87-203) are restated in
     tests/test_oracle_invariants.py.
+    PINNED since round 6 by the one libstage-rendered artefact in the checkout, doc/stage2.gif (Stage's own GUI,
+    23 frames of worlds/stage2.world; tools/make_golden_gif.py -> tests/golden/stage_gui_stage2.npz,
+    tests/test_golden_gui.py): bitmap bounding box -> ``size`` scaling, image row 0 = +y, floorplan centred on its pose;
+    polygon obstacles rescaled to ``size`` on their pose; the 0.44 x 0.38 footprint centred on the pose; cmd_pose = teleport
+    onto the table poses; 'Reach Goal' inside 0.5 m of the robot's own table goal; displacement per tick = v x 0.1 s with
+    v <= 1 as a hard ceiling; heading in degrees CCW from +x with motion along it.
+    STILL UNPINNED (nothing in a GUI picture shows them): the order of operations inside one tick, Stage's raster
+    collision test (fidelity mode's shared-cell rule), the quantisation of ranges to raster cells.
   * env tick, Python half (reward / terminal, observation, local goal, episode set-up, reset
     distributions): follows the reference's Python line by line (citations on each function) and is
     PINNED by golden vectors made by running the reference's own stage_world1.py / stage_world2.py /

@@ -256,9 +256,13 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
 _heads_scratch = {}
 
 
-def _heads_backward_scratch(device):
-    key = (device.type, device.index)
+def _heads_backward_scratch(device, stream):
+    """The partial records between the heads' backward and finalize kernels: one buffer per (device, STREAM), like the loss
+    kernel's -- two trainers, rank threads or side streams of one process must not overwrite each other's partials."""
+    key = (device.type, device.index, int(stream))
     if key not in _heads_scratch:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("policy_heads backward: first use on this stream inside a graph capture -- call it once before capturing")
         lib = _lib.load()
         n = C.c_size_t()
         _lib.check(lib.mrca_policy_heads_backward_scratch(C.byref(n)), "mrca_policy_heads_backward_scratch")
@@ -302,7 +306,7 @@ class _PolicyHeads(torch.autograd.Function):
         dw = torch.empty(3 * 128 + 3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            scratch = _heads_backward_scratch(dev)
+            scratch = _heads_backward_scratch(dev, stream.value or 0)
             _lib.check(lib.mrca_policy_heads_backward(a.data_ptr(), c.data_ptr(), mean.data_ptr(),
                                                       None if gmean is None else gmean.data_ptr(),
                                                       None if gvalue is None else gvalue.data_ptr(), n, w1.data_ptr(), w2.data_ptr(),

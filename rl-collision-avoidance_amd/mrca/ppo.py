@@ -476,6 +476,16 @@ class _ObsPrefetch:
         self._issue(k + 1)
         return x
 
+    def close(self):
+        """Leaving the minibatch loop (normally or on a KL early stop): a gather issued ahead and never taken still reads the
+        permutation slices on the side stream -- the main stream waits for it before that memory can be handed out again,
+        and the prefetched stacks are dropped."""
+        if self.on and self.ready:
+            self.main.wait_stream(self.side)
+            for x in self.ready.values():
+                x.record_stream(self.main)
+            self.ready.clear()
+
 
 def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_value, drop_last, value_coef,
                 index_batches, dist, flat_grads, log, autocast_dtype=None, kl_ctl=None, max_grad_norm=0.0,
@@ -566,6 +576,7 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
                 log.append((policy_loss.detach(), value_loss.detach(), dist_entropy.detach()))
             if stop:
                 break
+        fetch.close()
         if kl_ctl is not None and n_done:
             kl_ctl.step(optimizer, kl_sum, n_done, dist)
         if stop:

@@ -222,6 +222,13 @@ class Stage1Trainer:
         return None if self.kl_ctl is None else self.kl_ctl.last_kl
 
     def run(self, ticks):
+        """``ticks`` ticks, eight per graph replay where they fit inside the horizon, ``tick()`` for the rest.
+
+        Reproducibility: with ``hp.graph_tick`` an eight-tick replay draws its sampling noise with ONE randn(8, N, 2), a
+        single tick with randn(N, 2); the generator maps Philox offsets to elements by launch shape, so the two are
+        different noise streams of the same seed.  A rollout is reproduced by the same seed, generator state AND the same
+        grouping of ticks (same ``run`` arguments from the same ``t``); ``run()`` and ``tick()`` must not be mixed where
+        value-for-value replay matters -- mrca/train.py drives ``tick()`` only, bench.py ``run()`` only."""
         if not self.started:
             self.start()
         env, hp = self.env, self.hp
@@ -275,7 +282,8 @@ def make_bench_step(env, mode, dist, batch_size=16384, inference_dtype=None, upd
         # the previous tick's kernels: 265 vs 256 us per tick with one tick per replay, profiles/r04_v_bench_rollout*.json),
         # so a run of n ticks replays the long graph n // 8 times and the short one for the remainder
         # the sampling noise of all the ticks of a replay is drawn by ONE launch at its head (a randn of 8192 numbers is a
-        # 5 us launch of its own in a 250 us tick; the draws are the generator's next ticks x N x 2 normals either way)
+        # 5 us launch of its own in a 250 us tick).  NOT the same numbers as eight one-tick draws: the generator's Philox
+        # offset -> element mapping depends on the launch's shape, so g8 and g1 are two different noise streams of one seed)
         def capture(ticks):
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(tr.gen)

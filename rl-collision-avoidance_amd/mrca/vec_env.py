@@ -6,6 +6,7 @@ One instance owns one libmrca_env handle on one GPU.  Every reference getter
 once.  torch is used for device memory and streams only; all arithmetic runs in the HIP library.
 """
 import ctypes as C
+import operator
 
 import numpy as np
 import torch
@@ -284,13 +285,15 @@ class VecStageWorld:
         device tensors: a scripted scenario, the benchmark's action pool); ``chains`` world ranges tick on streams of their
         own, half a tick apart (mrca_step_many).  Equal to ``num_ticks`` calls of ``step``."""
         # (the pointer table of a list is built once per list object: a 20-tick region is 0.6 ms, sixteen data_ptr() calls and
-        # their checks are 2 % of it)
+        # their checks are 2 % of it.  The entry keeps the tensors themselves: an element replaced in place -- pool[i] = t --
+        # fails the identity compare below and rebuilds the table, and a table never outlives the memory it points at)
         cache = self.__dict__.setdefault("_many_ptrs", {})
         entry = cache.get(id(actions))
-        if entry is None or entry[0] is not actions or len(actions) != entry[2]:
+        if entry is None or entry[0] is not actions or len(actions) != entry[2] or \
+                not all(map(operator.is_, actions, entry[3])):
             ptrs = [self._ptr(t, torch.float32, self.N * 2).value for t in actions]
             cache.clear()
-            entry = cache[id(actions)] = (actions, (C.c_void_p * len(actions))(*ptrs), len(actions))
+            entry = cache[id(actions)] = (actions, (C.c_void_p * len(actions))(*ptrs), len(actions), tuple(actions))
         rc = self.lib.mrca_step_many(self._h, entry[1], entry[2], int(first_tick), int(num_ticks), int(chains), self._stream())
         if rc:
             _lib.check(rc, "mrca_step_many")

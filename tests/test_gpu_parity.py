@@ -464,6 +464,46 @@ def test_full_batch_bit_exact_vs_c_oracle(hip, name, worlds, R, steps):
     env.close()
 
 
+@pytest.mark.parametrize("name,worlds,R,ticks", [("stage1", 128, 32, 400), ("stage2", 187, 44, 400),
+                                                 ("stage1_fidelity", 128, 32, 200)])
+def test_soak_at_the_benchmarks_own_shape(hip, name, worlds, R, ticks):
+    """The benchmark's OWN shape, long: BASELINE configs[1] / configs[2] at full size through the schedule bench.py times
+    (one mrca_step_many call per 50 ticks, two world ranges half a tick apart on two streams, actions drawn i.i.d. per tick)
+    for hundreds of ticks against the C oracle stepping the same actions tick by tick -- every field of every robot compared
+    every 50 ticks.  Long enough that every Stage-1 robot goes through at least two whole episodes (crash or the t > 150
+    time-out, then the in-kernel restart with fresh Philox draws) and every Stage-2 group restarts several times."""
+    import bench
+    fid = name.endswith("_fidelity")
+    sc = S.stage1(num_worlds=worlds, robots_per_world=R, seed=77, stage_resolution=fid) if name.startswith("stage1") else \
+        S.stage2(num_worlds=worlds, seed=77, stage_resolution=fid)
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    pool = bench.action_pool(sc.num_robots, env.device, 7, depth=ticks)
+    host_pool = [a.cpu().numpy() for a in pool]
+    sched = bench.TickSchedule(env, pool, chains=2, native=True)
+    env.reset()
+    ora.reset()
+    torch.cuda.synchronize()
+    U.assert_state_equal(U.HostView(env), ora, what=f"{name} soak reset")
+    timeouts = 0
+    for first in range(0, ticks, 50):
+        sched.run(first, 50)
+        for k in range(first, first + 50):
+            ora.step(host_pool[k])
+            timeouts += int((np.asarray(ora.result) == 3).sum())
+        torch.cuda.synchronize()
+        U.assert_state_equal(U.HostView(env), ora, what=f"{name} soak after {first + 50} scheduled ticks")
+    U.assert_hits_equal(env, ora, what=f"{name} soak, final tick")
+    env.check()
+    ep = np.asarray(ora.episode)
+    if name.startswith("stage1"):
+        assert ep.min() >= (2 if ticks >= 400 else 1), ep.min()
+    else:
+        assert ep.min() >= 2, ep.min()               # every group restarted at least twice
+    assert timeouts > 0                               # and the time-out path ran
+    env.close()
+
+
 @pytest.mark.parametrize("knob,label", [(256, "1 beam per thread"), (512, "2 beams per thread, one after the other"),
                                         (512 + 4096, "2 beams per thread in lock step"),
                                         (768, "4 beams per thread, one after the other (2 waves per workgroup)"),

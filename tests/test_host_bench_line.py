@@ -85,6 +85,45 @@ def test_eight_rank_line_carries_the_scale_evidence():
     assert d["roofline"]["value_at_kernel_sum"] > d["value"] / 2
 
 
+def test_flop_model_and_the_side_figures_rooflines():
+    """the rollout and train side figures carry a FLOP roofline of their own -- fp32 MFMA peak, FLOPs
+    counted from the layer shapes of model/net.py:19-33 (checked here against an actual CNNPolicy's parameter shapes)."""
+    from mrca.net import CNNPolicy
+    pol = CNNPolicy(frames=3, action_space=2, beams=512)
+    sd = pol.state_dict()
+    l1, l2 = 255, 128
+    macs = 0
+    for tower in ("act", "crt"):
+        w1, w2 = sd[f"{tower}_fea_cv1.weight"], sd[f"{tower}_fea_cv2.weight"]
+        macs += w1.numel() * l1 + w2.numel() * l2 + sd[f"{tower}_fc1.weight"].numel() + sd[f"{tower}_fc2.weight"].numel()
+    macs += sd["actor1.weight"].numel() + sd["actor2.weight"].numel() + sd["critic.weight"].numel()
+    assert bench.policy_flops() == 2 * macs == 6390656
+    r = bench.flop_roofline(16.8e6, bench.policy_flops(), "test", bench._kernel_rates()[0])
+    assert r["bound"] == "fp32_mfma" and r["peak"] == 157.3 and r["unit"] == "TFLOP/s"
+    assert abs(r["achieved"] - 16.8e6 * 6390656 / 1e12) < 1e-9 and abs(r["frac"] - r["achieved"] / 157.3) < 1e-12
+    assert 0.6 < r["frac"] < 0.75                                       # round 5's 16.8 M = 68 % of the fp32 roof
+    assert all(set(k) >= {"kernel", "avg_us", "tflops", "frac", "source"} and os.path.exists(os.path.join(ROOT, k["source"]))
+               for k in r["kernels"])
+    t = bench.flop_roofline(2.4e6, bench.policy_flops() * (1 + 3 * 2), "test", bench._kernel_rates()[1])
+    assert 0.65 < t["frac"] < 0.72                                      # round 5's 2.40 M = 68 %
+    extra = {"rollout_side_figure": {"value": 16.8e6, "unit": "agent-steps/s", "roofline": r},
+             "train_side_figure": {"value": 2.4e6, "unit": "agent-steps/s", "roofline": t, "collective": None,
+                                   "hparams": {"horizon": 128, "epoch": 2, "minibatch_per_rank": 16384, "dtype": "f32"}}}
+    d = json.loads(json.dumps(_line(1, extra)))
+    assert d["train_side_figure"]["roofline"]["bound"] == "fp32_mfma" and d["rollout_side_figure"]["roofline"]["kernels"]
+
+
+def test_the_action_pool_is_as_deep_as_the_region_it_serves():
+    """actions i.i.d. per step -- the pool holds one batch per tick of the region (bench.main / env_side_figure ask
+    for warm-up + steps entries, at most 1024), and tick k takes entry k % depth"""
+    import torch
+    pool = bench.action_pool(64, torch.device("cpu"), 3, depth=120)
+    assert len(pool) == 120 and all(p.shape == (64, 2) and p.dtype == torch.float32 for p in pool)
+    flat = torch.stack(pool)
+    assert (flat[..., 0] >= 0).all() and (flat[..., 0] < 1).all() and (flat[..., 1] >= -1).all() and (flat[..., 1] < 1).all()
+    assert len({tuple(p[0].tolist()) for p in pool}) == 120            # no entry repeats
+
+
 def test_the_gradient_bucket_of_the_policy_is_8_69_MB():
     """what the train side figure's collective will report at N > 1: one flat fp32 bucket of every parameter of CNNPolicy"""
     import torch
