@@ -197,11 +197,14 @@ class TickSchedule:
     (mrca_step_worlds), so the result is the one-chain result bit for bit (tests/test_gpu_parity.py); what changes is that
     the latency-bound move launch (10 us at 4 % of the chip's issue slots) no longer has the chip to itself."""
 
-    def __init__(self, env, pool, chains=1, graph=True, native=False):
+    def __init__(self, env, pool, chains=1, graph=True, native=False, chained=False):
         # native=True: one mrca_step_many call per run() -- the library enqueues every launch of the ticks itself (two plain
         # streams for two chains, one event to set them half a tick apart): no graph to instantiate, upload or launch, and no
         # Python between the launches
         self.env, self.pool, self.graph, self.native = env, pool, graph and not native, native
+        # native, chained=True: round 5's schedule inside mrca_step_many (chains = -P: one `move, ray, move, ray ...` chain per
+        # world range) instead of round 6's run-ahead schedule (move launches on a stream of their own, ahead of the ray casts)
+        self.chained = chained
         self.chains = max(1, min(int(chains), env.W))
         W, P = env.W, self.chains
         self.ranges = [(c * W // P, (c + 1) * W // P - c * W // P) for c in range(P)]
@@ -210,7 +213,9 @@ class TickSchedule:
         self.sync_every_tick = os.environ.get("MRCA_CHAIN_SYNC", "first") == "every"
         # ticks per hipGraph: a graph forks into the chains at its head and joins them at its end, and the chains are set half
         # a tick apart once per graph -- the longer the graph, the less of a tick that is
-        self.ticks_per_graph = int(os.environ.get("MRCA_TICKS_PER_GRAPH", "64"))
+        # (native: ticks per mrca_step_many call -- the library's run-ahead pass covers up to 256 ticks, and every pass ends with
+        # a join of its streams that costs ~90 us: 64-tick calls were 8 % of a long run)
+        self.ticks_per_graph = int(os.environ.get("MRCA_TICKS_PER_GRAPH", "256" if (native and not chained) else "64"))
 
     @property
     def side(self):
@@ -291,7 +296,7 @@ class TickSchedule:
             # (at most `ticks_per_graph` ticks per call: thousands of launches enqueued at once run the HIP runtime out of its
             # pools, and the region after such a call was measured 15 % slow, profiles/r05_n_*)
             for k, m in self.chunks(first, count):
-                self.env.step_many(self.pool, k, m, self.chains)
+                self.env.step_many(self.pool, k, m, -self.chains if self.chained else self.chains)
         elif not self.graph:
             self.issue(first, count)
         else:
@@ -318,7 +323,8 @@ def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note="", schedule=
     env = VecStageWorld(sc, lazy_obs=lazy_obs)
     try:
         pool = action_pool(sc.num_robots, env.device, seed, depth=max(16, min(1024, 32 + ticks)) if schedule != "graph" else 16)
-        sched = TickSchedule(env, pool, chains=chains, graph=schedule == "graph", native=schedule == "native")
+        sched = TickSchedule(env, pool, chains=chains, graph=schedule == "graph", native=schedule in ("native", "chained"),
+                             chained=schedule == "chained")
         env.reset()
         for k in range(3):
             env.step(pool[k])
@@ -373,6 +379,11 @@ def assemble_line(*, args, sc, N, world_size, value, elapsed, ray_ms, mv_ms, lau
                                      "Python, tick by tick"),
                    "chains": (sched['chains'] if sched is not None else None),
                    "schedule": (None if sched is None else
+                                f"run-ahead (round 6): the move launches of the region's ticks on a stream of their own, each tick "
+                                f"into a slot of its own, ahead of the ray casts of {sched['chains']} world range(s) on "
+                                f"{sched['chains']} stream(s), every ray cast behind the event of its tick's move launch "
+                                "(include/mrca_env.h mrca_step_many, DESIGN.md 5.10)"
+                                if sched['native'] and not sched.get('chained') else
                                 "one chain: move launch, ray cast over all worlds" if sched['chains'] == 1 else
                                 f"{sched['chains']} world ranges half a tick apart (a range's move launch runs next to the "
                                 "previous range's ray cast: mrca_move_worlds / mrca_observe_worlds on two streams / graph "
@@ -481,10 +492,11 @@ def main():
                          "/ graph branch, half a tick apart, so that one range's move launch runs next to another's ray cast "
                          "(TickSchedule; mrca_move_worlds / mrca_observe_worlds).  1 = every tick as two launches over all worlds "
                          "(rounds 1-4).  Default: 2")
-    ap.add_argument("--schedule", default=None, choices=["native", "graph", "eager"],
+    ap.add_argument("--schedule", default=None, choices=["native", "chained", "graph", "eager"],
                     help="env mode: how the timed ticks reach the GPU.  native (default): ONE mrca_step_many call, the library "
-                         "enqueues every launch itself; graph: replayed as hipGraphs captured from Python; eager (= --no-graph): "
-                         "launched tick by tick from Python")
+                         "enqueues every launch itself, the move launches running ahead of the ray casts on a stream of their own "
+                         "(round 6); chained: the same call with round 5's schedule (one move-ray-move-ray chain per world range); "
+                         "graph: replayed as hipGraphs captured from Python; eager (= --no-graph): launched tick by tick from Python")
     ap.add_argument("--graph", action="store_true",
                     help="(the default since round 4; kept for old command lines) env mode: the timed ticks are replayed as "
                          "hipGraphs -- 16 ticks per graph, one per entry of the action pool -- instead of being launched "
@@ -582,7 +594,8 @@ def main():
         # --chains world ranges half a tick apart: TickSchedule above.
         if args.schedule is None:
             args.schedule = "eager" if args.no_graph else ("graph" if args.graph else "native")
-        sched = TickSchedule(env, pool, chains=args.chains, graph=args.schedule == "graph", native=args.schedule == "native")
+        sched = TickSchedule(env, pool, chains=args.chains, graph=args.schedule == "graph",
+                             native=args.schedule in ("native", "chained"), chained=args.schedule == "chained")
         step_fn = None
     else:
         from mrca import gemm_tuning
@@ -789,7 +802,8 @@ def main():
     def _emit():
         line = assemble_line(args=args, sc=sc, N=N, world_size=world_size, value=value, elapsed=elapsed, ray_ms=ray_ms, mv_ms=mv_ms,
                              launches=launches, kernel_timing_note=kernel_timing_note,
-                             sched=None if sched is None else {"graph": sched.graph, "native": sched.native, "chains": sched.chains},
+                             sched=None if sched is None else {"graph": sched.graph, "native": sched.native, "chains": sched.chains,
+                                                               "chained": sched.chained},
                              extra=extra, per_rank=per_rank, ranks_seen=ranks_seen, devices=devices,
                              backend=dist.get_backend() if dist is not None else None, cpu_baseline_fn=cpu_baseline)
         print(json.dumps(line))

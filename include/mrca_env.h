@@ -194,11 +194,18 @@ int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, 
 /* num_ticks ticks of every world from ONE call, with commands that are already on the device (a scripted scenario, a replayed
  * log, the benchmark's action pool): tick k (k = 0 .. num_ticks - 1) takes actions_dev[(first_tick + k) % num_actions], each
  * f32[N,2] as for mrca_step.  Equal, field for field, to num_ticks calls of mrca_step.
- * chains = P > 1: the worlds are dealt to P contiguous ranges, each ticking on a stream of its own (range 0 on `stream`, the
- * others on streams the env creates once and keeps), the ranges set half a tick apart at the start -- range c's first move
- * launch waits for range c - 1's -- so that one range's move launch runs next to another's ray cast; `stream` waits for all
- * of them before the call's work counts as done, and they for everything queued on `stream` before the call.  The host only
- * enqueues (no synchronisation); the call is capturable into a hipGraph like any other.  robots_per_world > 64: P is 1. */
+ * Because every command is known up front, tick k + 1's move launch does not depend on tick k's ray cast -- only on what the
+ * ray cast READS of a move launch: pose, head record, goal, fresh flag, outline.  The call therefore lets the move launches
+ * RUN AHEAD (since round 6): tick 0's goes out on `stream`, the others on a stream the env owns, back to back, each writing
+ * those five fields into a slot of its own (a ring of <= 255 slots beside the arena, 53 B per robot and slot, at most 256 MB; the call's last
+ * tick writes the env's own fields, so MRCA_F_POSE etc. are current when the call's work is done and never in between); the
+ * ray casts of chains = P contiguous world ranges run on P streams (range 0 on `stream`, the others on streams the env created
+ * in mrca_create for P <= 4), tick after tick, each behind the event "tick k's move launch is through".  `stream` waits for
+ * all of them before the call's work counts as done, and they for everything queued on `stream` before the call.  What a tick
+ * then costs is its ray casts alone.  The host only enqueues (no synchronisation, nothing spins on the
+ * device); the call is capturable into a hipGraph like any other (chains > 4: call it once outside the capture first).
+ * chains = -P: round 5's schedule instead -- P chains `move, ray cast, move, ray cast ...` of one world range each, half a tick
+ * apart (kept for A/B runs: tools/region_sweep.py --schedule chained).  robots_per_world > 64: one chain, in order. */
 int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_actions, int32_t first_tick, int32_t num_ticks,
                    int32_t chains, void* stream);
 

@@ -232,7 +232,62 @@ struct mrca_env {
     std::vector<hipStream_t> chain_stream;
     std::vector<hipEvent_t> chain_moved, chain_done;
     hipEvent_t chain_fork = nullptr;
+    // mrca_step_many's run-ahead schedule: the move launches of a call's ticks run on a stream of their own,
+    // AHEAD of the ray casts, each tick writing the five things a ray cast reads of a move launch -- pose, head record, goal,
+    // fresh flag, outline -- into a slot of its own, so that no move launch ever waits for a ray cast.  Slot 0 is the env's
+    // own fields (where a call starts and where its last tick ends); slots 1 .. ahead_slots live in `ahead_mem`.
+    char* ahead_mem = nullptr;
+    size_t ahead_bytes = 0;                 // per slot
+    size_t ahead_off[5] = {0, 0, 0, 0, 0};  // pose, head, goal, fresh, outline inside a slot
+    int ahead_slots = 0;                    // 0: the ring could not be allocated -> the chained schedule
+    hipStream_t move_stream = nullptr;
+    std::vector<hipEvent_t> moved;          // [kAheadTicks] "tick k's move launch is through"
 };
+
+constexpr int kAheadTicks = 256;            // most ticks one run-ahead pass covers (a pass ends with every stream joined: ~90 us)
+constexpr size_t kAheadMaxBytes = 256u << 20;
+constexpr int kChainStreamsAtCreate = 3;    // world ranges 1 .. 3 get their streams in mrca_create (chains <= 4)
+
+// the env's view with slot b's buffers in place of the five fields (b = 0: the env's own)
+static mrca::EnvView slot_view(const mrca_env* env, int b) {
+    mrca::EnvView v = env->view;
+    if (b > 0) {
+        char* base = env->ahead_mem + (size_t)(b - 1) * env->ahead_bytes;
+        v.pose = reinterpret_cast<float*>(base + env->ahead_off[0]);
+        v.head = reinterpret_cast<float4*>(base + env->ahead_off[1]);
+        v.goal = reinterpret_cast<float*>(base + env->ahead_off[2]);
+        v.fresh = reinterpret_cast<uint8_t*>(base + env->ahead_off[3]);
+        if (env->view.outline) v.outline = reinterpret_cast<mrca::OutlineBits*>(base + env->ahead_off[4]);
+    }
+    return v;
+}
+
+// the streams, events and the run-ahead ring an env owns beside its arena (mrca_destroy, and mrca_create when it gives up)
+static void release_side_objects(mrca_env* env) {
+    for (hipEvent_t e : env->ev) (void)hipEventDestroy(e);
+    for (hipStream_t s : env->chain_stream) {
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+    }
+    if (env->move_stream) {
+        (void)hipStreamSynchronize(env->move_stream);
+        (void)hipStreamDestroy(env->move_stream);
+    }
+    for (hipEvent_t e : env->moved)
+        if (e) (void)hipEventDestroy(e);
+    if (env->ahead_mem) (void)hipFree(env->ahead_mem);
+    for (hipEvent_t e : env->chain_moved) (void)hipEventDestroy(e);
+    for (hipEvent_t e : env->chain_done) (void)hipEventDestroy(e);
+    if (env->chain_fork) (void)hipEventDestroy(env->chain_fork);
+    env->ev.clear();
+    env->chain_stream.clear();
+    env->moved.clear();
+    env->chain_moved.clear();
+    env->chain_done.clear();
+    env->move_stream = nullptr;
+    env->ahead_mem = nullptr;
+    env->chain_fork = nullptr;
+}
 
 extern "C" {
 
@@ -283,6 +338,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
         env->owns_arena = true;
     }
     auto bail = [&](int rc) {
+        release_side_objects(env);
         if (env->owns_arena) (void)hipFree(env->arena);
         delete env;
         return rc;
@@ -481,6 +537,44 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     if (env->lds_bytes > 160 * 1024)
         return bail(fail(MRCA_ERR_UNSUPPORTED, "the ray cast needs %zu B of LDS per robot (> 160 KiB): too many beams",
                          env->lds_bytes));
+    if (!v.big) {
+        // the run-ahead ring of mrca_step_many (outside the arena: a caller-provided arena keeps its documented size).  As many
+        // slots as fit the budget, at most one per tick of a pass; none (allocation failed) = the chained schedule, no error
+        size_t off = 0;
+        const size_t part[5] = {N * 3 * 4, N * sizeof(float4), N * 2 * 4, N, v.outline ? N * sizeof(mrca::OutlineBits) : 0};
+        for (int i = 0; i < 5; ++i) {
+            env->ahead_off[i] = off;
+            off += align_up(part[i]);
+        }
+        env->ahead_bytes = off;
+        size_t slots = kAheadMaxBytes / off;
+        if (slots > (size_t)kAheadTicks - 1) slots = kAheadTicks - 1;
+        if (slots >= 1 && hipMalloc(reinterpret_cast<void**>(&env->ahead_mem), slots * off) == hipSuccess) {
+            env->ahead_slots = (int)slots;
+        } else {
+            (void)hipGetLastError();
+            env->ahead_mem = nullptr;
+        }
+        bool ok = hipStreamCreateWithFlags(&env->move_stream, hipStreamNonBlocking) == hipSuccess;
+        env->moved.assign(kAheadTicks, nullptr);
+        for (auto& e : env->moved) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (int c = 0; c < kChainStreamsAtCreate && ok; ++c) {
+            hipStream_t st = nullptr;
+            hipEvent_t ea = nullptr, eb = nullptr;
+            ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess;
+            if (ok) {
+                env->chain_stream.push_back(st);
+                env->chain_moved.push_back(ea);
+                env->chain_done.push_back(eb);
+            }
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            env->ahead_slots = 0;       // (whatever was created is released by mrca_destroy)
+        }
+    }
     mrca::launch_head_init(v, nullptr);   // head records of the construction-time poses (all at the origin)
     HIP_TRY_BAIL(hipGetLastError());
     HIP_TRY_BAIL(hipDeviceSynchronize());
@@ -491,14 +585,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
 
 int mrca_destroy(mrca_env* env) {
     if (!env) return MRCA_OK;
-    for (hipEvent_t e : env->ev) (void)hipEventDestroy(e);
-    for (hipStream_t s : env->chain_stream) {
-        (void)hipStreamSynchronize(s);
-        (void)hipStreamDestroy(s);
-    }
-    for (hipEvent_t e : env->chain_moved) (void)hipEventDestroy(e);
-    for (hipEvent_t e : env->chain_done) (void)hipEventDestroy(e);
-    if (env->chain_fork) (void)hipEventDestroy(env->chain_fork);
+    release_side_objects(env);
     if (env->owns_arena) HIP_TRY(hipFree(env->arena));
     delete env;
     return MRCA_OK;
@@ -605,6 +692,82 @@ int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, 
     return worlds_impl(env, nullptr, first_world, num_worlds, stream, kPhaseObserve);
 }
 
+// One run-ahead pass of mrca_step_many: K <= ahead_slots + 1 ticks.  Tick k's move launch covers ALL worlds and writes slot
+// w(k) = K - 1 - k (slot 0 = the env's own fields: the pass starts from them and its last tick leaves them current), reading
+// slot w(k - 1); tick 0 goes out on the caller's stream, ticks 1 .. K - 1 on the env's move stream, back to back -- a slot per
+// tick, so a move launch waits for no ray cast.  The ray casts of world range c run on the range's stream (range 0: the
+// caller's), tick after tick, each behind the event "tick k's move launch is through".  Nothing else is ordered: the ray
+// casts are what a tick costs (19.5 us for 4096 robots as two ranges, profiles/r06_a_ray_only_probe.txt), the move launches
+// (8.5 us) run beside them.  Every dependency is a stream order or an event; nothing spins.
+static int run_ahead_pass(mrca_env* env, const float* const* act, int K, int P, hipStream_t s0) {
+    const int W = env->view.W, R = env->view.R;
+    auto stream_of = [&](int c) { return c == 0 ? s0 : env->chain_stream[c - 1]; };
+    auto first_world = [&](int c) { return (int)((int64_t)c * W / P); };
+    hipError_t herr = hipSuccess;
+    bool move_forked = false;
+    // Ticks are enqueued in BLOCKS -- [0], [1], [2, 3], then fours: a block's move launches first, ONE event behind the last of
+    // them, then every range's stream waits for that event once and takes the block's ray casts.  hipStreamWaitEvent is the
+    // dearest call here (4.0 us of host time against 2.35 for a launch, profiles/r06_b_anyorder_probe.txt): a wait per tick
+    // and range made the host 15.8 us per tick against the device's 19.1 -- any hiccup starved the queues.  The move launches
+    // are far ahead of the ray casts from the third tick on (8.5 us against 19 per tick), so waiting for a block's LAST move
+    // launch delays no ray cast; the first two ticks are blocks of their own so that the first ray casts start at once.
+    for (int a = 0; a < K && herr == hipSuccess;) {
+        const int len = a < 2 ? 1 : a < 4 ? 2 : 4;
+        const int e = a + len < K ? a + len : K;
+        hipStream_t sm = a == 0 ? s0 : env->move_stream;
+        if (a == 1) {                       // the move stream starts behind tick 0's move launch (and so behind the caller's work)
+            herr = hipStreamWaitEvent(env->move_stream, env->moved[0], 0);
+            if (herr != hipSuccess) break;
+            move_forked = true;
+        }
+        for (int k = a; k < e; ++k) {
+            mrca::EnvView mv = slot_view(env, K - 1 - k);
+            const mrca::EnvView in = slot_view(env, k == 0 ? 0 : K - k);
+            mv.world_first = 0;
+            mv.world_count = W;
+            mrca::launch_move(mv, act[k], sm, nullptr, nullptr, &in);
+        }
+        herr = hipEventRecord(env->moved[e - 1], sm);
+        if (herr != hipSuccess) break;
+        for (int c = 0; c < P && herr == hipSuccess; ++c) {
+            hipStream_t sc = stream_of(c);
+            if (c > 0 || a > 0) {           // (range 0's first ray cast follows tick 0's move launch on the caller's stream itself)
+                herr = hipStreamWaitEvent(sc, env->moved[e - 1], 0);
+                if (herr != hipSuccess) break;
+            }
+            const int w0 = first_world(c), wn = first_world(c + 1) - w0;
+            for (int k = a; k < e; ++k) {
+                mrca::EnvView rv = slot_view(env, K - 1 - k);
+                rv.ray_first = w0 * R;
+                rv.ray_count = wn * R;
+                rv.world_first = w0;
+                rv.world_count = wn;
+                mrca::launch_raycast(rv, /*only_fresh=*/0, sc);
+                if (!env->cfg.lazy_obs) mrca::launch_materialize(rv, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, sc);
+            }
+        }
+        a = e;
+    }
+    // join: the caller's stream continues when every range is through (the move stream is: range 0 waited for its last launch)
+    hipError_t jerr = hipSuccess;
+    if (K > 0) {
+        for (int c = 1; c < P; ++c) {
+            hipError_t e1 = hipEventRecord(env->chain_done[c - 1], stream_of(c));
+            hipError_t e2 = hipStreamWaitEvent(s0, env->chain_done[c - 1], 0);
+            if (jerr == hipSuccess) jerr = e1 != hipSuccess ? e1 : e2;
+        }
+        if (move_forked && herr != hipSuccess) {     // an early exit: the move stream may still be forked off the caller's
+            hipError_t e1 = hipEventRecord(env->chain_fork, env->move_stream);
+            hipError_t e2 = hipStreamWaitEvent(s0, env->chain_fork, 0);
+            if (jerr == hipSuccess) jerr = e1 != hipSuccess ? e1 : e2;
+        }
+    }
+    if (herr != hipSuccess) return fail(MRCA_ERR_HIP, "mrca_step_many: %s", hipGetErrorString(herr));
+    if (jerr != hipSuccess) return fail(MRCA_ERR_HIP, "mrca_step_many (join): %s", hipGetErrorString(jerr));
+    HIP_TRY(hipGetLastError());
+    return MRCA_OK;
+}
+
 int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_actions, int32_t first_tick, int32_t num_ticks,
                    int32_t chains, void* stream) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
@@ -613,18 +776,21 @@ int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_a
     for (int i = 0; i < num_actions; ++i)
         if (!actions_dev[i]) return fail(MRCA_ERR_INVALID, "mrca_step_many: actions_dev[%d] is NULL", i);
     const int W = env->view.W;
-    int P = chains < 1 ? 1 : chains;
+    const bool chained = chains < 0;          // chains = -P: round 5's schedule (P chains `move, ray, move, ray ...` half a tick apart)
+    int P = chains < 0 ? -chains : chains;
+    if (P < 1) P = 1;
     if (P > W) P = W;
     if (env->view.big) P = 1;
     auto act = [&](int k) { return actions_dev[(size_t)((int64_t)first_tick + k) % (size_t)num_actions]; };
-    if (P == 1) {
-        for (int k = 0; k < num_ticks; ++k)
-            if (int rc = step_impl(env, act(k), 0, env->view.N, stream)) return rc;
-        return MRCA_OK;
-    }
     DeviceGuard guard(env->cfg.device);
     hipStream_t s0 = static_cast<hipStream_t>(stream);
+    // streams and events of ranges beyond the ones mrca_create made: never inside a capture (stream creation is not capturable)
     while ((int)env->chain_stream.size() < P - 1) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s0, &cs);
+        if (cs != hipStreamCaptureStatusNone)
+            return fail(MRCA_ERR_INVALID, "mrca_step_many: chains %d needs streams the env has not created yet -- call it once "
+                                          "outside the capture first (mrca_create prepares chains <= %d)", P, kChainStreamsAtCreate + 1);
         hipStream_t s;
         hipEvent_t a, b;
         HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -634,29 +800,57 @@ int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_a
         env->chain_moved.push_back(a);
         env->chain_done.push_back(b);
     }
+    if (!env->chain_fork) HIP_TRY(hipEventCreateWithFlags(&env->chain_fork, hipEventDisableTiming));
     if (num_ticks == 0) return MRCA_OK;
+    if (!chained && !env->view.big && env->ahead_slots > 0) {
+        // the run-ahead schedule, in passes of at most ahead_slots + 1 ticks (a pass ends with every stream joined)
+        const int per = env->ahead_slots + 1 < kAheadTicks ? env->ahead_slots + 1 : kAheadTicks;
+        std::vector<const float*> a((size_t)per);
+        for (int k0 = 0; k0 < num_ticks; k0 += per) {
+            const int K = num_ticks - k0 < per ? num_ticks - k0 : per;
+            for (int k = 0; k < K; ++k) a[(size_t)k] = act(k0 + k);
+            if (int rc = run_ahead_pass(env, a.data(), K, P, s0)) return rc;
+        }
+        return MRCA_OK;
+    }
+    if (P == 1) {
+        for (int k = 0; k < num_ticks; ++k)
+            if (int rc = step_impl(env, act(k), 0, env->view.N, stream)) return rc;
+        return MRCA_OK;
+    }
     auto stream_of = [&](int c) { return c == 0 ? s0 : env->chain_stream[c - 1]; };
     auto first_world = [&](int c) { return (int)((int64_t)c * W / P); };
     // (fork: range c's stream starts behind range c - 1's FIRST move launch -- which sits behind everything queued on the caller's
     // stream before this call, so that one wait is the fork AND the half tick between the ranges; the first launch of the call
     // goes out before any event is touched)
-    for (int k = 0; k < num_ticks; ++k) {
+    int rc = MRCA_OK;
+    hipError_t herr = hipSuccess;
+    int forked = 1;          // ranges below this index have launches on their streams: they must be joined on every path
+    for (int k = 0; k < num_ticks && rc == MRCA_OK && herr == hipSuccess; ++k) {
         const float* a = act(k);
         for (int c = 0; c < P; ++c) {
             hipStream_t sc = stream_of(c);
             const int w0 = first_world(c), wn = first_world(c + 1) - w0;
             // half a tick behind the previous range, once: its first move launch has finished, its first ray cast is starting
-            if (k == 0 && c > 0) HIP_TRY(hipStreamWaitEvent(sc, env->chain_moved[c - 1], 0));
-            if (int rc = worlds_impl(env, a, w0, wn, sc, kPhaseMove)) return rc;
-            if (k == 0 && c + 1 < P) HIP_TRY(hipEventRecord(env->chain_moved[c], sc));
-            if (int rc = worlds_impl(env, nullptr, w0, wn, sc, kPhaseObserve)) return rc;
+            if (k == 0 && c > 0) {
+                herr = hipStreamWaitEvent(sc, env->chain_moved[c - 1], 0);
+                if (herr != hipSuccess) break;
+                forked = c + 1;
+            }
+            if ((rc = worlds_impl(env, a, w0, wn, sc, kPhaseMove))) break;
+            if (k == 0 && c + 1 < P && (herr = hipEventRecord(env->chain_moved[c], sc)) != hipSuccess) break;
+            if ((rc = worlds_impl(env, nullptr, w0, wn, sc, kPhaseObserve))) break;
         }
     }
-    // join: the caller's stream continues when every range is through
-    for (int c = 1; c < P; ++c) {
-        HIP_TRY(hipEventRecord(env->chain_done[c - 1], stream_of(c)));
-        HIP_TRY(hipStreamWaitEvent(s0, env->chain_done[c - 1], 0));
+    // join: the caller's stream continues when every range is through -- on the error paths too (a forked stream left
+    // unjoined would dangle from a capture, and its launches would race the caller's next call)
+    for (int c = 1; c < forked; ++c) {
+        hipError_t e1 = hipEventRecord(env->chain_done[c - 1], stream_of(c));
+        hipError_t e2 = hipStreamWaitEvent(s0, env->chain_done[c - 1], 0);
+        if (herr == hipSuccess) herr = e1 != hipSuccess ? e1 : e2;
     }
+    if (rc != MRCA_OK) return rc;
+    if (herr != hipSuccess) return fail(MRCA_ERR_HIP, "mrca_step_many: %s", hipGetErrorString(herr));
     return MRCA_OK;
 }
 

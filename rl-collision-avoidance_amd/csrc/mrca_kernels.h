@@ -117,7 +117,9 @@ size_t move_lds_bytes(const EnvView& e);
 // `start` / `stop` (both or neither): events stamped with the BEGIN of the first and the END of the last kernel of the launch
 // (hipExtLaunchKernel: the dispatch's own timestamps -- what rocprofv3 reports -- instead of event records around it, which
 // read 2.5 us longer per kernel; bench.py)
-void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// in: the view whose pose / head / goal / outline the tick READS (nullptr: e's own -- an in-place tick); flags: hipExtLaunchKernel's
+void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
+                 const EnvView* in = nullptr, unsigned flags = 0);
 void launch_reset(const EnvView& e, const uint8_t* mask, const float* poses, const float* goals, hipStream_t s);
 void launch_head_init(const EnvView& e, hipStream_t s);
 void launch_lidar_grid(const EnvView& e, int counted, hipStream_t s);   // big worlds: hash of the current poses for the ray cast

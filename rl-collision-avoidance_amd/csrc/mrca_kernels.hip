@@ -273,9 +273,14 @@ __device__ unsigned long long g_ray_stamps[2][kRayStamps][kRayStampBlocks];
 // (csrc/build.sh: -amdgpu-kernarg-preload-count), so the loads the tick's dependent chain starts with go out at once instead
 // of one memory round trip later, behind the s_load of a 600-byte EnvView.  A/B on one box, three alternating runs each:
 // move 11.12 -> 10.85 us, ray cast 21.35 -> 20.51 us, profiles/r04_y_ab_kernarg_preload.txt.)
+// (pose_p / head_p / goal_p / outline_p are what the tick READS -- the poses, head records, goals and outlines as the tick
+// before left them; e.pose / e.head / e.goal / e.fresh / e.outline are where it WRITES them.  The same buffers for an ordinary
+// call; mrca_step_many alternates two sets, so that tick k + 1's move launch may run while tick k's ray cast still reads
+// tick k's poses: DESIGN.md 5.10.  With the two scalars they fill the 14 preloaded dwords exactly.)
 __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int world_first, const float* pose_p,
                                                                   const float4* head_p, const float* __restrict__ actions,
-                                                                  const uint8_t* live_p, EnvView e) {
+                                                                  const uint8_t* live_p, const float* goal_p,
+                                                                  const OutlineBits* outline_p, EnvView e) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
     MRCA_STAMP(0);
     const int world = world_first + blockIdx.x;     // (mrca_step_worlds: a launch may cover a range of worlds)
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int wo
     float x = pose_p[n * 3 + 0], y = pose_p[n * 3 + 1], th = pose_p[n * 3 + 2];
     const bool live = live_p[n] != 0;
     const float act_v = actions[n * 2 + 0], act_w = actions[n * 2 + 1];
-    float gx = e.goal[n * 2 + 0], gy = e.goal[n * 2 + 1];
+    float gx = goal_p[n * 2 + 0], gy = goal_p[n * 2 + 1];
     float pdist = e.prev_dist[n];
     int t = e.t[n];
     float reward = e.reward[n];
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int wo
     // tick start comes with the robot's record, kept by whoever moved it
     const bool raster = e.raster_inv > 0.0f;
     OutlineBits ob_old{0, 0, 0u, 0u};
-    if (raster) ob_old = e.outline[n];
+    if (raster) ob_old = outline_p[n];
     // a robot whose script no longer sends cmd_vel (dead, ppo_stage2.py:72-74): idles, or -- hold_velocity, what Stage
     // does with the last SetSpeed -- keeps driving at the command it was given last
     float held_v = 0.0f, held_w = 0.0f;
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int o
     }
     MRCA_RSTAMP(3);     // this wave's beams marched
     __syncthreads();  // neighbour list ready (the preparation wave built it while the others marched)
-    MRCA_RSTAMP(4);     // through the barrier
+    MRCA_RSTAMP(4);     // through the barrier / past the flag
     if constexpr (!BIG) {
         if (!marches) return;  // the dedicated preparation wave is done (whole wave: the barrier below counts live waves)
     }
@@ -1529,15 +1534,17 @@ size_t move_lds_bytes(const EnvView& e) {
     return b;
 }
 
-void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
+void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent_t start, hipEvent_t stop, const EnvView* in,
+                 unsigned flags) {
     if (!e.big) {
         if (e.world_count <= 0) return;
-        if (start || stop)
+        const EnvView& r = in ? *in : e;      // what the tick reads (the tick before's poses, heads, goals, outlines)
+        if (start || stop || flags)
             hipExtLaunchKernelGGL(move_kernel, dim3(e.world_count), dim3(kWave * kMoveWaves), (uint32_t)move_lds_bytes(e), s, start,
-                                  stop, 0, e.R, e.world_first, e.pose, e.head, actions, e.live, e);
+                                  stop, flags, e.R, e.world_first, r.pose, r.head, actions, e.live, r.goal, r.outline, e);
         else
             hipLaunchKernelGGL(move_kernel, dim3(e.world_count), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e.R, e.world_first,
-                               e.pose, e.head, actions, e.live, e);
+                               r.pose, r.head, actions, e.live, r.goal, r.outline, e);
         return;
     }
     // (the collision hash's heads and the lidar hash's counts are left clean by the tick before: bw_finish_kernel /

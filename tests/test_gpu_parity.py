@@ -188,7 +188,7 @@ def test_fp64_oracle_one_tick_from_identical_state(hip, name):
 
 
 @pytest.mark.parametrize("chains,graph", [(1, True), (2, True), (4, True), (2, False), (3, False), (1, "native"), (2, "native"),
-                                          (3, "native")])
+                                          (3, "native"), (5, "native"), (2, "chained"), (3, "chained")])
 @pytest.mark.parametrize("name", ["stage1", "stage2", "stage1_fidelity"])
 def test_bench_schedule_leaves_the_world_where_the_c_oracle_leaves_it(hip, name, chains, graph):
     """The execution modes bench.py TIMES -- one mrca_step_many call ("native": the library enqueues every launch, world ranges
@@ -204,7 +204,8 @@ def test_bench_schedule_leaves_the_world_where_the_c_oracle_leaves_it(hip, name,
     ora = U.COracleEnv(sc)
     pool = bench.action_pool(sc.num_robots, env.device, 5)
     host_pool = [a.cpu().numpy() for a in pool]
-    sched = bench.TickSchedule(env, pool, chains=chains, graph=graph is True, native=graph == "native")
+    sched = bench.TickSchedule(env, pool, chains=chains, graph=graph is True, native=graph in ("native", "chained"),
+                               chained=graph == "chained")
     sched.ticks_per_graph = 16
     assert sched.chains == min(chains, sc.num_worlds) and sum(c for _f, c in sched.ranges) == sc.num_worlds
     env.reset()
@@ -256,6 +257,41 @@ def test_step_many_inside_a_graph_capture(hip, chains):
     torch.cuda.synchronize()
     env.invalidate_views()
     U.assert_state_equal(U.HostView(env), ora, what=f"three replays of a captured mrca_step_many, chains={chains}")
+    env.check()
+    env.close()
+
+
+@pytest.mark.parametrize("chains", [2, -2])
+def test_step_many_first_call_inside_a_capture_and_passes_longer_than_the_ring(hip, chains):
+    """Two corners of mrca_step_many: (a) the env's streams and events exist since mrca_create, so the FIRST call may sit inside
+    a (global-mode) graph capture; (b) a call of more ticks than the run-ahead ring has slots (300 > 256) is cut into passes by
+    the library itself.  Run-ahead schedule (chains > 0) and round 5's chained one (chains < 0), against the C oracle."""
+    import bench
+    sc = S.stage2(num_worlds=3, seed=23)
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    pool = bench.action_pool(sc.num_robots, env.device, 11, depth=300)
+    host_pool = [a.cpu().numpy() for a in pool]
+    env.reset()
+    ora.reset()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        env.step_many(pool, 0, 5, chains)
+    g.replay()
+    for k in range(5):
+        ora.step(host_pool[k])
+    torch.cuda.synchronize()
+    env.invalidate_views()
+    U.assert_state_equal(U.HostView(env), ora, what=f"first call captured, chains={chains}")
+    env.step_many(pool, 0, 300, chains)
+    for k in range(300):
+        ora.step(host_pool[k])
+    torch.cuda.synchronize()
+    env.invalidate_views()
+    U.assert_state_equal(U.HostView(env), ora, what=f"300 ticks from one call, chains={chains}")
+    U.assert_hits_equal(env, ora, what="300 ticks from one call")
     env.check()
     env.close()
 

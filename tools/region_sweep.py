@@ -4,7 +4,7 @@ tick apart) timed for K = 5 .. 320 ticks between two device synchronisations, fi
 a straight line through the points gives the fixed cost of a region (the intercept: first launch out of an idle queue, the
 stagger, the drain, the synchronisation) and the steady tick (the slope).  The driver's bench run is K = 20.
 
-    python tools/region_sweep.py [--schedule native|graph]
+    python tools/region_sweep.py [--schedule native|chained|graph]     (chained: round 5's schedule inside mrca_step_many)
 """
 import argparse
 import os
@@ -29,13 +29,14 @@ ap.add_argument("--schedule", default="native")
 a = ap.parse_args()
 sc = S.stage1(num_worlds=128, robots_per_world=32, seed=1000)
 env = VecStageWorld(sc)
-pool = bench.action_pool(sc.num_robots, env.device, 1)
+pool = bench.action_pool(sc.num_robots, env.device, 1, depth=320)
 env.reset()
 for k in range(3):
     env.step(pool[k])
 torch.cuda.synchronize()
 for chains in (1, 2, 3):
-    sched = bench.TickSchedule(env, pool, chains=chains, graph=a.schedule == "graph", native=a.schedule == "native")
+    sched = bench.TickSchedule(env, pool, chains=chains, graph=a.schedule == "graph", native=a.schedule in ("native", "chained"),
+                               chained=a.schedule == "chained")
     pts = []
     for K in (5, 10, 20, 40, 80, 160, 320):
         sched.capture(0, K)
