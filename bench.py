@@ -345,6 +345,44 @@ def env_side_figure(sc, ticks, chains, lazy_obs=True, seed=1, note="", schedule=
         env.close()
 
 
+def side_scenario(name, scenario, worlds, robots_per_world, seed):
+    """the scenario of the env side figure `name` (the three configurations DESIGN.md / README quote beside `value`)"""
+    from mrca import scenario as S
+    if name == "stage2_side_figure":
+        return S.stage2(num_worlds=187, seed=seed), True
+    if name == "fidelity_side_figure":
+        return (S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=seed, stage_resolution=True)
+                if scenario == "stage1" else S.stage2(num_worlds=worlds, seed=seed, stage_resolution=True)), True
+    if name == "reference_shaped_obs_side_figure":
+        return (S.stage1(num_worlds=worlds, robots_per_world=robots_per_world, seed=seed) if scenario == "stage1" else
+                S.stage2(num_worlds=worlds, seed=seed)), False
+    raise SystemExit(f"bench.py: no side figure called {name}")
+
+
+def side_figure_main(argv):
+    """`python bench.py --side-figure NAME ...`: ONE env side figure in a process of its own, one JSON dict on stdout.  The
+    parent run starts these (see main): what a multi-stream schedule reaches depends on which hardware queues the runtime
+    gives its streams, and that on everything the process has created before (torch's stream pools, captured graphs, other
+    envs: tools/stream_pressure_probe.py measured 145 - 310 M for the SAME call on the Stage-2 map, profiles/r06_j_*) -- a
+    figure quoted beside `value` is measured the way `value` is: by a process that has done nothing else yet."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--side-figure", required=True)
+    ap.add_argument("--scenario", default="stage1")
+    ap.add_argument("--worlds", type=int, default=128)
+    ap.add_argument("--robots-per-world", type=int, default=32)
+    ap.add_argument("--chains", type=int, default=2)
+    ap.add_argument("--schedule", default="native")
+    ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--ticks", type=int, default=300)
+    ap.add_argument("--device-index", type=int, default=0)
+    a = ap.parse_args(argv)
+    torch.cuda.set_device(a.device_index)
+    import __graft_entry__ as G
+    G.build()
+    sc, lazy = side_scenario(a.side_figure, a.scenario, a.worlds, a.robots_per_world, a.seed)
+    print(json.dumps(env_side_figure(sc, ticks=a.ticks, chains=a.chains, lazy_obs=lazy, schedule=a.schedule)))
+
+
 def assemble_line(*, args, sc, N, world_size, value, elapsed, ray_ms, mv_ms, launches, kernel_timing_note, sched, extra,
                   per_rank=None, ranks_seen=None, devices=None, backend=None, cpu_baseline_fn=None):
     """The ONE JSON line of a run as a dict, from what the run measured (rank 0; a pure function of its arguments, so that
@@ -547,22 +585,18 @@ def main():
               file=sys.stderr)
         raise SystemExit(2)
     torch.cuda.set_device(dev_index)
-    dist = None
-    if world_size > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
-    if args.gpus != world_size and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world_size}; using {world_size}", file=sys.stderr)
-
+    # The library and the env come FIRST -- before the process group, its communicator and their streams exist: which hardware
+    # queues the env's streams get depends on what the process has created before them (side_figure_main), and the state `value`
+    # was measured in on one GPU (nothing but the env) is the state it should be measured in on eight.  Every rank may build
+    # (the driver's run finds the library built; a cold tree is built once, under a file lock).
+    import fcntl
     import __graft_entry__ as G
-    if rank == 0:
-        G.build()
-    if dist is not None:
-        dist.barrier()
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            G.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     from mrca import scenario as S
     from mrca.vec_env import VecStageWorld
 
@@ -574,6 +608,21 @@ def main():
     env = VecStageWorld(sc)
     N = sc.num_robots
     dev = env.device
+    dist = None
+    if world_size > 1:
+        if args.mode == "env" and not args.no_graph and not args.graph and args.schedule in (None, "native", "chained"):
+            # ... and its streams are USED once (a stream gets its hardware queue at its first launch)
+            env.reset()
+            env.step_many(action_pool(N, dev, 0, depth=2), 0, 2, args.chains or 2)
+            torch.cuda.synchronize()
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    if args.gpus != world_size and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world_size}; using {world_size}", file=sys.stderr)
     # one entry per tick of warm-up + timed region (<= 1024): the actions are i.i.d. per tick, not a 16-deep loop
     pool = action_pool(N, dev, 1 + rank, depth=max(16, min(1024, args.warmup + args.steps)) if args.mode == "env" else 16)
 
@@ -726,27 +775,32 @@ def main():
     #   reference_shaped_obs_side_figure   this workload with lazy_obs = 0: every tick also forms MRCA_F_SCAN and the
     #                                      deque-ordered, normalised MRCA_F_OBS (SURVEY 8d's "obs normalise + frame-stack update")
     if args.mode == "env" and not args.no_extra and not args.fidelity:
-        def side(name, make, note, **kw):
+        def side(name, note, ticks=300):
+            # (a process of its own: side_figure_main says why)
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--side-figure", name, "--scenario", args.scenario, "--worlds",
+                   str(args.worlds), "--robots-per-world", str(args.robots_per_world), "--chains", str(args.chains), "--schedule",
+                   args.schedule, "--seed", str(1000 + rank), "--ticks", str(ticks), "--device-index", str(dev.index)]
             try:
-                extra[name] = env_side_figure(make(), ticks=kw.pop("ticks", 300), chains=args.chains, note=note,
-                                              schedule=args.schedule, **kw)
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                if out.returncode != 0 or not lines:
+                    raise RuntimeError(f"rc {out.returncode}: {out.stderr.strip().splitlines()[-1] if out.stderr.strip() else 'no output'}")
+                extra[name] = json.loads(lines[-1])
+                extra[name]["note"] = note + "; measured by a process of its own started from this run"
             except Exception as exc:
                 extra[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if args.scenario == "stage1":
-            side("stage2_side_figure", lambda: S.stage2(num_worlds=187, seed=1000 + rank),
+            side("stage2_side_figure",
                  "BASELINE configs[2] (and configs[3]'s share of one GPU): 187 Stage-2 worlds x 44 robots = 8228 robots on the "
                  "800 x 800 obstacle map, group-synchronous episodes; not part of `value`", ticks=200)
         if world_size == 1:
             side("fidelity_side_figure",
-                 lambda: (S.stage1(num_worlds=args.worlds, robots_per_world=args.robots_per_world, seed=1000 + rank,
-                                   stage_resolution=True) if args.scenario == "stage1" else
-                          S.stage2(num_worlds=args.worlds, seed=1000 + rank, stage_resolution=True)),
                  "the same worlds in FIDELITY mode: Stage's own resolution (0.2 m, worlds/stage1.world:3), robots collide when "
                  "their outlines share a raster cell and see each other through that raster; not part of `value`")
-            side("reference_shaped_obs_side_figure", lambda: sc,
+            side("reference_shaped_obs_side_figure",
                  "the same workload with lazy_obs = 0: every tick also materialises MRCA_F_SCAN and the normalised, deque-ordered "
-                 "MRCA_F_OBS [N,3,512] a reference-shaped caller reads (one more kernel per range and tick); not part of `value`",
-                 lazy_obs=False)
+                 "MRCA_F_OBS [N,3,512] a reference-shaped caller reads (one more kernel per range and tick); not part of `value`")
         if dist is not None and "stage2_side_figure" in extra:
             # configs[3] = 65 536 robots over 8 GPUs: every rank ran its 8228 Stage-2 robots; the job's figure is all of them
             # over the slowest rank's time.  (Every rank takes part in the reduction whatever happened to its own figure: a
@@ -885,4 +939,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--side-figure" in sys.argv[1:]:
+        side_figure_main(sys.argv[1:])
+    else:
+        main()

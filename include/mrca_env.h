@@ -33,10 +33,12 @@
 extern "C" {
 #endif
 
-/* 5 (round 5): mrca_policy_tail takes fc1_b_dev (may be NULL) after h1_dev; added since 4, all additive: mrca_step_worlds,
+/* 6 (round 6): MRCA_F_HIT_BITS -- what a beam hit is a bit plane of its own, MRCA_F_SCAN_RING holds plain ranges (5: the sign
+ * bit of a ring entry); mrca_step_many's run-ahead schedule (chains < 0: the chained one).
+ * 5 (round 5): mrca_policy_tail takes fc1_b_dev (may be NULL) after h1_dev; added since 4, all additive: mrca_step_worlds,
  * mrca_move_worlds, mrca_observe_worlds, mrca_step_many, mrca_adam_step, mrca_policy_heads(_backward), mrca_relu_cat(_backward), mrca_rollout_rows +
  * mrca_rollout_store_state / _outcome, status bits for mrca_check.  4: the frame history became a ring of raw scans (MRCA_F_SCAN_RING, MRCA_F_RING_HEAD). */
-#define MRCA_ABI_VERSION 5
+#define MRCA_ABI_VERSION 6
 
 typedef struct mrca_env mrca_env; /* opaque */
 
@@ -90,14 +92,17 @@ enum mrca_field {
     MRCA_F_T,             /* i32 [N]     the `step` argument of get_reward_and_terminate (ppo_stage1.py:57,118)          */
     MRCA_F_EPISODE,       /* i32 [N]     episode counter (RNG stream position)                                          */
     MRCA_F_PREV_DIST,     /* f32 [N]     self.distance      stage_world1.py:176-177,185-186                              */
-    MRCA_F_SCAN_RING,     /* f32 [N,F,B] the last F scans of every robot (RAW ranges, 0..6 m) as a ring (ABI 4): a tick writes ONE
-                           *             row per robot -- the tick's only per-beam store -- logical frame f (0 = oldest) of
-                           *             robot n is slot (head[n] + 1 + f) mod F.  (ABI 3 kept a ring of NORMALISED frames
-                           *             next to MRCA_F_SCAN: every beam was stored twice.)  The SIGN BIT of an entry says
-                           *             what the beam hit: set = another robot (ranger_return 0.5, stage1.world:95 -- what
-                           *             stageros turns into LaserScan intensity 0, stageros.cpp:506), clear = the floorplan
-                           *             or nothing (range 6.0); the range is |entry|.  Every library reader takes |x|.    */
+    MRCA_F_SCAN_RING,     /* f32 [N,F,B] the last F scans of every robot (RAW ranges, 0..6 m, never negative) as a ring (ABI 4): a
+                           *             tick writes ONE row per robot -- the tick's only per-beam store -- logical frame f
+                           *             (0 = oldest) of robot n is slot (head[n] + 1 + f) mod F.  (ABI 3 kept a ring of
+                           *             NORMALISED frames next to MRCA_F_SCAN: every beam was stored twice.  ABI 4-5 kept
+                           *             what a beam hit in the SIGN BIT of its entry; since ABI 6 that is MRCA_F_HIT_BITS
+                           *             and an entry is the plain range.)                                               */
     MRCA_F_RING_HEAD,     /* u8  [N]     slot of robot n's newest scan in MRCA_F_SCAN_RING                                */
+    MRCA_F_HIT_BITS,      /* u64 [N,F,B/64] (ABI 6) what every beam of the ring hit, one bit per beam, slot by slot like the
+                           *             ring: bit (b & 63) of word b >> 6 set = beam b returned from ANOTHER ROBOT
+                           *             (ranger_return 0.5, stage1.world:95 -- what stageros turns into LaserScan intensity
+                           *             0, stageros.cpp:506), clear = the floorplan or nothing (range 6.0)              */
     MRCA_F_COUNT
 };
 
@@ -200,10 +205,12 @@ int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, 
  * those five fields into a slot of its own (a ring of <= 255 slots beside the arena, 53 B per robot and slot, at most 256 MB; the call's last
  * tick writes the env's own fields, so MRCA_F_POSE etc. are current when the call's work is done and never in between); the
  * ray casts of chains = P contiguous world ranges run on P streams (range 0 on `stream`, the others on streams the env created
- * in mrca_create for P <= 4), tick after tick, each behind the event "tick k's move launch is through".  `stream` waits for
+ * in mrca_create for P <= 2, at first use beyond), tick after tick, each behind the event "tick k's move launch is through".  `stream` waits for
  * all of them before the call's work counts as done, and they for everything queued on `stream` before the call.  What a tick
  * then costs is its ray casts alone.  The host only enqueues (no synchronisation, nothing spins on the
- * device); the call is capturable into a hipGraph like any other (chains > 4: call it once outside the capture first).
+ * device); the call is capturable into a hipGraph like any other (chains > 2: call it once outside the capture first).
+ * (Two streams of one process may share a hardware queue -- the runtime's choice, tools/queue_alias_probe.hip -- and then run
+ * one after the other: the schedule stays correct and loses its overlap.  DESIGN.md 5.10 lists what is known about it.)
  * chains = -P: round 5's schedule instead -- P chains `move, ray cast, move, ray cast ...` of one world range each, half a tick
  * apart (kept for A/B runs: tools/region_sweep.py --schedule chained).  robots_per_world > 64: one chain, in order. */
 int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_actions, int32_t first_tick, int32_t num_ticks,

@@ -769,7 +769,7 @@ class OracleEnv:
         oy = np.broadcast_to(y[:, None], (N, B))
         rng = grid_march(cfg.grid, ox, oy, dx, dy, f(RANGE_MAX), f)
         # what a beam hit: True = another robot closer than the floorplan (ranger_return 0.5 -> LaserScan intensity 0,
-        # stageros.cpp:501-506); the product keeps it in the sign bit of its scan ring
+        # stageros.cpp:501-506); the product keeps it as one bit per beam beside its scan ring (MRCA_F_HIT_BITS)
         self._hit_new = np.zeros((N, B), bool)
         if cfg.collision_raster > 0:
             # Fidelity mode: the lidar sees the other robots through the SAME raster they collide on (Stage's ranger walks

@@ -38,9 +38,11 @@ using mrca::DeviceGuard;
 
 // log2 of the beams a marching thread of the ray cast owns (EnvView::ray_shift): 2 per thread, 4 in worlds of more than 64
 // robots -- as long as that leaves the workgroup two whole wavefronts or more (the measurements: mrca_create)
+// (the marching threads of a workgroup are whole wavefronts -- beams >> shift is a multiple of 64: a wave's ballot is one word of
+// MRCA_F_HIT_BITS)
 inline int32_t product_ray_shift(int32_t beams, int32_t big) {
     if (big && (beams >> 2) >= 128 && (beams >> 2) % 64 == 0) return 2;
-    return beams >= 256 ? 1 : 0;
+    return (beams >= 256 && (beams >> 1) % 64 == 0) ? 1 : 0;
 }
 
 #define HIP_TRY(expr)                                                                               \
@@ -136,6 +138,7 @@ void make_layout(const mrca_config* c, Layout* L) {
     sz[MRCA_F_PREV_DIST] = N * 4;
     sz[MRCA_F_SCAN_RING] = N * F * B * 4;
     sz[MRCA_F_RING_HEAD] = N;
+    sz[MRCA_F_HIT_BITS] = N * F * (B / 64) * 8;
     size_t off = 0;
     for (int f = 0; f < MRCA_F_COUNT; ++f) {
         L->field_off[f] = off;
@@ -246,7 +249,10 @@ struct mrca_env {
 
 constexpr int kAheadTicks = 256;            // most ticks one run-ahead pass covers (a pass ends with every stream joined: ~90 us)
 constexpr size_t kAheadMaxBytes = 256u << 20;
-constexpr int kChainStreamsAtCreate = 3;    // world ranges 1 .. 3 get their streams in mrca_create (chains <= 4)
+// World range 1 gets its stream in mrca_create (chains <= 2, bench.py's default, may be captured at once); further ranges get
+// theirs at their first use -- an env does not park streams it may never use (the runtime maps a process's streams onto a
+// few hardware queues, DESIGN.md 5.10 "what the schedule depends on").
+constexpr int kChainStreamsAtCreate = 1;
 
 // the env's view with slot b's buffers in place of the five fields (b = 0: the env's own)
 static mrca::EnvView slot_view(const mrca_env* env, int b) {
@@ -431,6 +437,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.obs = reinterpret_cast<float*>(a + L.field_off[MRCA_F_OBS]);
     v.scan_ring = reinterpret_cast<float*>(a + L.field_off[MRCA_F_SCAN_RING]);
     v.ring_head = reinterpret_cast<uint8_t*>(a + L.field_off[MRCA_F_RING_HEAD]);
+    v.hit_bits = reinterpret_cast<unsigned long long*>(a + L.field_off[MRCA_F_HIT_BITS]);
     v.local_goal = reinterpret_cast<float*>(a + L.field_off[MRCA_F_LOCAL_GOAL]);
     v.reward = reinterpret_cast<float*>(a + L.field_off[MRCA_F_REWARD]);
     v.prev_dist = reinterpret_cast<float*>(a + L.field_off[MRCA_F_PREV_DIST]);

@@ -21,6 +21,7 @@ struct EnvView {
     float* obs;         // [N,F,B] the normalised frame stack in deque order -- made from scan_ring by materialize_kernel
     float* scan_ring;   // [N,F,B] the last F scans (RAW ranges) as a ring: slot ring_head[n] holds robot n's newest one
     uint8_t* ring_head; // [N]
+    unsigned long long* hit_bits;   // [N,F,B/64] what each beam of the ring hit: bit set = another robot (MRCA_F_HIT_BITS)
     float* local_goal;  // [N,2]
     float* reward;      // [N]
     float* prev_dist;   // [N]

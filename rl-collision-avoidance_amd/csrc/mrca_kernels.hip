@@ -158,7 +158,7 @@ struct MiniGrid {  // the move kernel's per-robot occupancy patch in LDS
 // wants -- MRCA_F_SCAN (the newest scan, contiguous) and MRCA_F_OBS (the normalised stack in deque order, what
 // CNNPolicy.forward eats) -- on demand (mrca_materialize) or after every call when the env was created with
 // lazy_obs = 0.  A thread owns float4 columns of robots [ray_first, ray_first + ray_count).
-// (the ring's SIGN BIT says what a beam hit -- set: another robot -- so every reader of a range takes |x|: a source modifier)
+// (ABI 4-5 kept what a beam hit in the ring's sign bit; the readers' |x| -- a source modifier, free -- stays as a belt)
 __device__ __forceinline__ float4 norm_obs4(float4 v) {
     return make_float4(norm_obs(fabsf(v.x)), norm_obs(fabsf(v.y)), norm_obs(fabsf(v.z)), norm_obs(fabsf(v.w)));
 }
@@ -1092,22 +1092,32 @@ __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int o
     //     each store instruction of a wave covers 256 contiguous bytes.
     {
         float* ring_row = e.scan_ring + (size_t)n * e.F * e.B;
+        const int words = e.B >> 6;
+        unsigned long long* hit_row = e.hit_bits + (size_t)n * e.F * words;
         const int new_slot = ring_slot + 1 == e.F ? 0 : ring_slot + 1;
         const bool fresh = __builtin_amdgcn_readfirstlane((int)fresh_byte) != 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int b = tid + k * T;
-            float r = rng[k] < kRangeMax ? rng[k] : kRangeMax;
-            // what the beam hit rides in the sign bit (a range is never negative): set = another robot.  stageros casts
-            // Stage's return value to uint8 for LaserScan.intensities (stageros.cpp:506): 1 floorplan, 0 robot or miss.
-            r = (from_robot[k] && rng[k] < kRangeMax) ? -r : r;
+            // (|x|: fidelity mode's closed form may return -0.0 for a beam that starts inside a marked cell)
+            const float r = fabsf(rng[k] < kRangeMax ? rng[k] : kRangeMax);
+            // what the beam hit: one bit per beam beside the ring (MRCA_F_HIT_BITS), set = another robot.  stageros casts
+            // Stage's return value to uint8 for LaserScan.intensities (stageros.cpp:506): 1 floorplan, 0 robot or miss.  A wave
+            // holds 64 consecutive beams (T is a multiple of 64: product_ray_shift), so its ballot IS the row's word b >> 6.
+            // (ABI 4-5 kept the flag in the range's sign bit: a reader that forgot |x| got negative ranges.)
+            const unsigned long long hm = __ballot(from_robot[k] && rng[k] < kRangeMax);
+            const bool word_lane = (tid & (kWave - 1)) == 0;
             // (nontemporal stores: the launch does not read its rows again.  Measured A/B on one box, round 4: 21.7 us with
             // them, 22.9 us with plain stores (profiles/r04_g_ab_nontemporal_row_stores.txt) -- although FETCH_SIZE does not
             // move, 2502 vs 2504 KiB: what they relieve is the write path, not the free-rectangle field's residency)
             if (fresh) {     // deque([obs] * F), ppo_stage1.py:59-60: every slot, the head stays where it is
-                for (int f = 0; f < e.F; ++f) __builtin_nontemporal_store(r, &ring_row[f * e.B + b]);
+                for (int f = 0; f < e.F; ++f) {
+                    __builtin_nontemporal_store(r, &ring_row[f * e.B + b]);
+                    if (word_lane) hit_row[f * words + (b >> 6)] = hm;
+                }
             } else {
                 __builtin_nontemporal_store(r, &ring_row[new_slot * e.B + b]);
+                if (word_lane) hit_row[new_slot * words + (b >> 6)] = hm;
             }
         }
         if (tid == 0 && !fresh) ring_head_p[n] = (uint8_t)new_slot;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     {                                                                                                    \
         const int idx = (q) * 64 + lane; /* float4 index: ci = idx / 128, m = idx % 128 -> x[ci][4m .. 4m+3] */ \
         float4 v = sx[q];                                                                                \
-        if (RAW) v = make_float4(norm_scan(fabsf(v.x)), norm_scan(fabsf(v.y)), norm_scan(fabsf(v.z)), norm_scan(fabsf(v.w))); /* sign bit = what the beam hit */ \
+        if (RAW) v = make_float4(norm_scan(fabsf(v.x)), norm_scan(fabsf(v.y)), norm_scan(fabsf(v.z)), norm_scan(fabsf(v.w))); /* |x|: rows stored under ABI 4-5 carried a flag in the sign bit */ \
         const int ci = idx >> 7, m = idx & 127;                                                          \
         float* xe = lds + kXE + ci * kXPitch + 2 * m;                                                    \
         float* xo = lds + kXO + ci * kXPitch + 2 * m + 1;                                                \

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void rollout_store_state_kernel(
         const long long n = k / fstride;
         const int col = (int)(k - n * fstride);
         const int hd = ring_head[n];
-        // (the ring's sign bit says what a beam hit: every reader of a range takes |x|)
+        // (|x|: a source modifier, free -- ABI 4-5 kept what a beam hit in the ring's sign bit)
         const float4 v = ring[(n * F + hd) * fstride + col];
         out[k] = make_float4(norm_obs(fabsf(v.x)), norm_obs(fabsf(v.y)), norm_obs(fabsf(v.z)), norm_obs(fabsf(v.w)));
         if (col != 0) continue;

@@ -9,7 +9,7 @@ PROFILING_LIB_PATH = os.path.join(_HERE, "libmrca_env_prof.so")
 # libmrca_env_prof.so); whichever it is, it must exist -- there is no fallback
 LIB_PATH = os.environ.get("MRCA_ENV_LIB") or os.path.join(_HERE, "libmrca_env.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 VIEW_SCAN, VIEW_OBS = 1, 2        # enum mrca_view
 
 FIELDS = [  # order = enum mrca_field
@@ -18,6 +18,7 @@ FIELDS = [  # order = enum mrca_field
     ("result", "u8", 1), ("first_result", "u8", 1), ("crashed", "u8", 1), ("live", "u8", 1), ("fresh", "u8", 1),
     ("t", "i32", 1), ("episode", "i32", 1), ("prev_dist", "f32", 1),
     ("scan_ring", "f32", "FB"), ("ring_head", "u8", 1),
+    ("hit_bits", "i64", "FW"),      # u64 [N,F,B/64] (torch has no arithmetic on uint64: the words are viewed as int64)
 ]
 
 EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_create", "mrca_destroy", "mrca_reset",

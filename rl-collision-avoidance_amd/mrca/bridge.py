@@ -23,7 +23,7 @@ until the next cmd_vel (Stage keeps it), and the watchdog is GLOBAL: when no rob
 
 ``intensities`` are Stage's per-beam return value cast to uint8 (``:501-506``): 1 for the floorplan (``ranger_return``
 default 1), 0 for another robot (``ranger_return 0.5``, worlds/stage1.world:95) and for a miss -- from the backend's
-``hit_robot`` field (the sign bit of the device's scan ring).  Not restated: tf broadcasts, camera topics (no camera in any
+``hit_robot`` field (the device's MRCA_F_HIT_BITS plane).  Not restated: tf broadcasts, camera topics (no camera in any
 world of the reference).
 """
 import math

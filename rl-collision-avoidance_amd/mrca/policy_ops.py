@@ -37,7 +37,7 @@ def normalize_scans(scans):
     RN(1/6).  CPU tensors (the tests' stand-ins) take numpy's correctly rounded quotient, which equals the kernel's
     result."""
     if not scans.is_cuda:
-        a = np.abs(scans.numpy())           # (the ring's sign bit says what a beam hit: the range is |x|)
+        a = np.abs(scans.numpy())           # (|x| as the kernel does: rows stored under ABI 4-5 carried a flag in the sign bit)
         return torch.from_numpy(a / a.dtype.type(6.0) - a.dtype.type(0.5))
     x = scans.contiguous()
     if x.dtype != torch.float32 or x.numel() % 4:

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from .scenario import Scenario
 
-_DTYPES = {"f32": torch.float32, "u8": torch.uint8, "i32": torch.int32}
+_DTYPES = {"f32": torch.float32, "u8": torch.uint8, "i32": torch.int32, "i64": torch.int64}
 
 RESULT_NAMES = {0: 0, 1: "Reach Goal", 2: "Crashed", 3: "Time out"}  # stage_world1.py:190-208
 
@@ -91,6 +91,8 @@ class VecStageWorld:
                 t = flat.view(self.N, self.B)
             elif shape == "FB":
                 t = flat.view(self.N, self.F, self.B)
+            elif shape == "FW":
+                t = flat.view(self.N, self.F, self.B // 64)
             elif shape == 1:
                 t = flat.view(self.N)
             else:
@@ -122,11 +124,13 @@ class VecStageWorld:
 
     @property
     def hit_robot(self):
-        """bool[N,B]: beam b of robot n returned from ANOTHER ROBOT (the sign bit of the newest scan's ring entry; clear =
-        the floorplan or no return).  stageros publishes it as LaserScan.intensities: 1 floorplan, 0 robot or miss
-        (stageros.cpp:501-506, ranger_return 0.5 cast to uint8)."""
+        """bool[N,B]: beam b of robot n returned from ANOTHER ROBOT (the newest scan's words of MRCA_F_HIT_BITS, one bit per
+        beam; clear = the floorplan or no return).  stageros publishes it as LaserScan.intensities: 1 floorplan, 0 robot or
+        miss (stageros.cpp:501-506, ranger_return 0.5 cast to uint8)."""
         ar = torch.arange(self.N, device=self.device)
-        return torch.signbit(self.scan_ring[ar, self.ring_head.long()])
+        words = self.hit_bits[ar, self.ring_head.long()]                       # i64 [N, B/64]
+        bit = torch.arange(64, device=self.device, dtype=torch.int64)
+        return ((words.unsqueeze(-1) >> bit) & 1).bool().reshape(self.N, self.B)
 
     def invalidate_views(self):
         """Tell the binding that the env moved on without it: ticks replayed as a hipGraph (or stepped by another binding of
@@ -301,10 +305,9 @@ class VecStageWorld:
         return self
 
     def ring_ranges(self):
-        """f32[N,F,B]: a COPY of the scan ring as plain ranges.  ``scan_ring`` itself keeps what every beam hit in the SIGN
-        bit of its entry (set: another robot; -0.0 included), in the default mode as in fidelity mode -- a consumer that reads
-        the field directly (``policy_obs()``, ``mrca_get_field(MRCA_F_SCAN_RING)``) must take |x| like the in-tree readers do
-        (``hit_robot``, the policy's front end, ``mrca_normalize_scans``); this accessor is for the ones that would forget."""
+        """f32[N,F,B]: a copy of the scan ring.  (ABI 4-5 kept what a beam hit in the sign bit of its ring entry and this
+        accessor stripped it; since ABI 6 the flag is ``hit_bits`` / ``hit_robot`` and the ring holds plain ranges -- kept
+        for the callers written against it.)"""
         return self.scan_ring.abs()
 
     def check(self):

@@ -32,7 +32,7 @@ def test_header_symbols_exported(built_lib):
 
 def test_abi_version(built_lib):
     from mrca import _lib
-    assert built_lib.mrca_abi_version() == 5 == _lib.ABI_VERSION
+    assert built_lib.mrca_abi_version() == 6 == _lib.ABI_VERSION
 
 
 def _cfg(sc):

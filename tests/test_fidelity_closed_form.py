@@ -139,7 +139,7 @@ def test_closed_form_return_equals_the_walk_through_marked_cells(res, kw):
     lib.emul_ray_outline(n, kw, res, ox.ctypes.data, oy.ctypes.data, dx.ctypes.data, dy.ctypes.data, ob.ctypes.data, 6.0,
                          closed.ctypes.data, walk.ctypes.data)
     # (the sign of a zero range is not part of the result: a crossing at time -0.0 -- an origin on a raster line -- makes the
-    # walk return -0.0, and the scan ring keeps |range| with what-the-beam-hit in the sign bit)
+    # walk return -0.0, and the scan ring keeps |range|)
     bad = np.nonzero(np.abs(closed).view(np.uint32) != np.abs(walk).view(np.uint32))[0]
     assert bad.size == 0, (bad[:5], closed[bad[:5]], walk[bad[:5]])
     hits = walk < 6.0

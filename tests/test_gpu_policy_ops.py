@@ -171,7 +171,8 @@ def test_front_end_reads_the_envs_frame_ring_in_place(pol):
         assert torch.equal(env.newest_frame(), env.obs[:, -1])
         # the views against the ring itself: newest scan, and torch's own x / 6 - 0.5 (the IEEE quotient minus one half)
         ar = torch.arange(env.N, device="cuda")
-        assert torch.equal(env.scan, ring[ar, head.slots.long()].abs())       # (sign bit: what the beam hit)
+        assert torch.equal(env.scan, ring[ar, head.slots.long()])             # (ABI 6: the ring holds plain ranges)
+        assert (ring >= 0).all() and not torch.signbit(ring).any()
         assert torch.equal(env.obs[:, -1], policy_ops.normalize_scans(env.scan))
         # ... which is the correctly rounded x / 6 minus one half (numpy on the host; torch's GPU `x / 6.0` multiplies by
         # RN(1/6) instead and differs in the last bit for one value in a few hundred)

@@ -94,12 +94,14 @@ def test_register_budget_and_no_scratch(device_asm):
 
 def test_env_kernels_get_their_leading_arguments_preloaded(device_asm):
     """move_kernel and every raycast_kernel lead with the scalars / pointers their first loads need, and the build asks for
-    gfx950's kernel-argument preload: the descriptor of each must say so (14 dwords for the ray cast, 10 for the move
-    kernel: R, the first world of the launch + four pointers), or the loads wait for the s_load of the EnvView again."""
+    gfx950's kernel-argument preload: the descriptor of each must say so (14 dwords for the ray cast; 14 for the move
+    kernel since round 6: R, the first world of the launch + SIX pointers -- what the tick reads of the tick before comes
+    through arguments of its own, mrca_step_many's run-ahead slots), or the loads wait for the s_load of the EnvView again
+    (DESIGN.md 5.3)."""
     text = "\n".join(device_asm)
     lengths = {m.group(1): int(m.group(2)) for m in
                re.finditer(r"\.amdhsa_kernel (\S+).*?\.amdhsa_user_sgpr_kernarg_preload_length (\d+)", text, re.S)}
     ray = [v for k, v in lengths.items() if "raycast_kernel" in k]
     move = [v for k, v in lengths.items() if "move_kernel" in k]
     assert len(ray) == 14 and all(v == 14 for v in ray), lengths
-    assert move == [10], lengths
+    assert move == [14], lengths

@@ -197,7 +197,7 @@ def assert_state_equal(a, b, fields=STATE_FIELDS, what=""):
 
 
 def assert_hits_equal(env, ora, what=""):
-    """What every beam hit: the device's flag (sign bit of its scan ring: another robot) against the oracle's."""
+    """What every beam hit: the device's flag (its MRCA_F_HIT_BITS plane: another robot) against the oracle's."""
     got = env.hit_robot.cpu().numpy()
     want = np.asarray(ora.hit_robot).astype(bool)
     if not np.array_equal(got, want):

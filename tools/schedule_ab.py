@@ -1,0 +1,17 @@
+import sys, os, json
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/rl-collision-avoidance_amd')
+import torch, bench
+from mrca import scenario as S
+import __graft_entry__ as G
+G.build()
+cases = {
+ "stage2": (lambda: S.stage2(num_worlds=187, seed=1000), True),
+ "stage1_fidelity": (lambda: S.stage1(num_worlds=128, robots_per_world=32, seed=1000, stage_resolution=True), True),
+ "stage1_eager_views": (lambda: S.stage1(num_worlds=128, robots_per_world=32, seed=1000), False),
+ "stage1": (lambda: S.stage1(num_worlds=128, robots_per_world=32, seed=1000), True),
+}
+for name, (mk, lazy) in cases.items():
+    for sched in ("native", "chained"):
+        for chains in (1, 2, 3):
+            r = bench.env_side_figure(mk(), ticks=300, chains=chains, lazy_obs=lazy, schedule=sched)
+            print(f"{name:20s} {sched:8s} chains={chains}: {r['value']/1e6:7.1f} M  {r['ms_per_step']*1e3:6.2f} us/tick", flush=True)
