@@ -1008,7 +1008,7 @@ int mrca_event_pair_overhead(void* stream, int32_t samples, float* us_out) {
 // in lock step instead of one after the other.
 int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     if (!env) return fail(MRCA_ERR_INVALID, "env is NULL");
-    env->view.debug_flags = flags & 0x7F;
+    env->view.debug_flags = flags & 0xFF;
     const int knob = (flags >> 8) & 7;
     if (knob) {
         const int shift = knob - 1;

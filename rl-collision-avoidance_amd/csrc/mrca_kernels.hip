@@ -797,11 +797,33 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // run-time branch the default launch was 0.85 us slower (A/B on one box, profiles/r04_h_ab_raster_path_in_default_kernel.txt:
 // twice the instructions for the same instruction cache).  Since round 5 a beam's return from another robot's outline is a
 // closed form over that robot's 16-byte outline record (ray_outline_entry) instead of a walk through a window of LDS bits.
+template <int K, bool BIG, bool SEQ, int RKW>
+__device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int ray_count, int R_, const float* __restrict__ pose_p,
+                                             const float4* __restrict__ head_p, const float* __restrict__ bcos_p,
+                                             const float* __restrict__ bsin_p, uint8_t* ring_head_p, const EnvView& e);
+
 template <int K, bool BIG, bool SEQ, int RKW = 0>
 __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int only_fresh, int ray_first, int ray_count, int R_,
                                                        const float* __restrict__ pose_p, const float4* __restrict__ head_p,
                                                        const float* __restrict__ bcos_p, const float* __restrict__ bsin_p,
                                                        uint8_t* ring_head_p, EnvView e) {
+    raycast_body<K, BIG, SEQ, RKW>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e);
+#if defined(MRCA_PROFILING)
+    // debug flag 128: every workgroup casts its robot's beams a SECOND time inside the same launch -- everything it touches
+    // is in its L1 / L2 by then, there is no launch boundary in between, no kernel argument to wait for: what a tick's ray
+    // cast would cost inside a persistent kernel that never leaves the chip.  (The second pass writes another ring slot: the
+    // results of a launch under this flag are for the clock only.)  tools/hot_pass_probe.py, DESIGN.md 10.2.
+    if (MRCA_DBG(e, 128)) {
+        __syncthreads();
+        raycast_body<K, BIG, SEQ, RKW>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e);
+    }
+#endif
+}
+
+template <int K, bool BIG, bool SEQ, int RKW>
+__device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int ray_count, int R_, const float* __restrict__ pose_p,
+                                             const float4* __restrict__ head_p, const float* __restrict__ bcos_p,
+                                             const float* __restrict__ bsin_p, uint8_t* ring_head_p, const EnvView& e) {
     // (the leading arguments repeat e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head: 14
     // dwords preloaded into SGPRs, see move_kernel)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
