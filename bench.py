@@ -462,12 +462,21 @@ def assemble_line(*, args, sc, N, world_size, value, elapsed, ray_ms, mv_ms, lau
                      "kernel_sum_us": (ray_avg_s + mv_avg_s) * 1e6 if launches else None,
                      "value_at_kernel_sum": N * world_size / (ray_avg_s + mv_avg_s) if launches else None,
                      "launches_timed": launches, "kernel_timing": kernel_timing_note,
+                     # the same bytes at the rate the TIMED REGION sustained: with the run-ahead schedule the ray casts of two world
+                     # ranges overlap and the move launches run beside them, so a tick costs less than one launch's own duration
+                     "sustained": ({"achieved": value / world_size * B_ENV_STRICT / 1e9,
+                                    "frac": value / world_size * B_ENV_STRICT / 1e9 / HBM_PEAK_GBS,
+                                    "bytes_per_agent_step": B_ENV_STRICT,
+                                    "note": "SURVEY 8d's B_env (2140 B per agent-step) x `value` per GPU: the whole tick at the "
+                                            "rate the timed region ran at"} if args.mode == "env" else None),
                      "note": "HBM is the nominal roof (SURVEY 8d: 2.1 kB per agent-step).  What the launch is made of: two "
                              "residency rounds of 2048 workgroups at eight waves per SIMD, each wave a chain of dependent memory "
                              "round trips (robot record, ~2.6 field lookups per beam, LDS hand-offs) around ~546 VALU instructions "
                              "-- about half of the SIMDs' issue slots while it runs, neither issue- nor bandwidth-bound: "
                              "launch time = one workgroup's lifetime + robots / throughput (8.2 us + 3.05 us per 1000 robots, "
-                             "profiles/r05_c_*), which is why world ranges on two streams pay; DESIGN.md 5.2, 5.9"},
+                             "profiles/r05_c_*), which is why overlapping launches pay (DESIGN.md 5.2, 5.10); a second pass over the "
+                             "same robots inside one launch, everything cache-hot, costs 90 - 92 % of the first "
+                             "(profiles/r06_o_hot_pass_probe.txt): the launch does not wait for its fetches"},
     }
     if args.mode == "rollout":
         # the rollout's own roofline: the policy forward is 6.4 MFLOP per agent-step (conv1 0.49 + conv2

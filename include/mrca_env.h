@@ -174,15 +174,18 @@ int mrca_step(mrca_env* env, const float* actions_dev, void* stream);
  * step) and advances all of them -- the ordered collision pass needs every provisional pose, and identical arithmetic
  * keeps the replicas bit-identical -- but casts the lidar only for its own robots
  * [first_robot, first_robot + num_robots): scan / obs / local_goal of the other robots are left untouched.  The
- * replicated move phase bounds the speed-up (DESIGN.md 7 carries the current figures: at 50 000 robots it was 43.5 us of a
- * 144 us tick in round 4, a ceiling of 2.6x on 8 GPUs, 2.2x projected from one rank's measured share,
- * profiles/r04_u_bigworld_shards8.jsonl). */
+ * replicated move phase bounds the speed-up.  Measured (round 6, one rank's share timed on one GPU,
+ * profiles/r06_b_bigworld_shards8.jsonl): the move phase is ~20 % of a tick at every size -- 43.7 of 143 us at
+ * 50 000 robots, 98 of 474 at 200 000, 244 of 1190 at 500 000 -- so 8 GPUs project to 2.2x / 3.1x / 3.1x (a jam: 2.5 / 3.8 /
+ * 4.3x) and the ceiling, ~3.3x, does not rise with the world: there is no size from which the replicated design alone reaches
+ * 6x.  Passing it takes a sharded move phase (spatial slabs + the transitive closure of each slab's lower-indexed neighbours
+ * and a second exchange per tick); one GPU does 400 M agent-steps/s at 500 000 robots as it is. */
 int mrca_step_slice(mrca_env* env, const float* actions_dev, int32_t first_robot, int32_t num_robots, void* stream);
 
 /* The same tick for the worlds [first_world, first_world + num_worlds) ONLY: their robots advance and are observed, every
  * other world is left exactly as it is.  Worlds never interact (one `stageros` process per world in the reference:
  * stage_world1.py:17-84), so a caller may step disjoint world ranges on DIFFERENT streams -- the latency-bound move launch
- * of one range then runs under the issue-bound ray cast of another (bench.py --chains) -- or give the policy of
+ * of one range then runs next to the ray cast of another (bench.py --schedule chained) -- or give the policy of
  * one range the time the simulator spends on the other.  actions_dev is still f32[N,2] indexed by robot; only the rows of the
  * range are read.  Calls on overlapping ranges must be ordered by the caller (same stream, or events).
  * robots_per_world > 64: only the full range (MRCA_ERR_UNSUPPORTED otherwise: one world's move phase is one launch chain). */

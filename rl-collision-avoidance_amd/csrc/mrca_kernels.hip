@@ -832,7 +832,8 @@ __device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int 
     const int tid = threadIdx.x;
     // (A variant of this kernel without the early exit -- so that nothing is waited for before every request of the
     // workgroup is out -- was measured and changed nothing: 27.96 us either way, profiles/r03/r03_l_bench_env.json.  The
-    // launch is bound by VALU issue with eight waves per SIMD, not by a workgroup's own latency chain.)
+    // launch uses ~45 % of the VALU issue slots: what it waits for is a workgroup's chain of dependent round trips at full
+    // occupancy, and one early exit less does not shorten that chain -- DESIGN.md 5.2.)
     if (only_fresh && e.fresh[n] == 0) return;  // block-uniform
 
     float4* nb = reinterpret_cast<float4*>(lds);
