@@ -151,6 +151,9 @@ int mrca_arena_bytes(const mrca_config* cfg, size_t* bytes_out);
 /* Replaces: StageWorld.__init__ (stage_world1.py:17-84) + the stageros process it talks to
  * (stageros.cpp:311-437).  arena_dev may be NULL (the library allocates) or caller-owned device
  * memory of at least mrca_arena_bytes() (e.g. a torch tensor's data_ptr). */
+/* (Beside the arena an env with robots_per_world <= 64 allocates the run-ahead ring of mrca_step_many -- 53 B per robot and
+ * slot, at most 255 slots / 256 MB; 55 MB at 4096 robots -- one stream + events for the move launches and one per world range in
+ * use.  If that allocation fails the env works without it: mrca_step_many then runs the chained schedule.) */
 int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrca_env** env_out);
 int mrca_destroy(mrca_env* env);
 
@@ -212,8 +215,12 @@ int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, 
  * all of them before the call's work counts as done, and they for everything queued on `stream` before the call.  What a tick
  * then costs is its ray casts alone.  The host only enqueues (no synchronisation, nothing spins on the
  * device); the call is capturable into a hipGraph like any other (chains > 2: call it once outside the capture first).
- * (Two streams of one process may share a hardware queue -- the runtime's choice, tools/queue_alias_probe.hip -- and then run
- * one after the other: the schedule stays correct and loses its overlap.  DESIGN.md 5.10 lists what is known about it.)
+ * Streams: the HIP runtime maps a process's streams onto a few hardware queues, and two streams that share one run their
+ * kernels one after the other (tools/queue_alias_probe.hip): the schedule stays correct and silently loses its overlap.  At the
+ * FIRST call on a given `stream` (outside a capture) the env therefore warms its streams and checks, with two 40 us probe
+ * kernels per pair, that its move stream and its ranges' streams really run next to `stream` and to each other, replacing the
+ * ones that do not: ~1 ms, once, and the one place where a call of this library synchronises (`stream` and the env's own
+ * streams).  Make that first call before a timed or latency-critical region.
  * chains = -P: round 5's schedule instead -- P chains `move, ray cast, move, ray cast ...` of one world range each, half a tick
  * apart (kept for A/B runs: tools/region_sweep.py --schedule chained).  robots_per_world > 64: one chain, in order. */
 int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_actions, int32_t first_tick, int32_t num_ticks,

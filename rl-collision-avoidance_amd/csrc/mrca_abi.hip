@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -245,6 +246,13 @@ struct mrca_env {
     int ahead_slots = 0;                    // 0: the ring could not be allocated -> the chained schedule
     hipStream_t move_stream = nullptr;
     std::vector<hipEvent_t> moved;          // [kAheadTicks] "tick k's move launch is through"
+    // stream choice (choose_streams below): the caller's stream the env's streams were last checked against, how many
+    // ranges that check covered, the streams found to share a hardware queue with another one (parked until mrca_destroy)
+    bool streams_checked = false;
+    hipStream_t checked_against = nullptr;
+    int checked_ranges = 0;
+    std::vector<hipStream_t> parked;
+    unsigned long long* probe_stamps = nullptr;   // [4] device: start / end of the two probe kernels
 };
 
 constexpr int kAheadTicks = 256;            // most ticks one run-ahead pass covers (a pass ends with every stream joined: ~90 us)
@@ -282,6 +290,10 @@ static void release_side_objects(mrca_env* env) {
     for (hipEvent_t e : env->moved)
         if (e) (void)hipEventDestroy(e);
     if (env->ahead_mem) (void)hipFree(env->ahead_mem);
+    if (env->probe_stamps) (void)hipFree(env->probe_stamps);
+    env->probe_stamps = nullptr;
+    for (hipStream_t s : env->parked) (void)hipStreamDestroy(s);
+    env->parked.clear();
     for (hipEvent_t e : env->chain_moved) (void)hipEventDestroy(e);
     for (hipEvent_t e : env->chain_done) (void)hipEventDestroy(e);
     if (env->chain_fork) (void)hipEventDestroy(env->chain_fork);
@@ -699,6 +711,91 @@ int mrca_observe_worlds(mrca_env* env, int32_t first_world, int32_t num_worlds, 
     return worlds_impl(env, nullptr, first_world, num_worlds, stream, kPhaseObserve);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Which streams?  The HIP runtime maps a process's streams onto a few hardware queues (four by default, handed out by use
+// count), and two streams that share a queue run their kernels ONE AFTER THE OTHER whatever the program says: the schedules
+// below then lose what they are built for, silently (tools/queue_alias_probe.hip: of twelve streams every one shares its queue
+// with two others; tools/stream_pressure_probe.py: the same mrca_step_many call at 305 M and at 150 M agent-steps/s on the
+// Stage-2 map depending on what else the process had created -- round 5's chained schedule halves in the same states).
+// Which streams share is the runtime's business, so the env MEASURES it: two 40 us probe kernels, one on each stream of a
+// pair (both warmed first: a stream's first launch creates its queue), stamped with the constant clock; if the second started
+// only after the first had ended, the pair shares a queue: the env parks that stream (a parked stream keeps its use count on
+// its queue, so the next candidate lands elsewhere) and tries another.  At the first mrca_step_many call on a given caller's
+// stream (again if that stream changes or more ranges are asked for), never inside a capture: ~1 ms, and the one place where a
+// call of this library synchronises.
+__global__ void stream_probe_kernel(unsigned long long ticks, unsigned long long* stamps, int slot) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+    if (threadIdx.x == 0 && stamps) {
+        stamps[slot * 2 + 0] = t0;
+        stamps[slot * 2 + 1] = wall_clock64();
+    }
+}
+
+// 1: the two streams ran the probes side by side; 0: one after the other; -1: a HIP call failed
+static int streams_overlap(mrca_env* env, hipStream_t a, hipStream_t b) {
+    int serial = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(64), 0, a, 4000ull, env->probe_stamps, 0);      // 40 us
+        hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(64), 0, b, 4000ull, env->probe_stamps, 1);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+        unsigned long long h[4];
+        if (hipMemcpy(h, env->probe_stamps, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (h[2] >= h[1] || h[0] >= h[3]) ++serial;
+    }
+    return serial >= 2 ? 0 : 1;
+}
+
+static int warm_stream(hipStream_t st) {
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(1), dim3(64), 0, st, 0ull, (unsigned long long*)nullptr, 0);
+    HIP_TRY(hipStreamSynchronize(st));
+    return MRCA_OK;
+}
+
+// make `*slot` a stream that overlaps with every stream of `others`; the ones that do not are parked
+static int choose_stream(mrca_env* env, hipStream_t* slot, const std::vector<hipStream_t>& others) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        if (!*slot) HIP_TRY(hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
+        if (int rc = warm_stream(*slot)) return rc;
+        bool good = true;
+        for (hipStream_t o : others) {
+            const int ov = streams_overlap(env, o, *slot);
+            if (ov < 0) return fail(MRCA_ERR_HIP, "mrca_step_many: stream probe failed: %s", hipGetErrorString(hipGetLastError()));
+            if (ov == 0) {
+                good = false;
+                break;
+            }
+        }
+        if (good) return MRCA_OK;
+        env->parked.push_back(*slot);
+        *slot = nullptr;
+    }
+    // six candidates in a row shared a queue with somebody: take one more as it comes (correct, only not concurrent)
+    HIP_TRY(hipStreamCreateWithFlags(slot, hipStreamNonBlocking));
+    return MRCA_OK;
+}
+
+static int choose_streams(mrca_env* env, hipStream_t s0, int P) {
+    if (!env->probe_stamps) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&env->probe_stamps), 4 * sizeof(unsigned long long)));
+    if (int rc = warm_stream(s0)) return rc;
+    std::vector<hipStream_t> chosen{s0};
+    if (env->ahead_slots > 0) {
+        if (int rc = choose_stream(env, &env->move_stream, chosen)) return rc;
+        chosen.push_back(env->move_stream);
+    }
+    for (int c = 1; c < P; ++c) {
+        if (int rc = choose_stream(env, &env->chain_stream[c - 1], chosen)) return rc;
+        chosen.push_back(env->chain_stream[c - 1]);
+    }
+    env->streams_checked = true;
+    env->checked_against = s0;
+    env->checked_ranges = P;
+    if (std::getenv("MRCA_DEBUG_STREAMS"))
+        std::fprintf(stderr, "[mrca] stream check against %p: %d range stream(s) + move stream chosen, %zu candidate(s) parked\n",
+                     (void*)s0, P - 1, env->parked.size());
+    return MRCA_OK;
+}
+
 // One run-ahead pass of mrca_step_many: K <= ahead_slots + 1 ticks.  Tick k's move launch covers ALL worlds and writes slot
 // w(k) = K - 1 - k (slot 0 = the env's own fields: the pass starts from them and its last tick leaves them current), reading
 // slot w(k - 1); tick 0 goes out on the caller's stream, ticks 1 .. K - 1 on the env's move stream, back to back -- a slot per
@@ -809,6 +906,13 @@ int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_a
     }
     if (!env->chain_fork) HIP_TRY(hipEventCreateWithFlags(&env->chain_fork, hipEventDisableTiming));
     if (num_ticks == 0) return MRCA_OK;
+    if (!env->view.big && (P > 1 || (!chained && env->ahead_slots > 0)) &&
+        (!env->streams_checked || env->checked_against != s0 || env->checked_ranges < P)) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s0, &cs);
+        if (cs == hipStreamCaptureStatusNone)          // (inside a capture: the streams as they are)
+            if (int rc = choose_streams(env, s0, P)) return rc;
+    }
     if (!chained && !env->view.big && env->ahead_slots > 0) {
         // the run-ahead schedule, in passes of at most ahead_slots + 1 ticks (a pass ends with every stream joined)
         const int per = env->ahead_slots + 1 < kAheadTicks ? env->ahead_slots + 1 : kAheadTicks;

@@ -286,8 +286,10 @@ class VecStageWorld:
 
     def step_many(self, actions, first_tick, num_ticks, chains=1):
         """``num_ticks`` ticks from ONE call: tick k takes ``actions[(first_tick + k) % len(actions)]`` (a list of f32[N,2]
-        device tensors: a scripted scenario, the benchmark's action pool); ``chains`` world ranges tick on streams of their
-        own, half a tick apart (mrca_step_many).  Equal to ``num_ticks`` calls of ``step``."""
+        device tensors: a scripted scenario, the benchmark's action pool).  Equal to ``num_ticks`` calls of ``step``.
+        ``chains`` = P > 0: the library's run-ahead schedule -- the move launches on a stream of the env's own, ahead of the ray
+        casts of P world ranges on P streams (mrca_step_many); ``chains`` = -P: round 5's P chains half a tick
+        apart.  The first call on a stream spends ~1 ms warming and checking the env's streams (and synchronises once)."""
         # (the pointer table of a list is built once per list object: a 20-tick region is 0.6 ms, sixteen data_ptr() calls and
         # their checks are 2 % of it.  The entry keeps the tensors themselves: an element replaced in place -- pool[i] = t --
         # fails the identity compare below and rebuilds the table, and a table never outlives the memory it points at)

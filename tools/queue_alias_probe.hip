@@ -20,11 +20,15 @@ __global__ void busy_kernel(unsigned long long ticks, unsigned long long* stamps
 int main(int argc, char** argv) {
     const int S = argc > 1 ? atoi(argv[1]) : 12;
     const int high = argc > 2 ? atoi(argv[2]) : -1;      // index of a stream to create at HIGH priority (-1: none)
+    const int masked_from = argc > 3 ? atoi(argv[3]) : 1 << 30;   // streams with index >= this: hipExtStreamCreateWithCUMask, all CUs
     std::vector<hipStream_t> st(S, nullptr);
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     for (int i = 1; i < S; ++i) {
-        if (i == high) (void)hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi);
+        if (i >= masked_from) {
+            uint32_t mask[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+            if (hipExtStreamCreateWithCUMask(&st[i], 8, mask) != hipSuccess) printf("stream %d: hipExtStreamCreateWithCUMask failed\n", i);
+        } else if (i == high) (void)hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, hi);
         else (void)hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
     }
     unsigned long long* stamps;
@@ -36,8 +40,8 @@ int main(int argc, char** argv) {
     void* a1[] = {&ticks, &stamps, &s1};
     for (int i = 0; i < S; ++i) (void)hipLaunchKernel((const void*)busy_kernel, dim3(1), dim3(64), a0, 0, st[i]);
     (void)hipDeviceSynchronize();
-    printf("%d streams (0 = NULL stream%s); '#': the pair ran one after the other, '.': overlapped\n    ", S,
-           high > 0 ? ", one at high priority" : "");
+    printf("%d streams (0 = NULL stream%s%s); '#': the pair ran one after the other, '.': overlapped\n    ", S,
+           high > 0 ? ", one at high priority" : "", masked_from < S ? ", the upper ones created with a full CU mask" : "");
     for (int j = 0; j < S; ++j) printf("%2d ", j);
     printf("\n");
     for (int i = 0; i < S; ++i) {
