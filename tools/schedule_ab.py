@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""mrca_step_many's two schedules side by side in ONE fresh process: run-ahead ("native": the move launches on a stream of
+their own, ahead of the ray casts -- DESIGN.md 5.10) against round 5's chained one ("chained": `move, ray, move, ray ...` per
+world range), 1 - 3 world ranges, on the four configurations bench.py quotes (Stage-2 map, fidelity mode, reference-shaped
+observations, configs[1]); 300 ticks each through bench.env_side_figure.        python tools/schedule_ab.py
+(profiles/r06_h_schedule_ab_fresh_process.txt)"""
 import sys, os, json
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/rl-collision-avoidance_amd')
 import torch, bench
