@@ -4,9 +4,13 @@ their own, ahead of the ray casts -- DESIGN.md 5.10) against round 5's chained o
 world range), 1 - 3 world ranges, on the four configurations bench.py quotes (Stage-2 map, fidelity mode, reference-shaped
 observations, configs[1]); 300 ticks each through bench.env_side_figure.        python tools/schedule_ab.py
 (profiles/r06_h_schedule_ab_fresh_process.txt)"""
-import sys, os, json
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/rl-collision-avoidance_amd')
-import torch, bench
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rl-collision-avoidance_amd"))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
 from mrca import scenario as S
 import __graft_entry__ as G
 G.build()
