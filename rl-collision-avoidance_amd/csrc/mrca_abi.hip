@@ -2,6 +2,7 @@
 // table / map upload, kernel sequencing and optional HIP-event timing.  No torch, no Python.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -248,8 +249,7 @@ struct mrca_env {
     std::vector<hipEvent_t> moved;          // [kAheadTicks] "tick k's move launch is through"
     // stream choice (choose_streams below): the caller's stream the env's streams were last checked against, how many
     // ranges that check covered, the streams found to share a hardware queue with another one (parked until mrca_destroy)
-    bool streams_checked = false;
-    hipStream_t checked_against = nullptr;
+    std::vector<hipStream_t> checked_against;    // caller's streams the env's CURRENT streams have been checked against
     int checked_ranges = 0;
     std::vector<hipStream_t> parked;
     unsigned long long* probe_stamps = nullptr;   // [4] device: start / end of the two probe kernels
@@ -777,6 +777,7 @@ static int choose_stream(mrca_env* env, hipStream_t* slot, const std::vector<hip
 
 static int choose_streams(mrca_env* env, hipStream_t s0, int P) {
     if (!env->probe_stamps) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&env->probe_stamps), 4 * sizeof(unsigned long long)));
+    const size_t parked_before = env->parked.size();
     if (int rc = warm_stream(s0)) return rc;
     std::vector<hipStream_t> chosen{s0};
     if (env->ahead_slots > 0) {
@@ -787,12 +788,15 @@ static int choose_streams(mrca_env* env, hipStream_t s0, int P) {
         if (int rc = choose_stream(env, &env->chain_stream[c - 1], chosen)) return rc;
         chosen.push_back(env->chain_stream[c - 1]);
     }
-    env->streams_checked = true;
-    env->checked_against = s0;
-    env->checked_ranges = P;
+    // (a caller that alternates between a few streams is checked once per stream, not once per call -- unless a check had to
+    // replace one of the env's streams: then what was verified before no longer holds)
+    if (env->parked.size() != parked_before || P > env->checked_ranges) env->checked_against.clear();
+    if (env->checked_against.size() >= 8) env->checked_against.erase(env->checked_against.begin());
+    env->checked_against.push_back(s0);
+    if (P > env->checked_ranges) env->checked_ranges = P;
     if (std::getenv("MRCA_DEBUG_STREAMS"))
         std::fprintf(stderr, "[mrca] stream check against %p: %d range stream(s) + move stream chosen, %zu candidate(s) parked\n",
-                     (void*)s0, P - 1, env->parked.size());
+                     (void*)s0, env->checked_ranges - 1, env->parked.size());
     return MRCA_OK;
 }
 
@@ -907,7 +911,8 @@ int mrca_step_many(mrca_env* env, const float* const* actions_dev, int32_t num_a
     if (!env->chain_fork) HIP_TRY(hipEventCreateWithFlags(&env->chain_fork, hipEventDisableTiming));
     if (num_ticks == 0) return MRCA_OK;
     if (!env->view.big && (P > 1 || (!chained && env->ahead_slots > 0)) &&
-        (!env->streams_checked || env->checked_against != s0 || env->checked_ranges < P)) {
+        (env->checked_ranges < P ||
+         std::find(env->checked_against.begin(), env->checked_against.end(), s0) == env->checked_against.end())) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s0, &cs);
         if (cs == hipStreamCaptureStatusNone)          // (inside a capture: the streams as they are)

@@ -296,6 +296,36 @@ def test_step_many_first_call_inside_a_capture_and_passes_longer_than_the_ring(h
     env.close()
 
 
+def test_step_many_from_alternating_caller_streams(hip):
+    """mrca_step_many checks its streams against the caller's stream at the first call on it (hardware-queue sharing,
+    DESIGN.md 5.10); a caller that alternates between the NULL stream and two streams of its own must get the same world
+    whichever stream a call came in on -- each call ordered behind the one before by the caller's own events."""
+    import bench
+    sc = S.stage1(num_worlds=6, robots_per_world=16, seed=41)
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    pool = bench.action_pool(sc.num_robots, env.device, 13, depth=48)
+    host_pool = [a.cpu().numpy() for a in pool]
+    env.reset()
+    ora.reset()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    k = 0
+    for rep in range(6):
+        s = streams[rep % 3]
+        s.wait_stream(streams[(rep - 1) % 3])
+        with torch.cuda.stream(s):
+            env.step_many(pool, k, 8, 2)
+        for j in range(8):
+            ora.step(host_pool[k + j])
+        k += 8
+    torch.cuda.synchronize()
+    env.invalidate_views()
+    U.assert_state_equal(U.HostView(env), ora, what="48 ticks from three alternating caller streams")
+    env.check()
+    env.close()
+
+
 def test_world_range_calls_leave_the_other_worlds_alone(hip):
     """mrca_step_worlds / mrca_move_worlds / mrca_observe_worlds: only the worlds of the range tick; a world stepped alone
     ends where the same world of a fully stepped env ends."""
