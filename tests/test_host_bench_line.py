@@ -124,6 +124,23 @@ def test_the_action_pool_is_as_deep_as_the_region_it_serves():
     assert len({tuple(p[0].tolist()) for p in pool}) == 120            # no entry repeats
 
 
+def test_side_figures_have_their_scenarios_and_a_process_of_their_own():
+    """bench.py --side-figure NAME: the three env side figures are measured by fresh processes (DESIGN.md 5.10 "streams"); the
+    scenario of each is what the documents quote -- configs[2] (187 Stage-2 worlds x 44 robots = 8228), the same worlds at
+    Stage's resolutions, the same worlds with the reference-shaped views formed every tick."""
+    sc, lazy = bench.side_scenario("stage2_side_figure", "stage1", 128, 32, 1000)
+    assert sc.num_robots == 8228 and sc.robots_per_world == 44 and lazy is True
+    sc, lazy = bench.side_scenario("fidelity_side_figure", "stage1", 128, 32, 1000)
+    assert sc.num_robots == 4096 and getattr(sc, "collision_raster", 0.0) == 0.2 and abs(sc.grid.cell - 0.2) < 1e-9 and lazy is True
+    sc, lazy = bench.side_scenario("reference_shaped_obs_side_figure", "stage1", 128, 32, 1000)
+    assert sc.num_robots == 4096 and getattr(sc, "collision_raster", 0.0) == 0.0 and lazy is False
+    import pytest
+    with pytest.raises(SystemExit):
+        bench.side_scenario("no_such_figure", "stage1", 128, 32, 1000)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"--side-figure" in sys.argv[1:]' in src and "subprocess.run(cmd" in src
+
+
 def test_the_gradient_bucket_of_the_policy_is_8_69_MB():
     """what the train side figure's collective will report at N > 1: one flat fp32 bucket of every parameter of CNNPolicy"""
     import torch
