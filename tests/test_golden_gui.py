@@ -385,3 +385,8 @@ def test_motion_follows_heading(gui):
             assert dx > 0                                              # forward = +x of the body frame, v >= 0
             n += 1
     assert n >= 3
+    # ... and the heading never turns faster than the action bound allows: |w| <= 1 rad/s (action_bound, ppo_stage2.py:179, circle_test.py:96) x 10 ticks x 0.1 s
+    # = 57.3 deg between two frames (a weak bound like the displacement's: 10 ticks per frame is read off the same picture)
+    turns = [abs(((b[3] - a[3] + 180.0) % 360.0) - 180.0) for a, b in zip(lab[:-1], lab[1:])
+             if np.isfinite(a[3]) and np.isfinite(b[3])]
+    assert len(turns) >= 8 and max(turns) <= 57.3 + 1.0, turns
