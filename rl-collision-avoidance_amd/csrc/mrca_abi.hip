@@ -531,6 +531,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
         const float reach = 2.0f * 0.2907f + 0.001f + (cfg->collision_raster > 0.0f ? 1.4143f * cfg->collision_raster : 0.0f);
         v.collide_reach2 = cfg->collision_raster > 0.0f ? reach * reach : mrca::kCollideReach2;
     }
+    v.r_magic = R <= 64 ? (uint32_t)(((1ull << 32) + (uint64_t)R - 1) / (uint64_t)R) : 0u;
     v.debug_flags = 0;
     // Launch shape of the ray cast, measured (profiles/r02/r02_c_ablation_launch_shapes.txt, 4096 / 8228 robots, HIP events):
     //   2 beams per thread one after the other, first wave prepares the neighbours   28.1 / 33.7 us   <- product

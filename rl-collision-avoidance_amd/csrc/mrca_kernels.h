@@ -95,6 +95,7 @@ struct EnvView {
     int32_t ray_shift;    // raycast_kernel marches 1 << ray_shift beams per thread in lock step
     int32_t ray_sequential; // 1 (with ray_shift 1): the two beams of a thread are marched one after the other
     int32_t ray_prep_wave;  // 1: a dedicated wave prepares the neighbour list (blockDim = beams >> ray_shift + 64)
+    uint32_t r_magic;     // ceil(2^32 / R) for R <= 64: n / R == umulhi(n, r_magic) for every robot index n < 2^24
     int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
     uint32_t* status;     // [1] sticky device-side error bits (kStatus*), read and cleared by mrca_check()
 };

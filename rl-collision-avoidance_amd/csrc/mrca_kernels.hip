@@ -780,10 +780,11 @@ __device__ __forceinline__ void mask_or(unsigned long long* p, unsigned long lon
 
 // blockIdx -> robot: consecutive robots (one world's robots) share an XCD's L2 (block b runs on
 // XCD b % 8, guide T1); a pure permutation, so correctness never depends on it.
+// (unsigned arithmetic: b and N are never negative, and a signed % 8 and / 8 are eleven scalar instructions where three do)
 __device__ __forceinline__ int block_to_robot(int b, int N) {
-    if (N % 8) return b;
-    const int per = N / 8;
-    return (b % 8) * per + b / 8;
+    const uint32_t ub = (uint32_t)b, un = (uint32_t)N;
+    if (un & 7u) return b;
+    return (int)((ub & 7u) * (un >> 3) + (ub >> 3));
 }
 
 // The march reads the free-rectangle field straight from its L1/L2-resident global copy: ~2 dependent
@@ -850,7 +851,10 @@ __device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int 
     const int prep_base = extra ? T : 0;
     const bool is_prep = tid >= prep_base && tid < prep_base + kWave;   // wave-uniform
     const bool marches = tid < T;                                       // wave-uniform
-    const int world = n / R_;
+    // n / R without the ~25 scalar instructions of a 32-bit division: small worlds (R <= 64, n < 2^24) take the exact multiply-high
+    // with the host's ceil(2^32 / R) (error n x (m R - 2^32) < 2^24 x 64 < 2^32).  (A scalar instruction costs the launch twice
+    // what a vector one costs -- one scalar unit per CU for 32 waves: profiles/r06_ac_*.)
+    const int world = BIG ? n / R_ : (R_ == 1 ? n : (int)__umulhi((uint32_t)n, e.r_magic));   // (2^32 / 1 does not fit the magic)
     const int local = n - world * R_;
     // the robot's own record: pose, sin / cos and the field entry of its cell.  Block-uniform -- but fetched with VECTOR
     // loads (the index goes through an opaque zero): as scalar loads they shared the out-of-order scalar counter with
@@ -1114,9 +1118,11 @@ __device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int 
     //     business (materialize_kernel).  Every thread stores its own beams -- lane l of a wave holds beam base + l, so
     //     each store instruction of a wave covers 256 contiguous bytes.
     {
-        float* ring_row = e.scan_ring + (size_t)n * e.F * e.B;
+        // (row = n x F fits 32 bits -- n < 2^24, F <= 8 --: one 32 x 32 -> 64 multiply per address instead of a 64 x 32 chain of ten)
+        const uint32_t row = (uint32_t)n * (uint32_t)e.F;
+        float* ring_row = e.scan_ring + (size_t)row * (uint32_t)e.B;
         const int words = e.B >> 6;
-        unsigned long long* hit_row = e.hit_bits + (size_t)n * e.F * words;
+        unsigned long long* hit_row = e.hit_bits + (size_t)row * (uint32_t)words;
         const int new_slot = ring_slot + 1 == e.F ? 0 : ring_slot + 1;
         const bool fresh = __builtin_amdgcn_readfirstlane((int)fresh_byte) != 0;
 #pragma unroll
