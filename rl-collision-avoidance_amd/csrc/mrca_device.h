@@ -292,6 +292,15 @@ MRCA_HD MarchOrigin march_origin(const Field& field, const GridGeom& g, float ox
 // a wavefront stay in lock step.  No (tx, ty) state is carried -- boundary times are always re-derived
 // from the closed form, which is what makes every path through here produce the same numbers as
 // grid_march.
+// a loop counter kept PER LANE in a vector register (the compiler would otherwise hold a uniform counter in an SGPR and turn
+// its test into a lane mask: s_add, s_cmp, s_cselect, s_or, s_mov per trip)
+MRCA_HD int lane_counter(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+
 template <class Field>
 MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const MarchOrigin& org, float dx, float dy,
                               float tmax) {
@@ -318,10 +327,14 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
     // The state is just the next pending boundary on each axis (the cell follows from it).
     int bx = ix0 + ux;
     int by = iy0 + uy;
-    float t = 0.0f;
-    bool hit = false;
-    int guard = kMaxMarchSteps;
+    // (the loop's bookkeeping the vector way: the result is selected inside the loop -- a ray hits once, then leaves it -- and the
+    // trip guard is a per-lane counter: carried as lane MASKS they cost three and five scalar instructions per trip, and a
+    // scalar instruction costs the launch twice a vector one, profiles/r06_ac_*)
+    float out = tmax;
+    int guard = lane_counter(kMaxMarchSteps);
+    bool hit;
     do {
+        float t;
         // faces of the rectangle known to be free: e cells beyond the current cell's own far face
         const int ex = (int)(v & 255u), ey = (int)((v >> 8) & 255u);   // (both as 8-bit fields: one v_and / v_bfe + a 24-bit mad each)
         const int Bx = mad24(ex, sx, bx);
@@ -332,7 +345,7 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
         const float tBy = ynz ? rawy : kInf;
         const bool xe = tBx < tBy;  // leaves through the x face (ties: y first)
         t = xe ? tBx : tBy;
-        if (t >= tmax_c) break;
+        if (t >= tmax_c) { hit = false; break; }
         // the other ("secondary") axis: which of its crossings were consumed before time t?
         // x exit: y crossings with ty(b) <= t;  y exit: x crossings with tx(b) < t.
         const float fS = xe ? fy : fx;
@@ -363,8 +376,10 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
         by = xe ? bS : By + sy;
         v = field(bx - ux, by - uy, qbytes);  // cells outside the map read as empty (the zero border)
         hit = v == kCellOccupied;
-    } while (!hit && --guard > 0);
-    return hit ? t * g.cell : tmax;
+        out = hit ? t * g.cell : out;
+        guard = lane_counter(guard - 1);
+    } while (!hit && guard > 0);
+    return out;
 }
 
 template <class Field>
