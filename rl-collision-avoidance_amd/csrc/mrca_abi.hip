@@ -1,6 +1,8 @@
 // mrca_abi.hip -- host side of include/mrca_env.h: config validation, the SoA device arena,
 // table / map upload, kernel sequencing and optional HIP-event timing.  No torch, no Python.
 #include <hip/hip_runtime.h>
+#include <string>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -533,6 +535,10 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     }
     v.r_magic = R <= 64 ? (uint32_t)(((1ull << 32) + (uint64_t)R - 1) / (uint64_t)R) : 0u;
     v.debug_flags = 0;
+#if defined(MRCA_PROFILING)
+    v.launch_stamps = nullptr;
+    v.launch_slot = 0;
+#endif
     // Launch shape of the ray cast, measured (profiles/r02/r02_c_ablation_launch_shapes.txt, 4096 / 8228 robots, HIP events):
     //   2 beams per thread one after the other, first wave prepares the neighbours   28.1 / 33.7 us   <- product
     //   1 beam per thread (512 threads), first wave prepares                           31.6 / 41.1 us
@@ -801,6 +807,81 @@ static int choose_streams(mrca_env* env, hipStream_t s0, int P) {
     return MRCA_OK;
 }
 
+#if defined(MRCA_PROFILING)
+// Profiling build, MRCA_LAUNCH_STAMPS=1: the timeline of every run-ahead pass without a profiler attached (rocprofv3's tracing
+// triples the host's cost per launch, and a short region is host-paced) -- every launch of the pass stamps its first start and
+// last end on the device's constant clock (MRCA_LAUNCH_BEGIN / _END), the host notes when it enqueued it; printed to stderr
+// after a device synchronisation at the end of the pass.  tools/region_once.py, DESIGN.md 5.10.
+struct LaunchLog {
+    unsigned long long* dev = nullptr;
+    std::vector<std::string> what;
+    std::vector<double> host_at;
+    double host_t0 = 0.0;
+    bool on = false;
+};
+static LaunchLog g_log;
+constexpr int kLogSlots = 2048;
+static double host_now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static void log_begin() {
+    g_log.on = getenv("MRCA_LAUNCH_STAMPS") != nullptr;
+    if (!g_log.on) return;
+    if (!g_log.dev && hipMalloc(reinterpret_cast<void**>(&g_log.dev), kLogSlots * 16) != hipSuccess) {
+        g_log.on = false;
+        return;
+    }
+    std::vector<unsigned long long> init((size_t)kLogSlots * 2);
+    for (int i = 0; i < kLogSlots; ++i) {
+        init[2 * i] = ~0ull;
+        init[2 * i + 1] = 0ull;
+    }
+    (void)hipMemcpy(g_log.dev, init.data(), init.size() * 8, hipMemcpyHostToDevice);
+    g_log.what.clear();
+    g_log.host_at.clear();
+    g_log.host_t0 = host_now_us();
+}
+static void log_note(const char* kind, int tick, int range) {      // a host-side call that is not a launch
+    if (!g_log.on) return;
+    char buf[64];
+    snprintf(buf, sizeof buf, "%s t%d r%d", kind, tick, range);
+    fprintf(stderr, "  host %7.1f us: %s\n", host_now_us() - g_log.host_t0, buf);
+}
+static void log_tag(mrca::EnvView& v, const char* kind, int tick, int range) {
+    v.launch_stamps = nullptr;
+    if (!g_log.on || (int)g_log.what.size() >= kLogSlots) return;
+    char buf[64];
+    snprintf(buf, sizeof buf, "%s t%d r%d", kind, tick, range);
+    v.launch_stamps = g_log.dev;
+    v.launch_slot = (int)g_log.what.size();
+    g_log.what.push_back(buf);
+    g_log.host_at.push_back(host_now_us() - g_log.host_t0);
+}
+static void log_end() {
+    if (!g_log.on) return;
+    const double host_done = host_now_us() - g_log.host_t0;
+    (void)hipDeviceSynchronize();
+    const double synced = host_now_us() - g_log.host_t0;
+    std::vector<unsigned long long> h((size_t)kLogSlots * 2);
+    (void)hipMemcpy(h.data(), g_log.dev, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < g_log.what.size(); ++i) t0 = h[2 * i] < t0 ? h[2 * i] : t0;
+    fprintf(stderr, "# pass of %zu launches: host enqueued for %.1f us, synchronised at %.1f us; device times from the first start\n",
+            g_log.what.size(), host_done, synced);
+    for (size_t i = 0; i < g_log.what.size(); ++i)
+        fprintf(stderr, "%-14s enqueued %7.1f | starts %7.2f ends %7.2f (%6.2f us)\n", g_log.what[i].c_str(), g_log.host_at[i],
+                (double)(h[2 * i] - t0) / 100.0, (double)(h[2 * i + 1] - t0) / 100.0, (double)(h[2 * i + 1] - h[2 * i]) / 100.0);
+}
+#define MRCA_LOG_BEGIN() log_begin()
+#define MRCA_LOG_TAG(v, kind, tick, range) log_tag(v, kind, tick, range)
+#define MRCA_LOG_END() log_end()
+#else
+#define MRCA_LOG_BEGIN() ((void)0)
+#define MRCA_LOG_TAG(v, kind, tick, range) ((void)0)
+#define MRCA_LOG_END() ((void)0)
+#endif
+
+
 // One run-ahead pass of mrca_step_many: K <= ahead_slots + 1 ticks.  Tick k's move launch covers ALL worlds and writes slot
 // w(k) = K - 1 - k (slot 0 = the env's own fields: the pass starts from them and its last tick leaves them current), reading
 // slot w(k - 1); tick 0 goes out on the caller's stream, ticks 1 .. K - 1 on the env's move stream, back to back -- a slot per
@@ -814,19 +895,28 @@ static int run_ahead_pass(mrca_env* env, const float* const* act, int K, int P, 
     auto first_world = [&](int c) { return (int)((int64_t)c * W / P); };
     hipError_t herr = hipSuccess;
     bool move_forked = false;
-    // Ticks are enqueued in BLOCKS -- [0], [1], [2, 3], then fours: a block's move launches first, ONE event behind the last of
-    // them, then every range's stream waits for that event once and takes the block's ray casts.  hipStreamWaitEvent is the
-    // dearest call here (4.0 us of host time against 2.35 for a launch, profiles/r06_b_anyorder_probe.txt): a wait per tick
-    // and range made the host 15.8 us per tick against the device's 19.1 -- any hiccup starved the queues.  The move launches
-    // are far ahead of the ray casts from the third tick on (8.5 us against 19 per tick), so waiting for a block's LAST move
-    // launch delays no ray cast; the first two ticks are blocks of their own so that the first ray casts start at once.
-    for (int a = 0; a < K && herr == hipSuccess;) {
-        const int len = a < 2 ? 1 : a < 4 ? 2 : 4;
-        const int e = a + len < K ? a + len : K;
-        hipStream_t sm = a == 0 ? s0 : env->move_stream;
-        if (a == 1) {                       // the move stream starts behind tick 0's move launch (and so behind the caller's work)
-            herr = hipStreamWaitEvent(env->move_stream, env->moved[0], 0);
-            if (herr != hipSuccess) break;
+    MRCA_LOG_BEGIN();
+    // Ticks are enqueued in BLOCKS -- [0], [1], [2], [3], then fours: a block's move launches, ONE event behind the last of them,
+    // and every range's stream waits for that event once before it takes the block's ray casts.  hipStreamWaitEvent is the
+    // dearest call here (4.6 us of host time against ~3 for a launch: a build with host timers, profiles/r06_ai_*): a wait per
+    // tick and range made the host 15.8 us per tick against the device's 19.1 -- any hiccup starved the queues.
+    // The HOST ORDER matters as much: the host needs ~13 us per tick, the device ~16.5, so the device is never far behind the
+    // host and what is enqueued late starts late.  The move launches of block b + 3 are therefore enqueued BEFORE the ray casts
+    // of block b: they have a queue of their own, under load they come ~13 us apart (not 8.5: the launch stamps of the
+    // profiling build, MRCA_LAUNCH_STAMPS), and a ray cast waits 10 us beyond the end of the move launch it depends on.
+    // Measured (own ticks on the caller's stream x blocks of lead, profiles/r06_ai_*): lead 1 (round 6's first form) 463 us
+    // per 20-tick region, lead 2 - 4 with one or two own ticks 436 - 445; tick 0 alone on the caller's stream and lead 3 kept.
+    int first_of[kAheadTicks + 2];
+    int nb = 0;
+    for (int a = 0; a < K; a += a < 4 ? 1 : 4) first_of[nb++] = a;
+    first_of[nb] = K;
+    constexpr int own = 1;                       // ticks below this one: move launches on the caller's stream
+    auto moves_of = [&](int b) {
+        const int a = first_of[b], e = first_of[b + 1];
+        hipStream_t sm = a < own ? s0 : env->move_stream;
+        if (a >= own && !move_forked) {       // the move stream starts behind the caller's last move launch (and so behind the caller's work)
+            herr = hipStreamWaitEvent(env->move_stream, env->moved[a - 1], 0);
+            if (herr != hipSuccess) return;
             move_forked = true;
         }
         for (int k = a; k < e; ++k) {
@@ -834,15 +924,18 @@ static int run_ahead_pass(mrca_env* env, const float* const* act, int K, int P, 
             const mrca::EnvView in = slot_view(env, k == 0 ? 0 : K - k);
             mv.world_first = 0;
             mv.world_count = W;
+            MRCA_LOG_TAG(mv, "move", k, 0);
             mrca::launch_move(mv, act[k], sm, nullptr, nullptr, &in);
         }
         herr = hipEventRecord(env->moved[e - 1], sm);
-        if (herr != hipSuccess) break;
+    };
+    auto rays_of = [&](int b) {
+        const int a = first_of[b], e = first_of[b + 1];
         for (int c = 0; c < P && herr == hipSuccess; ++c) {
             hipStream_t sc = stream_of(c);
-            if (c > 0 || a > 0) {           // (range 0's first ray cast follows tick 0's move launch on the caller's stream itself)
+            if (c > 0 || a >= own) {        // (range 0's first ray casts follow their ticks' move launches on the caller's stream itself)
                 herr = hipStreamWaitEvent(sc, env->moved[e - 1], 0);
-                if (herr != hipSuccess) break;
+                if (herr != hipSuccess) return;
             }
             const int w0 = first_world(c), wn = first_world(c + 1) - w0;
             for (int k = a; k < e; ++k) {
@@ -851,11 +944,17 @@ static int run_ahead_pass(mrca_env* env, const float* const* act, int K, int P, 
                 rv.ray_count = wn * R;
                 rv.world_first = w0;
                 rv.world_count = wn;
+                MRCA_LOG_TAG(rv, "ray", k, c);
                 mrca::launch_raycast(rv, /*only_fresh=*/0, sc);
                 if (!env->cfg.lazy_obs) mrca::launch_materialize(rv, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, sc);
             }
         }
-        a = e;
+    };
+    constexpr int lead = 3;                      // how many blocks the move launches are enqueued ahead of the ray casts (>= 1)
+    for (int b = 0; b < nb && b < lead && herr == hipSuccess; ++b) moves_of(b);
+    for (int b = 0; b < nb && herr == hipSuccess; ++b) {
+        if (b + lead < nb) moves_of(b + lead);
+        if (herr == hipSuccess) rays_of(b);
     }
     // join: the caller's stream continues when every range is through (the move stream is: range 0 waited for its last launch)
     hipError_t jerr = hipSuccess;
@@ -871,6 +970,7 @@ static int run_ahead_pass(mrca_env* env, const float* const* act, int K, int P, 
             if (jerr == hipSuccess) jerr = e1 != hipSuccess ? e1 : e2;
         }
     }
+    MRCA_LOG_END();
     if (herr != hipSuccess) return fail(MRCA_ERR_HIP, "mrca_step_many: %s", hipGetErrorString(herr));
     if (jerr != hipSuccess) return fail(MRCA_ERR_HIP, "mrca_step_many (join): %s", hipGetErrorString(jerr));
     HIP_TRY(hipGetLastError());

@@ -59,16 +59,21 @@ MRCA_HD void sincos_det(float th, float* sn, float* cs) {
 // IEEE quotient for every float with 2^-100 <= |d| <= 2^100 (exhaustive sweep over all 2^32 bit patterns on the MI355X,
 // tools/check_rcp.hip, profiles/r02/r02_e_check_rcp.txt: 0 mismatches; the mismatches outside are results that underflow) --
 // in 3 instructions instead of the ~11 of the compiler's division expansion; anything outside that range takes the IEEE
-// division.  The host build (test harness) is the plain quotient, which is the specification.
+// division.  The test for "outside" is ONE wave-uniform branch (a ballot): written as a per-lane `if` it cost every caller
+// eleven scalar instructions and three branches of exec-mask bookkeeping around a path no beam direction ever takes
+// (profiles/r06_ac_*: a scalar instruction costs the ray cast twice a vector one).  PRECONDITION d != 0 -- a zero yields NaN,
+// not an infinity: every caller tests for it anyway (`d != 0 ? r : inf` with r computed unconditionally, so that the select
+// stays a select), and an axis-parallel beam must not send its whole wave down the slow path.
+// The host build (test harness) is the plain quotient, which is the specification.
 MRCA_HD float rcp_exact(float d) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float a = fabsf(d);
-    if (a >= 7.8886090522101181e-31f && a <= 1.2676506002282294e30f) {
-        const float r = __builtin_amdgcn_rcpf(d);
-        const float e = __builtin_fmaf(-d, r, 1.0f);
-        return __builtin_fmaf(e, r, r);
-    }
-    return 1.0f / d;
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    const float fast = __builtin_fmaf(e, r, r);
+    const bool outside = !(a >= 7.8886090522101181e-31f && a <= 1.2676506002282294e30f) && a != 0.0f;
+    if (__builtin_amdgcn_ballot_w64(outside) != 0ull) return outside ? 1.0f / d : fast;
+    return fast;
 #else
     return 1.0f / d;
 #endif
@@ -292,6 +297,17 @@ MRCA_HD MarchOrigin march_origin(const Field& field, const GridGeom& g, float ox
 // a wavefront stay in lock step.  No (tx, ty) state is carried -- boundary times are always re-derived
 // from the closed form, which is what makes every path through here produce the same numbers as
 // grid_march.
+// x exit of a jump: a crossing is consumed when its time is <= t; y exit: when it is < t.  Both as ONE strict comparison against
+// this bound: t itself, or the next float above it.  t >= 0 (a time along the ray; a -0 counts as +0), finite.
+MRCA_HD float at_or_before(float t, bool inclusive) {
+    uint32_t u;
+    __builtin_memcpy(&u, &t, 4);
+    u = (u & 0x7FFFFFFFu) + (inclusive ? 1u : 0u);
+    float r;
+    __builtin_memcpy(&r, &u, 4);
+    return r;
+}
+
 // a loop counter kept PER LANE in a vector register (the compiler would otherwise hold a uniform counter in an SGPR and turn
 // its test into a lane mask: s_add, s_cmp, s_cselect, s_or, s_mov per trip)
 MRCA_HD int lane_counter(int x) {
@@ -315,8 +331,9 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
     uint32_t v = xpos ? vq >> 16 : vq & 0xFFFFu;  // carried: one field lookup per jump
     if (v == kCellOccupied) return 0.0f;
     if (!(tmax_c > 0.0f)) return tmax;
-    const float inv_dx = xnz ? rcp_exact(dx) : kInf;
-    const float inv_dy = ynz ? rcp_exact(dy) : kInf;
+    const float rdx = rcp_exact(dx), rdy = rcp_exact(dy);   // (unconditionally: a select, not a branch around the ballot inside)
+    const float inv_dx = xnz ? rdx : kInf;
+    const float inv_dy = ynz ? rdy : kInf;
     const int sx = xpos ? 1 : -1, sy = ypos ? 1 : -1;
     const int ux = xpos ? 1 : 0, uy = ypos ? 1 : 0;      // current cell = pending boundary - u, on each axis
     // a pending boundary only ever moves in the direction of travel: clamp(b, from b0) = med3(b, b0, lim)
@@ -327,14 +344,18 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
     // The state is just the next pending boundary on each axis (the cell follows from it).
     int bx = ix0 + ux;
     int by = iy0 + uy;
-    // (the loop's bookkeeping the vector way: the result is selected inside the loop -- a ray hits once, then leaves it -- and the
-    // trip guard is a per-lane counter: carried as lane MASKS they cost three and five scalar instructions per trip, and a
-    // scalar instruction costs the launch twice a vector one, profiles/r06_ac_*)
+    // The loop's bookkeeping the vector way (a scalar instruction costs the launch twice a vector one, profiles/r06_ac_*):
+    //   * the result is selected inside the loop -- a ray hits once, then leaves it;
+    //   * ONE exit: `left`, a per-lane trip counter that a hit, the end of the beam and the trip guard all set to 0 (as lane
+    //     MASKS the three exits cost eleven scalar instructions per trip);
+    //   * the secondary axis is settled for every lane and selected away for an axis-parallel ray (its numbers are NaNs then,
+    //     never used): a branch around it cost the exec-mask bookkeeping of a region per trip;
+    //   * "consumed at or before t" is "before the next float above t" (t >= 0 by construction; -0 counts as +0; denormals are
+    //     honoured, .amdhsa_float_denorm_mode_32 3): one bit trick instead of an equality compare and two mask operations per
+    //     candidate.
     float out = tmax;
-    int guard = lane_counter(kMaxMarchSteps);
-    bool hit;
+    int left = lane_counter(kMaxMarchSteps);
     do {
-        float t;
         // faces of the rectangle known to be free: e cells beyond the current cell's own far face
         const int ex = (int)(v & 255u), ey = (int)((v >> 8) & 255u);   // (both as 8-bit fields: one v_and / v_bfe + a 24-bit mad each)
         const int Bx = mad24(ex, sx, bx);
@@ -344,16 +365,16 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
         const float tBx = xnz ? rawx : kInf;
         const float tBy = ynz ? rawy : kInf;
         const bool xe = tBx < tBy;  // leaves through the x face (ties: y first)
-        t = xe ? tBx : tBy;
-        if (t >= tmax_c) { hit = false; break; }
-        // the other ("secondary") axis: which of its crossings were consumed before time t?
-        // x exit: y crossings with ty(b) <= t;  y exit: x crossings with tx(b) < t.
-        const float fS = xe ? fy : fx;
-        const float invS = xe ? inv_dy : inv_dx;
-        const int sS = xe ? sy : sx;
-        const int bS0 = xe ? by : bx;
-        int bS = bS0;
-        if (bothnz) {
+        const float t = xe ? tBx : tBy;
+        if (t >= tmax_c) {
+            left = 0;
+        } else {
+            // the other ("secondary") axis: which of its crossings were consumed before time t?
+            // x exit: y crossings with ty(b) <= t;  y exit: x crossings with tx(b) < t.
+            const float fS = xe ? fy : fx;
+            const float invS = xe ? inv_dy : inv_dx;
+            const int sS = xe ? sy : sx;
+            const int bS0 = xe ? by : bx;
             // position on the secondary axis at time t.  The consumed crossings are exactly those on
             // the near side of p* = fS + t*dS*(1 +- 2.4e-7) (rounding of 1/dS and of the closed form),
             // and pT differs from p* by far less than one cell (|t*dS| <= 170, |fS| <= 2^16: < 0.01),
@@ -366,19 +387,24 @@ MRCA_HD float grid_march_skip(const Field& field, const GridGeom& g, const March
             const int bprev = b - sS;
             const float tp = ((float)bprev - fS) * invS;      // the crossing before b ...
             const float tc = ((float)b - fS) * invS;          // ... and b itself: consumed before t?
-            const bool cons_p = (tp < t) | ((tp == t) & xe);
-            const bool cons_c = (tc < t) | ((tc == t) & xe);
-            bS = cons_c ? b + sS : b;                         // cons_c implies cons_p (times are monotone)
+            const float tle = at_or_before(t, xe);            // x exit: "<= t", y exit: "< t"
+            const bool cons_p = tp < tle;
+            const bool cons_c = tc < tle;
+            int bS = cons_c ? b + sS : b;                     // cons_c implies cons_p (times are monotone)
             bS = ((b != bS0) & !cons_p) ? bprev : bS;
+            // An axis-parallel ray never crosses a boundary of its zero axis -- which then is always the secondary
+            // axis (its exit time is +inf): it keeps its pending boundary
+            bS = bothnz ? bS : bS0;
+            // pending boundaries after the jump: the exit-axis face is crossed, the secondary axis resumes at bS
+            bx = xe ? Bx + sx : bS;
+            by = xe ? bS : By + sy;
+            v = field(bx - ux, by - uy, qbytes);  // cells outside the map read as empty (the zero border)
+            const bool hit = v == kCellOccupied;
+            out = hit ? t * g.cell : out;
+            left = hit ? 0 : left - 1;
         }
-        // pending boundaries after the jump: the exit-axis face is crossed, the secondary axis resumes at bS
-        bx = xe ? Bx + sx : bS;
-        by = xe ? bS : By + sy;
-        v = field(bx - ux, by - uy, qbytes);  // cells outside the map read as empty (the zero border)
-        hit = v == kCellOccupied;
-        out = hit ? t * g.cell : out;
-        guard = lane_counter(guard - 1);
-    } while (!hit && guard > 0);
+        left = lane_counter(left);
+    } while (left > 0);
     return out;
 }
 

@@ -98,6 +98,12 @@ struct EnvView {
     uint32_t r_magic;     // ceil(2^32 / R) for R <= 64: n / R == umulhi(n, r_magic) for every robot index n < 2^24
     int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
     uint32_t* status;     // [1] sticky device-side error bits (kStatus*), read and cleared by mrca_check()
+#if defined(MRCA_PROFILING)
+    // profiling build only (MRCA_LAUNCH_STAMPS, mrca_abi.hip): [2 * slots] first start / last end of a launch on the 100 MHz
+    // constant clock, by thread 0 of every 64th workgroup and the last (every workgroup: 4096 atomics on one word made a launch five times longer) -- the timeline of a mrca_step_many pass without a profiler attached
+    unsigned long long* launch_stamps;
+    int32_t launch_slot;
+#endif
 };
 
 // bits of EnvView::status
@@ -109,8 +115,18 @@ constexpr uint32_t kStatusOutlineWindow = 2u;      // fidelity mode: an outline 
 // libmrca_env_prof.so, used by tools/ablate.py); in the product they fold to `false` at compile time.
 #if defined(MRCA_PROFILING)
 #define MRCA_DBG(e, bit) (((e).debug_flags & (bit)) != 0)
+#define MRCA_LAUNCH_BEGIN(e)                                                                                      \
+    do {                                                                                                          \
+        if ((e).launch_stamps && threadIdx.x == 0 && ((blockIdx.x & 63) == 0 || blockIdx.x == gridDim.x - 1)) atomicMin((e).launch_stamps + 2 * (e).launch_slot, wall_clock64()); \
+    } while (0)
+#define MRCA_LAUNCH_END(e)                                                                                            \
+    do {                                                                                                              \
+        if ((e).launch_stamps && threadIdx.x == 0 && ((blockIdx.x & 63) == 0 || blockIdx.x == gridDim.x - 1)) atomicMax((e).launch_stamps + 2 * (e).launch_slot + 1, wall_clock64()); \
+    } while (0)
 #else
 #define MRCA_DBG(e, bit) false
+#define MRCA_LAUNCH_BEGIN(e) ((void)0)
+#define MRCA_LAUNCH_END(e) ((void)0)
 #endif
 
 size_t ray_lds_bytes(const EnvView& e);

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int wo
                                                                   const uint8_t* live_p, const float* goal_p,
                                                                   const OutlineBits* outline_p, EnvView e) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
+    MRCA_LAUNCH_BEGIN(e);
     MRCA_STAMP(0);
     const int world = world_first + blockIdx.x;     // (mrca_step_worlds: a launch may cover a range of worlds)
     const int tid = threadIdx.x;
@@ -717,6 +718,7 @@ __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int wo
         if (raster) e.outline[n] = ob_cur;
     }
     MRCA_STAMP(8);      // stores drained
+    MRCA_LAUNCH_END(e);
 }
 
 __device__ __forceinline__ void write_head(const EnvView& e, int n, float x, float y, float th) {
@@ -808,7 +810,9 @@ __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int o
                                                        const float* __restrict__ pose_p, const float4* __restrict__ head_p,
                                                        const float* __restrict__ bcos_p, const float* __restrict__ bsin_p,
                                                        uint8_t* ring_head_p, EnvView e) {
+    MRCA_LAUNCH_BEGIN(e);
     raycast_body<K, BIG, SEQ, RKW>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e);
+    MRCA_LAUNCH_END(e);
 #if defined(MRCA_PROFILING)
     // debug flag 128: every workgroup casts its robot's beams a SECOND time inside the same launch -- everything it touches
     // is in its L1 / L2 by then, there is no launch boundary in between, no kernel argument to wait for: what a tick's ray
