@@ -228,6 +228,7 @@ struct mrca_env {
     char* arena = nullptr;
     bool owns_arena = false;
     mrca::EnvView view;
+    mrca::EnvView* view_dev = nullptr;    // `view` in device memory (outside the arena): what move_kernel / raycast_kernel read
     size_t lds_bytes = 0;
     // timing
     int timing = 0;      // 0 off, n > 0: record events on every n-th step
@@ -278,6 +279,17 @@ static mrca::EnvView slot_view(const mrca_env* env, int b) {
     return v;
 }
 
+// env->view -> its device copy (mrca_create; the profiling build's debug switches).  Synchronous: no launch that reads the
+// copy is in flight at either place.
+static hipError_t upload_view(mrca_env* env) {
+    hipError_t e = hipSuccess;
+    if (!env->view_dev) e = hipMalloc(reinterpret_cast<void**>(&env->view_dev), sizeof(mrca::EnvView));
+    if (e != hipSuccess) return e;
+    env->view.dev = env->view_dev;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    return hipMemcpy(env->view_dev, &env->view, sizeof(mrca::EnvView), hipMemcpyHostToDevice);
+}
+
 // the streams, events and the run-ahead ring an env owns beside its arena (mrca_destroy, and mrca_create when it gives up)
 static void release_side_objects(mrca_env* env) {
     for (hipEvent_t e : env->ev) (void)hipEventDestroy(e);
@@ -292,6 +304,9 @@ static void release_side_objects(mrca_env* env) {
     for (hipEvent_t e : env->moved)
         if (e) (void)hipEventDestroy(e);
     if (env->ahead_mem) (void)hipFree(env->ahead_mem);
+    if (env->view_dev) (void)hipFree(env->view_dev);
+    env->view_dev = nullptr;
+    env->view.dev = nullptr;
     if (env->probe_stamps) (void)hipFree(env->probe_stamps);
     env->probe_stamps = nullptr;
     for (hipStream_t s : env->parked) (void)hipStreamDestroy(s);
@@ -535,6 +550,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     }
     v.r_magic = R <= 64 ? (uint32_t)(((1ull << 32) + (uint64_t)R - 1) / (uint64_t)R) : 0u;
     v.debug_flags = 0;
+    v.dev = nullptr;                      // (upload_view, at the end of mrca_create)
 #if defined(MRCA_PROFILING)
     v.launch_stamps = nullptr;
     v.launch_slot = 0;
@@ -601,6 +617,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
             env->ahead_slots = 0;       // (whatever was created is released by mrca_destroy)
         }
     }
+    HIP_TRY_BAIL(upload_view(env));       // (the view is final from here on)
     mrca::launch_head_init(v, nullptr);   // head records of the construction-time poses (all at the origin)
     HIP_TRY_BAIL(hipGetLastError());
     HIP_TRY_BAIL(hipDeviceSynchronize());
@@ -1231,6 +1248,8 @@ int mrca_set_debug_flags(mrca_env* env, int32_t flags) {
     }
     env->view.ray_prep_wave = (flags & 0x800) ? 1 : 0;
     env->view.ray_sequential = (flags & 0x1000) ? 0 : 1;
+    DeviceGuard guard(env->cfg.device);
+    HIP_TRY(upload_view(env));            // move_kernel / raycast_kernel read the switches from the device copy
     return MRCA_OK;
 }
 #endif

@@ -7,8 +7,11 @@
 
 namespace mrca {
 
-// Everything a kernel needs, passed by value (kernarg segment).  All pointers are device memory
-// inside the env's arena.
+// Everything a kernel needs.  All pointers are device memory inside the env's arena.  Most kernels take it by value (kernarg
+// segment); the two of the tick -- move_kernel, raycast_kernel -- read the env's DEVICE copy of it (`dev`) and take what
+// differs from launch to launch as small arguments of their own (MoveOut / RayIn): a launch costs the host 2.6 us with up
+// to 104 bytes of kernel arguments and 3.2 - 3.5 us from 128 bytes on (tools/launch_cost_probe.hip), and a short
+// mrca_step_many region is paced by the host (profiles/r06_ai_*).
 struct EnvView {
     int32_t N, R, W, B, F;
     // per-robot state (SoA arena, 256-B aligned fields)
@@ -98,6 +101,8 @@ struct EnvView {
     uint32_t r_magic;     // ceil(2^32 / R) for R <= 64: n / R == umulhi(n, r_magic) for every robot index n < 2^24
     int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
     uint32_t* status;     // [1] sticky device-side error bits (kStatus*), read and cleared by mrca_check()
+    const EnvView* dev;   // the env's copy of this struct in device memory (mrca_abi.hip: uploaded by mrca_create, again by the
+                          // profiling build's debug switches); a host-side copy with other slots / ranges keeps pointing at it
 #if defined(MRCA_PROFILING)
     // profiling build only (MRCA_LAUNCH_STAMPS, mrca_abi.hip): [2 * slots] first start / last end of a launch on the 100 MHz
     // constant clock, by thread 0 of every 64th workgroup and the last (every workgroup: 4096 atomics on one word made a launch five times longer) -- the timeline of a mrca_step_many pass without a profiler attached
@@ -128,6 +133,29 @@ constexpr uint32_t kStatusOutlineWindow = 2u;      // fidelity mode: an outline 
 #define MRCA_LAUNCH_BEGIN(e) ((void)0)
 #define MRCA_LAUNCH_END(e) ((void)0)
 #endif
+
+// What a move launch WRITES that mrca_step_many gives a slot per tick (the rest of its outputs it finds in *dev), and what a ray
+// cast reads of such a slot beside its leading arguments; in the profiling build also the launch's stamp slot.
+struct MoveOut {
+    float* pose;
+    float4* head;
+    float* goal;
+    uint8_t* fresh;
+    OutlineBits* outline;
+#if defined(MRCA_PROFILING)
+    unsigned long long* launch_stamps;
+    int32_t launch_slot;
+#endif
+};
+struct RayIn {
+    const float* goal;
+    const uint8_t* fresh;
+    const OutlineBits* outline;
+#if defined(MRCA_PROFILING)
+    unsigned long long* launch_stamps;
+    int32_t launch_slot;
+#endif
+};
 
 size_t ray_lds_bytes(const EnvView& e);
 size_t move_lds_bytes(const EnvView& e);

@@ -280,8 +280,21 @@ __device__ unsigned long long g_ray_stamps[2][kRayStamps][kRayStampBlocks];
 __global__ __launch_bounds__(kWave * kMoveWaves) void move_kernel(int R_, int world_first, const float* pose_p,
                                                                   const float4* head_p, const float* __restrict__ actions,
                                                                   const uint8_t* live_p, const float* goal_p,
-                                                                  const OutlineBits* outline_p, EnvView e) {
+                                                                  const OutlineBits* outline_p, const EnvView* __restrict__ view_p,
+                                                                  MoveOut out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t mini[];
+    // the env's view from device memory (uniform loads off a read-only pointer: scalar, like the kernel-argument loads they
+    // replace), with this launch's output slot in place of the five fields a slot holds
+    EnvView e = *view_p;
+    e.pose = out.pose;
+    e.head = out.head;
+    e.goal = out.goal;
+    e.fresh = out.fresh;
+    e.outline = out.outline;
+#if defined(MRCA_PROFILING)
+    e.launch_stamps = out.launch_stamps;
+    e.launch_slot = out.launch_slot;
+#endif
     MRCA_LAUNCH_BEGIN(e);
     MRCA_STAMP(0);
     const int world = world_first + blockIdx.x;     // (mrca_step_worlds: a launch may cover a range of worlds)
@@ -809,7 +822,17 @@ template <int K, bool BIG, bool SEQ, int RKW = 0>
 __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int only_fresh, int ray_first, int ray_count, int R_,
                                                        const float* __restrict__ pose_p, const float4* __restrict__ head_p,
                                                        const float* __restrict__ bcos_p, const float* __restrict__ bsin_p,
-                                                       uint8_t* ring_head_p, EnvView e) {
+                                                       uint8_t* ring_head_p, const EnvView* __restrict__ view_p, RayIn in) {
+    EnvView e = *view_p;        // (the env's view from device memory, see move_kernel; this launch's slot: what it reads of it)
+    e.pose = const_cast<float*>(pose_p);
+    e.head = const_cast<float4*>(head_p);
+    e.goal = const_cast<float*>(in.goal);
+    e.fresh = const_cast<uint8_t*>(in.fresh);
+    e.outline = const_cast<OutlineBits*>(in.outline);
+#if defined(MRCA_PROFILING)
+    e.launch_stamps = in.launch_stamps;
+    e.launch_slot = in.launch_slot;
+#endif
     MRCA_LAUNCH_BEGIN(e);
     raycast_body<K, BIG, SEQ, RKW>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e);
     MRCA_LAUNCH_END(e);
@@ -1582,12 +1605,17 @@ void launch_move(const EnvView& e, const float* actions, hipStream_t s, hipEvent
     if (!e.big) {
         if (e.world_count <= 0) return;
         const EnvView& r = in ? *in : e;      // what the tick reads (the tick before's poses, heads, goals, outlines)
+        MoveOut out{e.pose, e.head, e.goal, e.fresh, e.outline};
+#if defined(MRCA_PROFILING)
+        out.launch_stamps = e.launch_stamps;
+        out.launch_slot = e.launch_slot;
+#endif
         if (start || stop || flags)
             hipExtLaunchKernelGGL(move_kernel, dim3(e.world_count), dim3(kWave * kMoveWaves), (uint32_t)move_lds_bytes(e), s, start,
-                                  stop, flags, e.R, e.world_first, r.pose, r.head, actions, e.live, r.goal, r.outline, e);
+                                  stop, flags, e.R, e.world_first, r.pose, r.head, actions, e.live, r.goal, r.outline, e.dev, out);
         else
             hipLaunchKernelGGL(move_kernel, dim3(e.world_count), dim3(kWave * kMoveWaves), move_lds_bytes(e), s, e.R, e.world_first,
-                               r.pose, r.head, actions, e.live, r.goal, r.outline, e);
+                               r.pose, r.head, actions, e.live, r.goal, r.outline, e.dev, out);
         return;
     }
     // (the collision hash's heads and the lidar hash's counts are left clean by the tick before: bw_finish_kernel /
@@ -1664,16 +1692,21 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t 
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
     const bool seq = e.ray_sequential != 0;
+    RayIn rin{e.goal, e.fresh, e.outline};
+#if defined(MRCA_PROFILING)
+    rin.launch_stamps = e.launch_stamps;
+    rin.launch_slot = e.launch_slot;
+#endif
 #define MRCA_RAY(K, BIG, SEQ) MRCA_RAY4(K, BIG, SEQ, 0)
 #define MRCA_RAY4(K, BIG, SEQ, RKWV)                                                                                          \
     do {                                                                                                               \
         if (start || stop)                                                                                             \
             hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0,     \
                                   only_fresh, e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin,         \
-                                  e.ring_head, e);                                                                       \
+                                  e.ring_head, e.dev, rin);                                                              \
         else                                                                                                           \
             hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV>), grid, dim3(threads), lds, s, only_fresh, e.ray_first,    \
-                               e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head, e);              \
+                               e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head, e.dev, rin);     \
     } while (0)
     if (raster_mode) {
         if (e.raster_kw <= 4) {
