@@ -436,6 +436,10 @@ int mrca_debug_ray_stamps(mrca_env* env, double* out /* [17] */);
  * conv2's tile pairs 0 / 1 (out[4], out[5]); out[6] = robots per wave; out[7] = shader clock during the loop [GHz].  See
  * tools/fwd_phases.py. */
 int mrca_debug_fwd_stamps(double* out /* [8] */);
+/* the same for the last mrca_lidar_features_backward launch: out[0..6] = ticks per item in: scan staged | gradient rows staged |
+ * conv1 recompute | conv2 wgrad | conv2 dgrad | ReLU mask | conv1 wgrad; out[8] = items per wave; out[9] = shader clock [GHz].
+ * See tools/bwd_phases.py. */
+int mrca_debug_bwd_stamps(double* out /* [10] */);
 #endif
 
 #ifdef __cplusplus

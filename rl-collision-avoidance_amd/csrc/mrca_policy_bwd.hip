@@ -36,6 +36,10 @@ namespace mrca_pbwd {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// relu as ONE integer instruction (as the forward kernel forms it, mrca_policy.hip): max(bits, 0) -- every negative float, -0
+// included, has a negative bit pattern; `x > 0 ? x : 0` compiled to a canonicalising max and a max
+__device__ __forceinline__ float relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 __device__ inline f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -53,21 +57,27 @@ struct GradLoads {
     float ge, fe;
 };
 
+// `n` is WAVE-UNIFORM (the kernel makes it so with readfirstlane): an item's rows then start at a scalar base, the lane's share
+// of the address is one loop-invariant 32-bit offset and the rest an immediate -- written with per-lane 64-bit pointers the 38
+// loads of an item kept 76 address registers alive, the kernel ran out of VGPRs and moved ~440 values per item through AGPRs
+// (profiles/r06_ak_*).
 __device__ inline void request_scan(ScanLoads& ld, const float* __restrict__ obs, int n, int lane) {
-    const float4* xs = reinterpret_cast<const float4*>(obs + (size_t)n * kFrames * kBeams);
+    const float* xs = obs + (size_t)n * (kFrames * kBeams) + 4 * lane;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) ld.x[q] = xs[q * 64 + lane];
+    for (int q = 0; q < 6; ++q) ld.x[q] = *reinterpret_cast<const float4*>(xs + q * 256);
 }
 
 __device__ inline void request_grad(GradLoads& ld, const float* __restrict__ feat_t, const float* __restrict__ gfeat_t,
                                     int n, int h, int lane) {
     const size_t row = (size_t)n * (kCh * kL2) + kHalf * h;
+    // float4 index idx = q * 64 + lane: c = idx / 16 = 4q + lane / 16, m = idx % 16 = lane % 16 -> [c][64h + 4m .. 4m+3]
+    const int lo = (lane >> 4) * kL2 + 4 * (lane & 15);
+    const float* gb = gfeat_t + row + lo;
+    const float* fb = feat_t + row + lo;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int idx = q * 64 + lane;           // float4 index: c = idx / 16, m = idx % 16 -> [c][64h + 4m .. 4m+3]
-        const size_t off = row + (size_t)(idx >> 4) * kL2 + 4 * (idx & 15);
-        ld.g[q] = *reinterpret_cast<const float4*>(gfeat_t + off);
-        ld.f[q] = *reinterpret_cast<const float4*>(feat_t + off);
+        ld.g[q] = *reinterpret_cast<const float4*>(gb + q * 4 * kL2);
+        ld.f[q] = *reinterpret_cast<const float4*>(fb + q * 4 * kL2);
     }
     ld.ge = 0.0f;
     ld.fe = 0.0f;
@@ -112,13 +122,30 @@ __device__ inline void stage_grad(float* lds, const GradLoads& ld, int lane) {
 // every MFMA group then waits a full LDS round trip; measured 41 % of the MFMA peak)
 #define MRCA_PIN() __builtin_amdgcn_sched_barrier(0)
 
+#if defined(MRCA_PROFILING)
+// profiling build only: s_memtime ticks a wave spends in each phase of an item (summed over its items) + item count; reading
+// the clock drains the LDS queue, so the stamped kernel runs a few per cent slower than the product (tools/bwd_phases.py)
+constexpr int kBwdStamps = 10, kBwdStampWaves = 1024;
+__device__ unsigned long long g_bwd_stamps[kBwdStamps][kBwdStampWaves];
+#define MRCA_BSTAMP(k)                                              \
+    {                                                               \
+        MRCA_PIN();                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        bst[k] += t_ - bprev;                                       \
+        bprev = t_;                                                 \
+        MRCA_PIN();                                                 \
+    }
+#else
+#define MRCA_BSTAMP(k)
+#endif
+
 __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel(
     const float* __restrict__ obs, int n_items, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ feat, const float* __restrict__ gfeat_act,
     const float* __restrict__ gfeat_crt, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: and with it the item index and every row base
     float* lds = lds_all + wave * kWaveFloats;
     const int gwave = blockIdx.x * kWavesPerBlock + wave;
     const int nwaves = gridDim.x * kWavesPerBlock;
@@ -191,32 +218,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
         request_grad(sg, feat_t, gfeat_t, n, 0, lane);
     }
 
+#if defined(MRCA_PROFILING)
+    unsigned long long bst[kBwdStamps] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long breal0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long bprev = __builtin_amdgcn_s_memtime();
+#endif
     for (; n < n_items; n += stride) {
         stage_scan(lds, sx, lane);
         MRCA_PIN();
+        MRCA_BSTAMP(0)      // scan staged
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             stage_grad(lds, sg, lane);
             MRCA_PIN();
-            // the inputs of the next half travel while this one computes
-            if (h == 0) {
-                request_grad(sg, feat_t, gfeat_t, n, 1, lane);
-            } else if (n + stride < n_items) {
-                request_scan(sx, obs, n + stride, lane);
-                request_grad(sg, feat_t, gfeat_t, n + stride, 0, lane);
-            }
             // --- h1 paddings of this half: h = 0: h1[-1] (H1O[c][0]); h = 1: h1[255] (H1O[c][64])
             if (lane < kCh) lds[kH1O + lane * kHPitch + (h ? kHalf : 0)] = 0.0f;
             MRCA_PIN();
+            MRCA_BSTAMP(1)      // gradient rows staged, the next half's requested
             // --- conv1 recompute: 128 positions p = pstart + 32 T + col, two tiles at a time, bias through the K padding
             const int pstart = conv1_pstart(h);
-#pragma unroll
-            for (int T = 0; T < 4; T += 2) {
-                float ba[8], bb[8];
+            // The second tile pair's MFMAs carry the first pair's leave (accumulator -> ReLU -> H1 image, 32 rows = ~100 vector and
+            // LDS instructions) between them, two rows per MFMA pair: left behind its own MFMAs the leave stood with the matrix
+            // pipe idle, ~900 clocks per tile pair (tools/bwd_phases.py, profiles/r06_ak_*).
+            {
+                float ba[8], bb[8], bc[8], bd[8];
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    ba[s] = xrow[s][pstart + 32 * T];
-                    bb[s] = xrow[s][pstart + 32 * T + 32];
+                    ba[s] = xrow[s][pstart];
+                    bb[s] = xrow[s][pstart + 32];
                 }
                 ba[7] = hl ? 1.0f : ba[7];
                 bb[7] = hl ? 1.0f : bb[7];
@@ -227,14 +256,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
                     acca = MRCA_MFMA(a1[s], ba[s], acca);
                     accb = MRCA_MFMA(a1[s], bb[s], accb);
                 }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    bc[s] = xrow[s][pstart + 64];
+                    bd[s] = xrow[s][pstart + 96];
+                }
+                bc[7] = hl ? 1.0f : bc[7];
+                bd[7] = hl ? 1.0f : bd[7];
                 MRCA_PIN();
+                f32x16 accc = zero16(), accd = zero16();
                 // h1_store_off(pstart + 32 T + col, h) + rowmap(r, hl) * kHPitch, see hst above
 #pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    accc = MRCA_MFMA(a1[s], bc[s], accc);
+                    accd = MRCA_MFMA(a1[s], bd[s], accd);
+#pragma unroll
+                    for (int r = 2 * s; r < 2 * s + 2; ++r) {
+                        hst[h][rowmap(r, 0) * kHPitch] = relu(acca[r]);
+                        hst[h][16 + rowmap(r, 0) * kHPitch] = relu(accb[r]);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    MRCA_PIN();
+                }
+#pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    hst[h][16 * T + rowmap(r, 0) * kHPitch] = acca[r] > 0.0f ? acca[r] : 0.0f;
-                    hst[h][16 * T + 16 + rowmap(r, 0) * kHPitch] = accb[r] > 0.0f ? accb[r] : 0.0f;
+                    hst[h][32 + rowmap(r, 0) * kHPitch] = relu(accc[r]);
+                    hst[h][48 + rowmap(r, 0) * kHPitch] = relu(accd[r]);
                 }
             }
+            MRCA_BSTAMP(2)      // conv1 recomputed
             // --- conv2 wgrad: contraction over this half's 64 positions, two per MFMA (i = 2s + hl), operands of four
             //     steps requested ahead of the MFMAs that use them
             {
@@ -272,9 +324,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
                     MRCA_PIN();
                 }
             }
+            MRCA_BSTAMP(3)      // conv2 wgrad
             // --- conv2 dgrad -> ReLU mask -> conv1 wgrad, 32 conv2 positions (64 h1 positions) at a time
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                // the inputs of the next half travel while the second quarter of this one computes (~7000 clocks: three HBM round
+                // trips).  Requested at the half's start they held 90 registers through its conv2 wgrad and first dgrad -- the
+                // phases with the most operands in flight -- and the kernel spilled into AGPRs there (profiles/r06_ak_*).
+                if (u == 1) {
+                    if (h == 0) {
+                        request_grad(sg, feat_t, gfeat_t, n, 1, lane);
+                    } else if (n + stride < n_items) {
+                        request_scan(sx, obs, n + stride, lane);
+                        request_grad(sg, feat_t, gfeat_t, n + stride, 0, lane);
+                    }
+                    MRCA_PIN();
+                }
                 const int I0 = 32 * u;                        // position inside the half; l = 64h + I0 + row
                 f32x16 accE = zero16(), accO = zero16();     // dh1 at p = 2l and 2l + 1
                 float ge[2][4], gs[2][4], wa[2][4], wb[2][4], wc[2][4];
@@ -287,9 +352,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
                     wc[0][k] = w2l[(2 * 32 + 2 * k) * 32];
                 }
                 MRCA_PIN();
+                float me[16], mo[16];
+                float xe[2][4], xo[2][4];
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) {
                     const int cur = ch & 1, nxt = cur ^ 1;
+                    if (ch == 3) {
+                        // the mask source and conv1 wgrad's first scan operands: requested in front of dgrad's LAST chunk, whose
+                        // twelve MFMAs cover the round trip (behind them it was the first thing the idle matrix pipe waited for)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            me[r] = m1e[I0 + rowmap(r, 0)];
+                            mo[r] = m1o[I0 + rowmap(r, 0) + 1];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int p = 2 * (kHalf * h + I0 + rowmap(k, 0));
+                            xe[0][k] = xw[p];
+                            xo[0][k] = xw[p + 1];
+                        }
+                    }
                     if (ch < 3) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -310,25 +392,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
                     }
                     MRCA_PIN();
                 }
-                // the mask source and conv1 wgrad's first scan operands: requested while the last MFMAs drain
-                float me[16], mo[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    me[r] = m1e[I0 + rowmap(r, 0)];
-                    mo[r] = m1o[I0 + rowmap(r, 0) + 1];
-                }
-                float xe[2][4], xo[2][4];
+                MRCA_BSTAMP(4)      // conv2 dgrad
+                // g1 = dh1 where h1 > 0, formed FOUR ROWS AHEAD of the MFMAs that take it as their B operand and between those of the
+                // chunk before: masked all at once in front of the first MFMA, the 32 rows (accumulator read, compare, select, write
+                // back: 128 instructions) stood with the matrix pipe idle, 1730 clocks per quarter item -- 13 % of the kernel
+                // (tools/bwd_phases.py, profiles/r06_ak_*)
+                float gE[4], gO[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int p = 2 * (kHalf * h + I0 + rowmap(k, 0));
-                    xe[0][k] = xw[p];
-                    xo[0][k] = xw[p + 1];
+                    gE[k] = me[k] > 0.0f ? accE[k] : 0.0f;
+                    gO[k] = mo[k] > 0.0f ? accO[k] : 0.0f;
+                    xe[0][k] = ones_row ? 1.0f : xe[0][k];
+                    xo[0][k] = ones_row ? 1.0f : xo[0][k];
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    accE[r] = me[r] > 0.0f ? accE[r] : 0.0f;
-                    accO[r] = mo[r] > 0.0f ? accO[r] : 0.0f;
-                }
+                MRCA_BSTAMP(5)      // ReLU mask (of the first four rows)
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) {
                     const int cur = ch & 1, nxt = cur ^ 1;
@@ -341,17 +418,43 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
                         }
                     }
                     MRCA_PIN();
+                    float nE[4], nO[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int r = 4 * ch + k;
-                        acc1e = MRCA_MFMA(ones_row ? 1.0f : xe[cur][k], accE[r], acc1e);
-                        acc1o = MRCA_MFMA(ones_row ? 1.0f : xo[cur][k], accO[r], acc1o);
+                        // two matrix instructions, then -- while they run -- the vector instructions of a row pair of the next chunk
+                        acc1e = MRCA_MFMA(xe[cur][k], gE[k], acc1e);
+                        acc1o = MRCA_MFMA(xo[cur][k], gO[k], acc1o);
+                        if (ch < 3) {
+                            const int r = 4 * (ch + 1) + k;
+                            nE[k] = me[r] > 0.0f ? accE[r] : 0.0f;
+                            nO[k] = mo[r] > 0.0f ? accO[r] : 0.0f;
+                            xe[nxt][k] = ones_row ? 1.0f : xe[nxt][k];
+                            xo[nxt][k] = ones_row ? 1.0f : xo[nxt][k];
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                        }
+                        MRCA_PIN();
                     }
-                    MRCA_PIN();
+                    if (ch < 3) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            gE[k] = nE[k];
+                            gO[k] = nO[k];
+                        }
+                    }
                 }
+                MRCA_BSTAMP(6)      // conv1 wgrad
             }
         }
+#if defined(MRCA_PROFILING)
+        bst[8] += 1;
+#endif
     }
+#if defined(MRCA_PROFILING)
+    bst[9] = __builtin_amdgcn_s_memrealtime() - breal0;
+    if (lane == 0 && gwave < kBwdStampWaves)
+        for (int k = 0; k < kBwdStamps; ++k) g_bwd_stamps[k][gwave] = bst[k];
+#endif
 
     // --- this wave's partial sums
     float* P = partial + (size_t)gwave * kPartFloats;
@@ -429,6 +532,36 @@ static int prepare_device(int* cus_out) {
 }
 
 }  // namespace mrca_pbwd
+
+#if defined(MRCA_PROFILING)
+// Profiling build only: where the waves of the LAST mrca_lidar_features_backward launch spent their time.  out[0..6] = s_memtime
+// ticks per item in: scan staged | gradient rows staged | conv1 recompute | conv2 wgrad | conv2 dgrad | ReLU mask | conv1 wgrad,
+// averaged over the waves that had work; out[7] = 0; out[8] = items per wave; out[9] = the shader clock during the loop [GHz].
+// Synchronises the device.  tools/bwd_phases.py.
+extern "C" int mrca_debug_bwd_stamps(double* out /* [10] */) {
+    using namespace mrca_pbwd;
+    if (!out) return mrca::set_error(MRCA_ERR_INVALID, "mrca_debug_bwd_stamps: NULL");
+    if (hipDeviceSynchronize() != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_debug_bwd_stamps: sync failed");
+    static unsigned long long h[kBwdStamps][kBwdStampWaves];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bwd_stamps), sizeof(h), 0, hipMemcpyDeviceToHost) != hipSuccess)
+        return mrca::set_error(MRCA_ERR_HIP, "mrca_debug_bwd_stamps: copy failed");
+    double sum[kBwdStamps] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int waves = 0;
+    for (int w = 0; w < kBwdStampWaves; ++w) {
+        if (h[8][w] == 0) continue;
+        ++waves;
+        double ticks = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            sum[k] += (double)h[k][w] / (double)h[8][w];
+            ticks += (double)h[k][w];
+        }
+        sum[8] += (double)h[8][w];
+        sum[9] += ticks / ((double)h[9][w] * 10.0);
+    }
+    for (int k = 0; k < kBwdStamps; ++k) out[k] = waves ? sum[k] / waves : 0.0;
+    return MRCA_OK;
+}
+#endif
 
 extern "C" int mrca_lidar_features_backward_scratch(size_t* bytes_out) {
     using namespace mrca_pbwd;
