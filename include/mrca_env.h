@@ -295,6 +295,14 @@ int mrca_event_pair_overhead(void* stream, int32_t samples, float* us_out);
 int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t raw_scans, int32_t n_robots,
                         int32_t frames, int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
                         float* feat_dev, void* stream);
+/* The same with the stacks addressed THROUGH A ROW TABLE instead of gathered: frames_dev is a matrix of normalised frames
+ * f32[*,512] and rows_dev i32[n_samples,3] the row of each sample's three frames, oldest first.  What the PPO update reads of a
+ * rollout buffer that stores ONE frame per tick (model/ppo.py:143-194 indexes obs_batch[sampler]; here the stack of (tick t,
+ * robot i) is three rows of the frame store, mrca/ppo.py FrameRows): the minibatch's [n,3,512] copy -- 100 MB written and read
+ * per 16 384 samples -- is never made.  Same arithmetic, same results bit for bit. */
+int mrca_lidar_features_rows(const float* frames_dev, const int32_t* rows_dev, int32_t n_samples, int32_t frames, int32_t beams,
+                             const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev, float* feat_dev,
+                             void* stream);
 
 /* The rest of the rollout inference behind fc1 in one kernel (model/net.py:41-55,61-70: ReLU, cat with goal and speed,
  * fc2 + ReLU of both towers, actor1 / actor2 / critic heads with sigmoid / tanh; model/ppo.py:57-82 generate_action:
@@ -332,6 +340,12 @@ int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t
                                  const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* feat_dev,
                                  const float* gfeat_act_dev, const float* gfeat_crt_dev, float* dw1_dev, float* db1_dev,
                                  float* dw2_dev, float* db2_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
+/* ... and its row-table form (see mrca_lidar_features_rows): frames_dev f32[*,512], rows_dev i32[n_samples,3]. */
+int mrca_lidar_features_backward_rows(const float* frames_dev, const int32_t* rows_dev, int32_t n_samples, int32_t frames,
+                                      int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev,
+                                      const float* feat_dev, const float* gfeat_act_dev, const float* gfeat_crt_dev, float* dw1_dev,
+                                      float* db1_dev, float* dw2_dev, float* db2_dev, void* scratch_dev, size_t scratch_bytes,
+                                      void* stream);
 
 /* The loss tail of the PPO update, values AND gradients, in one launch (model/ppo.py:172-185 / :238-251: importance ratio,
  * clipped surrogate, value loss x value_coef, entropy bonus; log-density of model/utils.py:90-97) -- what PyTorch runs as

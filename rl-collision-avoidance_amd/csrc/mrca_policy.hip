@@ -78,15 +78,27 @@ __device__ unsigned long long g_fwd_stamps[kFwdStamps][kFwdStampWaves];
 #define MRCA_FSTAMP(k)
 #endif
 
-// the six float4 a lane loads of robot n's scan: float4 q covers logical frame q / 2; with a ring (head != NULL) frame f
-// sits in slot (head[n] + 1 + f) mod 3
-__device__ __forceinline__ void request_scan(float4 (&sx)[6], const float* __restrict__ obs, int n, int hd, int lane) {
-    const float4* src = reinterpret_cast<const float4*>(obs + (size_t)n * kFrames * kBeams);
-    const int s0 = hd == 2 ? 0 : hd + 1, s1 = s0 == 2 ? 0 : s0 + 1;      // hd = 2: the identity (deque order)
+// Where robot n's three frames are, as rows of 512 floats behind `obs`, oldest first:
+//   rows != NULL: the caller's table, rows[3 n + f] (the rollout buffer's one-frame-per-tick store read in place, mrca/ppo.py)
+//   head != NULL: `obs` is [n][3][512] used as a ring: frame f sits in slot (head[n] + 1 + f) mod 3
+//   neither:      `obs` is [n][3][512] in deque order
+// Fetched one robot ahead of the scan it describes (a dependent load in front of six float4 loads otherwise).
+struct FrameRows3 {
+    int r0, r1, r2;
+};
+__device__ __forceinline__ FrameRows3 frame_rows(const uint8_t* __restrict__ head, const int32_t* __restrict__ rows, int n) {
+    if (rows) return FrameRows3{rows[3 * n], rows[3 * n + 1], rows[3 * n + 2]};
+    const int hd = head ? head[n] : 2;                                  // hd = 2: the identity (deque order)
+    const int s0 = hd == 2 ? 0 : hd + 1, s1 = s0 == 2 ? 0 : s0 + 1;
+    return FrameRows3{3 * n + s0, 3 * n + s1, 3 * n + hd};
+}
+// the six float4 a lane loads of a robot's scan: float4 q covers logical frame q / 2
+__device__ __forceinline__ void request_scan(float4 (&sx)[6], const float* __restrict__ obs, FrameRows3 fr, int lane) {
+    const float4* src = reinterpret_cast<const float4*>(obs);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-        const int slot = (q >> 1) == 0 ? s0 : ((q >> 1) == 1 ? s1 : hd);
-        sx[q] = src[slot * (kBeams / 4) + (q & 1) * 64 + lane];
+        const int row = (q >> 1) == 0 ? fr.r0 : ((q >> 1) == 1 ? fr.r1 : fr.r2);
+        sx[q] = src[(size_t)row * (kBeams / 4) + (q & 1) * 64 + lane];
     }
 }
 
@@ -102,8 +114,8 @@ __device__ __forceinline__ float norm_scan(float x) {
 // RAW: `obs` holds raw ranges (the env's ring of scans); the observation is formed while the scan is staged
 template <bool RAW>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
-    const float* __restrict__ obs, const uint8_t* __restrict__ head, int n_robots, const float* __restrict__ w1,
-    const float* __restrict__ b1,
+    const float* __restrict__ obs, const uint8_t* __restrict__ head, const int32_t* __restrict__ rows, int n_robots,
+    const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ feat) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -204,9 +216,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     //   conv2 pair 1   | + pair 0's output through H1E[c][0..63] and out; the next robot's first conv1 operands
     // Every LDS operand is requested a chunk ahead, across the phase boundaries too.
     float4 sx[6];
-    int hd_next = 2;
-    request_scan(sx, obs, n, head ? head[n] : 2, lane);
-    if (head && n + stride < n_robots) hd_next = head[n + stride];
+    request_scan(sx, obs, frame_rows(head, rows, n), lane);
+    FrameRows3 fr_next = frame_rows(head, rows, n + stride < n_robots ? n + stride : n);
 
 #define MRCA_STAGE_SCAN(q)                                                                               \
     {                                                                                                    \
@@ -223,13 +234,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_kernel(
     }
 #define MRCA_REQUEST_NEXT()                                                                              \
     if (n + stride < n_robots) {                                                                         \
-        request_scan(sx, obs, n + stride, hd_next, lane);                                                \
-        if (head && n + 2 * stride < n_robots) hd_next = head[n + 2 * stride];                           \
+        request_scan(sx, obs, fr_next, lane);                                                            \
+        if (n + 2 * stride < n_robots) fr_next = frame_rows(head, rows, n + 2 * stride);                 \
     }
 #define MRCA_REQUEST_NEXT_AFTER() /* inside the loop: robot n + stride has just been staged */             \
     if (n + 2 * stride < n_robots) {                                                                     \
-        request_scan(sx, obs, n + 2 * stride, hd_next, lane);                                            \
-        if (head && n + 3 * stride < n_robots) hd_next = head[n + 3 * stride];                           \
+        request_scan(sx, obs, fr_next, lane);                                                            \
+        if (n + 3 * stride < n_robots) fr_next = frame_rows(head, rows, n + 3 * stride);                 \
     }
 #define MRCA_CONV1_LOAD(buf, T)                                                                          \
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                   \
@@ -451,9 +462,9 @@ extern "C" int mrca_debug_fwd_stamps(double* out /* [8] */) {
 }
 #endif
 
-extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t raw_scans, int32_t n_robots,
-                                   int32_t frames, int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
-                                   float* feat_dev, void* stream) {
+static int lidar_features_impl(const float* obs_dev, const uint8_t* obs_head_dev, const int32_t* rows_dev, int32_t raw_scans,
+                               int32_t n_robots, int32_t frames, int32_t beams, const float* w1_dev, const float* b1_dev,
+                               const float* w2_dev, const float* b2_dev, float* feat_dev, void* stream) {
     using namespace mrca_policy;
     if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !b2_dev || !feat_dev)
         return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features: NULL pointer");
@@ -488,11 +499,25 @@ extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head
     if (blocks > pairs_needed) blocks = pairs_needed;
     if (raw_scans)
         hipLaunchKernelGGL(lidar_features_kernel<true>, dim3(blocks), dim3(64 * kWavesPerBlock), lds,
-                           static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
+                           static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, rows_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
     else
         hipLaunchKernelGGL(lidar_features_kernel<false>, dim3(blocks), dim3(64 * kWavesPerBlock), lds,
-                           static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
+                           static_cast<hipStream_t>(stream), obs_dev, obs_head_dev, rows_dev, n_robots, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features launch: %s", hipGetErrorString(e));
     return MRCA_OK;
+}
+
+extern "C" int mrca_lidar_features(const float* obs_dev, const uint8_t* obs_head_dev, int32_t raw_scans, int32_t n_robots,
+                                   int32_t frames, int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
+                                   float* feat_dev, void* stream) {
+    return lidar_features_impl(obs_dev, obs_head_dev, nullptr, raw_scans, n_robots, frames, beams, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev,
+                               stream);
+}
+
+extern "C" int mrca_lidar_features_rows(const float* frames_dev, const int32_t* rows_dev, int32_t n_samples, int32_t frames, int32_t beams,
+                                        const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev,
+                                        float* feat_dev, void* stream) {
+    if (!rows_dev) return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features_rows: rows_dev is NULL");
+    return lidar_features_impl(frames_dev, nullptr, rows_dev, 0, n_samples, frames, beams, w1_dev, b1_dev, w2_dev, b2_dev, feat_dev, stream);
 }

@@ -61,7 +61,18 @@ struct GradLoads {
 // of the address is one loop-invariant 32-bit offset and the rest an immediate -- written with per-lane 64-bit pointers the 38
 // loads of an item kept 76 address registers alive, the kernel ran out of VGPRs and moved ~440 values per item through AGPRs
 // (profiles/r06_ak_*).
-__device__ inline void request_scan(ScanLoads& ld, const float* __restrict__ obs, int n, int lane) {
+// rows != NULL: `obs` is a matrix of frames [*, 512] and rows[3 n + f] the row of item n's frame f (deque order) -- the rollout
+// buffer's one-frame-per-tick store read in place (mrca/ppo.py FrameRows) instead of a gathered [n, 3, 512] copy of it
+__device__ inline void request_scan(ScanLoads& ld, const float* __restrict__ obs, const int32_t* __restrict__ rows, int n, int lane) {
+    if (rows) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const float* xs = obs + (size_t)rows[3 * n + f] * kBeams + 4 * lane;
+            ld.x[2 * f] = *reinterpret_cast<const float4*>(xs);
+            ld.x[2 * f + 1] = *reinterpret_cast<const float4*>(xs + 256);
+        }
+        return;
+    }
     const float* xs = obs + (size_t)n * (kFrames * kBeams) + 4 * lane;
 #pragma unroll
     for (int q = 0; q < 6; ++q) ld.x[q] = *reinterpret_cast<const float4*>(xs + q * 256);
@@ -140,8 +151,8 @@ __device__ unsigned long long g_bwd_stamps[kBwdStamps][kBwdStampWaves];
 #endif
 
 __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel(
-    const float* __restrict__ obs, int n_items, const float* __restrict__ w1, const float* __restrict__ b1,
-    const float* __restrict__ w2, const float* __restrict__ feat, const float* __restrict__ gfeat_act,
+    const float* __restrict__ obs, const int32_t* __restrict__ rows, int n_items, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ feat, const float* __restrict__ gfeat_act,
     const float* __restrict__ gfeat_crt, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     const int lane = threadIdx.x & 63;
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
     ScanLoads sx;
     GradLoads sg;
     if (n < n_items) {
-        request_scan(sx, obs, n, lane);
+        request_scan(sx, obs, rows, n, lane);
         request_grad(sg, feat_t, gfeat_t, n, 0, lane);
     }
 
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void lidar_features_bwd_kernel
                     if (h == 0) {
                         request_grad(sg, feat_t, gfeat_t, n, 1, lane);
                     } else if (n + stride < n_items) {
-                        request_scan(sx, obs, n + stride, lane);
+                        request_scan(sx, obs, rows, n + stride, lane);
                         request_grad(sg, feat_t, gfeat_t, n + stride, 0, lane);
                     }
                     MRCA_PIN();
@@ -573,18 +584,16 @@ extern "C" int mrca_lidar_features_backward_scratch(size_t* bytes_out) {
     return MRCA_OK;
 }
 
-extern "C" int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams,
-                                            const float* w1_dev, const float* b1_dev, const float* w2_dev,
-                                            const float* feat_dev, const float* gfeat_act_dev,
-                                            const float* gfeat_crt_dev, float* dw1_dev, float* db1_dev, float* dw2_dev,
-                                            float* db2_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+static int lidar_features_backward_impl(const char* who, const float* obs_dev, const int32_t* rows_dev, int32_t n_robots, int32_t frames,
+                                        int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* feat_dev,
+                                        const float* gfeat_act_dev, const float* gfeat_crt_dev, float* dw1_dev, float* db1_dev,
+                                        float* dw2_dev, float* db2_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
     using namespace mrca_pbwd;
     if (!obs_dev || !w1_dev || !b1_dev || !w2_dev || !feat_dev || !gfeat_act_dev || !gfeat_crt_dev || !dw1_dev || !db1_dev || !dw2_dev ||
         !db2_dev || !scratch_dev)
-        return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features_backward: NULL pointer");
+        return mrca::set_error(MRCA_ERR_INVALID, "%s: NULL pointer", who);
     if (frames != kFrames || beams != kBeams || n_robots < 1)
-        return mrca::set_error(MRCA_ERR_UNSUPPORTED, "mrca_lidar_features_backward: frames %d beams %d samples %d (needs 3 x 512, >= 1)",
-                               frames, beams, n_robots);
+        return mrca::set_error(MRCA_ERR_UNSUPPORTED, "%s: frames %d beams %d samples %d (needs 3 x 512, >= 1)", who, frames, beams, n_robots);
     mrca::DeviceGuard guard(mrca::device_of(obs_dev));     // launch where the buffers live
     int cus = 0;
     const int rc = prepare_device(&cus);
@@ -592,15 +601,35 @@ extern "C" int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robo
     const int blocks = cus;                 // persistent: one workgroup of 4 waves per CU
     const int nwaves = blocks * kWavesPerBlock;
     if (scratch_bytes < (size_t)nwaves * kPartFloats * sizeof(float))
-        return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features_backward: scratch of %zu B < %zu B", scratch_bytes,
-                               (size_t)nwaves * kPartFloats * sizeof(float));
+        return mrca::set_error(MRCA_ERR_INVALID, "%s: scratch of %zu B < %zu B", who, scratch_bytes, (size_t)nwaves * kPartFloats * sizeof(float));
     const size_t lds = (size_t)kBlockFloats * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(lidar_features_bwd_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), lds, st, obs_dev, n_robots,
+    hipLaunchKernelGGL(lidar_features_bwd_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), lds, st, obs_dev, rows_dev, n_robots,
                        w1_dev, b1_dev, w2_dev, feat_dev, gfeat_act_dev, gfeat_crt_dev, static_cast<float*>(scratch_dev));
     hipLaunchKernelGGL(lidar_features_bwd_finalize, dim3(2 * ((kPartFloats + 63) / 64)), dim3(64 * kFinGroups), 0, st,
                        static_cast<const float*>(scratch_dev), nwaves, dw1_dev, db1_dev, dw2_dev, db2_dev);
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_lidar_features_backward launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "%s launch: %s", who, hipGetErrorString(e));
     return MRCA_OK;
+}
+
+extern "C" int mrca_lidar_features_backward(const float* obs_dev, int32_t n_robots, int32_t frames, int32_t beams,
+                                            const float* w1_dev, const float* b1_dev, const float* w2_dev,
+                                            const float* feat_dev, const float* gfeat_act_dev,
+                                            const float* gfeat_crt_dev, float* dw1_dev, float* db1_dev, float* dw2_dev,
+                                            float* db2_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    return lidar_features_backward_impl("mrca_lidar_features_backward", obs_dev, nullptr, n_robots, frames, beams, w1_dev, b1_dev, w2_dev,
+                                        feat_dev, gfeat_act_dev, gfeat_crt_dev, dw1_dev, db1_dev, dw2_dev, db2_dev, scratch_dev,
+                                        scratch_bytes, stream);
+}
+
+extern "C" int mrca_lidar_features_backward_rows(const float* frames_dev, const int32_t* rows_dev, int32_t n_samples, int32_t frames,
+                                                 int32_t beams, const float* w1_dev, const float* b1_dev, const float* w2_dev,
+                                                 const float* feat_dev, const float* gfeat_act_dev, const float* gfeat_crt_dev,
+                                                 float* dw1_dev, float* db1_dev, float* dw2_dev, float* db2_dev, void* scratch_dev,
+                                                 size_t scratch_bytes, void* stream) {
+    if (!rows_dev) return mrca::set_error(MRCA_ERR_INVALID, "mrca_lidar_features_backward_rows: rows_dev is NULL");
+    return lidar_features_backward_impl("mrca_lidar_features_backward_rows", frames_dev, rows_dev, n_samples, frames, beams, w1_dev, b1_dev,
+                                        w2_dev, feat_dev, gfeat_act_dev, gfeat_crt_dev, dw1_dev, db1_dev, dw2_dev, db2_dev, scratch_dev,
+                                        scratch_bytes, stream);
 }

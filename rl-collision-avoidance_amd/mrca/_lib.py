@@ -25,6 +25,7 @@ EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_crea
            "mrca_step", "mrca_step_slice", "mrca_step_worlds", "mrca_move_worlds", "mrca_observe_worlds", "mrca_step_many", "mrca_materialize", "mrca_newest_obs", "mrca_sparse_obs", "mrca_normalize_scans", "mrca_check", "mrca_get_field", "mrca_gae", "mrca_enable_timing", "mrca_read_timing",
            "mrca_event_pair_overhead",
            "mrca_lidar_features", "mrca_lidar_features_backward_scratch", "mrca_lidar_features_backward",
+           "mrca_lidar_features_rows", "mrca_lidar_features_backward_rows",
            "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch", "mrca_adam_step",
            "mrca_rollout_store_state", "mrca_rollout_store_outcome",
            "mrca_policy_heads", "mrca_policy_heads_backward_scratch", "mrca_policy_heads_backward", "mrca_relu_cat",
@@ -90,6 +91,9 @@ def load(path=None):
                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mrca_lidar_features.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mrca_lidar_features_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    lib.mrca_lidar_features_backward_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + \
+        [C.c_size_t, C.c_void_p]
     lib.mrca_lidar_features_backward_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_lidar_features_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 11 + \
         [C.c_size_t, C.c_void_p]

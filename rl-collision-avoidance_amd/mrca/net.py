@@ -71,11 +71,14 @@ class CNNPolicy(nn.Module):
         return self._tail(tw, h.contiguous().flatten(1), goal, speed)
 
     def mean_value(self, x, goal, speed):
+        from . import policy_ops
+        table = isinstance(x, policy_ops.FrameTable)
+        if table and not self.fused_train:
+            x = x.gather()
         if self.fused_train and x.is_cuda:
-            from . import policy_ops
             st = lambda a, c: torch.stack((a, c))      # noqa: E731  (its backward hands each tower its slice)
             fa, fc = policy_ops.lidar_features_fn(
-                x.float(), st(self.act_fea_cv1.weight, self.crt_fea_cv1.weight), st(self.act_fea_cv1.bias, self.crt_fea_cv1.bias),
+                x if table else x.float(), st(self.act_fea_cv1.weight, self.crt_fea_cv1.weight), st(self.act_fea_cv1.bias, self.crt_fea_cv1.bias),
                 st(self.act_fea_cv2.weight, self.crt_fea_cv2.weight), st(self.act_fea_cv2.bias, self.crt_fea_cv2.bias))
             # behind the front end the layers are the module's own Linear layers (library GEMMs); what sits BETWEEN them runs
             # as row kernels (csrc/mrca_policy_heads.hip): relu + cat with goal and speed in one launch, fc2's ReLU applied

@@ -49,6 +49,41 @@ def normalize_scans(scans):
     return out
 
 
+class FrameTable:
+    """Observation stacks addressed through a row table instead of gathered: ``frames`` f32[*, 512] (a matrix of normalised
+    frames: the rollout buffer's one-frame-per-tick store, flattened) and ``rows`` i32[n, 3], the row of each sample's three
+    frames, oldest first.  What ``lidar_features_fn`` takes in place of a [n, 3, 512] tensor (mrca_lidar_features_rows):
+    the minibatch's copy of its stacks -- 100 MB written and read per 16 384 samples -- is never made.  ``gather()`` makes it
+    for whoever needs a tensor (the stock policy path)."""
+
+    def __init__(self, frames, rows):
+        if not (frames.dtype == torch.float32 and frames.is_contiguous() and frames.dim() == 2 and frames.shape[1] == 512):
+            raise ValueError("FrameTable: frames must be a contiguous float32 matrix [*, 512]")
+        if not (rows.dtype == torch.int32 and rows.is_contiguous() and rows.dim() == 2 and rows.shape[1] == 3 and
+                rows.device == frames.device):
+            raise ValueError("FrameTable: rows must be a contiguous int32 tensor [n, 3] on the frames' device")
+        self.frames, self.rows = frames, rows
+
+    @property
+    def shape(self):
+        return (self.rows.shape[0], 3, 512)
+
+    @property
+    def device(self):
+        return self.frames.device
+
+    @property
+    def is_cuda(self):
+        return self.frames.is_cuda
+
+    def gather(self):
+        return self.frames[self.rows.long()]
+
+    def record_stream(self, stream):
+        if self.rows.is_cuda:
+            self.rows.record_stream(stream)
+
+
 def lidar_features(obs, w1, b1, w2, b2, out=None, head=None):
     """relu(conv2(relu(conv1(obs)))) of the actor and the critic tower in one launch.
     obs f32[N,3,512]; w1 f32[2,32,3,5], b1 f32[2,32], w2 f32[2,32,32,3], b2 f32[2,32] (tower-major: actor, critic)
@@ -57,6 +92,24 @@ def lidar_features(obs, w1, b1, w2, b2, out=None, head=None):
     robot n's newest frame; the kernel reads the frames in deque order while staging -- and, for a ring of RAW scans,
     forms the observation x / 6 - 0.5 on the way.  None: ``obs`` is in deque order."""
     lib = _lib.load()
+    if isinstance(obs, FrameTable):
+        if head is not None:
+            raise ValueError("lidar_features: a FrameTable is in deque order already (no head)")
+        N = obs.rows.shape[0]
+        if not obs.is_cuda:
+            raise ValueError("lidar_features: the FrameTable must live on the GPU")
+        for t, shape in ((w1, (2, 32, 3, 5)), (b1, (2, 32)), (w2, (2, 32, 32, 3)), (b2, (2, 32))):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
+                raise ValueError(f"lidar_features: expected a contiguous cuda float32 tensor of shape {shape}, got "
+                                 f"{tuple(t.shape)} {t.dtype} {t.device}")
+        if out is None:
+            out = torch.empty(2, N, 4096, dtype=torch.float32, device=obs.device)
+        with torch.cuda.device(obs.device):
+            stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+            _lib.check(lib.mrca_lidar_features_rows(obs.frames.data_ptr(), obs.rows.data_ptr(), N, 3, 512, w1.data_ptr(),
+                                                    b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), stream),
+                       "mrca_lidar_features_rows")
+        return out
     head, raw = unwrap_head(head)
     N, F, B = obs.shape
     for t, shape in ((obs, (N, 3, 512)), (w1, (2, 32, 3, 5)), (b1, (2, 32)), (w2, (2, 32, 32, 3)), (b2, (2, 32))):
@@ -130,7 +183,9 @@ def lidar_features_backward(obs, w1, b1, w2, feat, gfeat_act, gfeat_crt):
     -> dw1 f32[2,32,3,5], db1 f32[2,32], dw2 f32[2,32,32,3], db2 f32[2,32]"""
     lib = _lib.load()
     N = obs.shape[0]
-    for t, shape in ((obs, (N, 3, 512)), (w1, (2, 32, 3, 5)), (b1, (2, 32)), (w2, (2, 32, 32, 3)), (feat, (2, N, 4096)),
+    table = obs if isinstance(obs, FrameTable) else None
+    for t, shape in (((obs, (N, 3, 512)),) if table is None else ()) + (
+                     (w1, (2, 32, 3, 5)), (b1, (2, 32)), (w2, (2, 32, 32, 3)), (feat, (2, N, 4096)),
                      (gfeat_act, (N, 4096)), (gfeat_crt, (N, 4096))):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape):
             raise ValueError(f"lidar_features_backward: expected a contiguous cuda float32 tensor of shape {shape}, got "
@@ -141,11 +196,13 @@ def lidar_features_backward(obs, w1, b1, w2, feat, gfeat_act, gfeat_crt):
     scratch = _backward_scratch(dev)
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.mrca_lidar_features_backward(obs.data_ptr(), N, 3, 512, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-                                                    feat.data_ptr(), gfeat_act.data_ptr(), gfeat_crt.data_ptr(),
-                                                    dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
-                                                    scratch.data_ptr(), scratch.numel(), stream),
-                   "mrca_lidar_features_backward")
+        tail = (N, 3, 512, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), feat.data_ptr(), gfeat_act.data_ptr(), gfeat_crt.data_ptr(),
+                dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), scratch.data_ptr(), scratch.numel(), stream)
+        if table is None:
+            _lib.check(lib.mrca_lidar_features_backward(obs.data_ptr(), *tail), "mrca_lidar_features_backward")
+        else:
+            _lib.check(lib.mrca_lidar_features_backward_rows(table.frames.data_ptr(), table.rows.data_ptr(), *tail),
+                       "mrca_lidar_features_backward_rows")
     return dw1, db1, dw2, db2
 
 
@@ -156,14 +213,25 @@ class _LidarFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, obs, w1, b1, w2, b2):
-        obs, w1, b1, w2, b2 = (t.detach().contiguous() for t in (obs, w1, b1, w2, b2))
+        w1, b1, w2, b2 = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        table = obs if isinstance(obs, FrameTable) else None
+        if table is None:
+            obs = obs.detach().contiguous()
         feat = lidar_features(obs, w1, b1, w2, b2)
-        ctx.save_for_backward(obs, w1, b1, w2, feat)
+        if table is None:
+            ctx.save_for_backward(obs, w1, b1, w2, feat)
+        else:       # (the frame store and the row table are data: kept by reference, like a saved tensor)
+            ctx.save_for_backward(table.frames, table.rows, w1, b1, w2, feat)
+        ctx.table = table is not None
         return feat[0], feat[1]
 
     @staticmethod
     def backward(ctx, g_act, g_crt):
-        obs, w1, b1, w2, feat = ctx.saved_tensors
+        if ctx.table:
+            frames, rows, w1, b1, w2, feat = ctx.saved_tensors
+            obs = FrameTable(frames, rows)
+        else:
+            obs, w1, b1, w2, feat = ctx.saved_tensors
         g_act = torch.zeros_like(feat[0]) if g_act is None else g_act.contiguous()
         g_crt = torch.zeros_like(feat[1]) if g_crt is None else g_crt.contiguous()
         dw1, db1, dw2, db2 = lidar_features_backward(obs, w1, b1, w2, feat, g_act, g_crt)

@@ -89,9 +89,12 @@ class FrameRows:
     the minibatch from the one-frame-per-tick store (RolloutBuffer, ``single_frame=True``).  Supports the two ways
     the update addresses its memory: integer index tensors and a boolean keep-mask (Stage-2 filtering)."""
 
-    def __init__(self, frames, fidx, rowmap=None):
+    def __init__(self, frames, fidx, rowmap=None, lazy=False):
         self.frames, self.fidx, self.rowmap = frames, fidx, rowmap      # [T+2,N,B], [T,N,F] int64, optional [n'] -> t*N+i
         self.N = fidx.shape[1]
+        # lazy: an integer index returns a policy_ops.FrameTable -- the frame store itself + the rows of the minibatch's stacks --
+        # instead of a gathered [mb, F, B] copy (set by the update when the policy's front end reads through such a table)
+        self.lazy = lazy
 
     @property
     def shape(self):
@@ -101,10 +104,14 @@ class FrameRows:
     def __getitem__(self, index):
         if index.dtype == torch.bool:
             base = torch.arange(self.fidx.shape[0] * self.N, device=index.device) if self.rowmap is None else self.rowmap
-            return FrameRows(self.frames, self.fidx, base[index])
+            return FrameRows(self.frames, self.fidx, base[index], self.lazy)
         flat = index if self.rowmap is None else self.rowmap[index]
         t, i = flat // self.N, flat % self.N
         fi = self.fidx[t, i]                                   # [mb, F]
+        if self.lazy:
+            from . import policy_ops
+            rows = (fi * self.N + i.unsqueeze(1)).to(torch.int32)
+            return policy_ops.FrameTable(self.frames.view(-1, self.frames.shape[2]), rows.contiguous())
         return self.frames[fi, i.unsqueeze(1)]                 # [mb, F, B]
 
     def materialise(self):
@@ -499,6 +506,11 @@ def _ppo_epochs(policy, optimizer, batch_size, flat, epoch, coeff_entropy, clip_
     # the loss tail (ratio, clipped surrogate, value loss, entropy and their gradients) as ONE launch where the policy's
     # front end already runs through the HIP kernels (policy_ops.ppo_loss); the stock expression otherwise
     fused_loss = bool(getattr(policy, "fused_train", False)) and advs.is_cuda and autocast_dtype is None
+    if isinstance(obss, FrameRows):
+        # the fused front end reads the minibatch's stacks out of the frame store through a row table (policy_ops.FrameTable);
+        # every other path gets the gathered tensor
+        obss.lazy = (fused_loss and obss.frames.is_cuda and obss.frames.dtype == torch.float32 and obss.frames.is_contiguous() and
+                     obss.frames.shape[2] == 512 and obss.fidx.shape[2] == 3 and obss.frames.numel() < 2 ** 31 * 512)
     small = (goals, speeds, actions, logprobs, targets, advs)
     for _ in range(epoch):
         if index_batches is not None:

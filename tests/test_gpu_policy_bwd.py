@@ -164,3 +164,57 @@ def test_policy_gradients_with_the_hip_front_end_equal_the_stock_gradients():
         assert w[1] <= 1e-3 and w[0] <= 2e-3, (k, w)
         assert w[3] <= 3e-2 and w[2] <= 3e-2, (k, w)
     assert float(fused["act_fea_cv1.weight"].abs().max()) > 0 and float(fused["crt_fea_cv2.bias"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("n", [1, 7, 300, 4097])
+def test_row_table_form_equals_the_gathered_form_bit_for_bit(n):
+    """mrca_lidar_features_rows / _backward_rows read the stacks out of a frame store through a row table; the kernels do the
+    same arithmetic on the same numbers as with the gathered [n, 3, 512] copy: features and gradients identical to the bit."""
+    from mrca import policy_ops
+    w1, b1, w2, b2 = (t.cuda().contiguous() for t in _weights(7 + n))
+    g = torch.Generator().manual_seed(500 + n)
+    store = (torch.rand(3 * n + 11, 512, generator=g) - 0.5).cuda()
+    rows = torch.randint(0, store.shape[0], (n, 3), generator=g, dtype=torch.int32).cuda()        # any rows, repeats included
+    table = policy_ops.FrameTable(store, rows)
+    x = table.gather()
+    assert x.shape == (n, 3, 512)
+    feat_t = policy_ops.lidar_features(table, w1, b1, w2, b2)
+    feat_x = policy_ops.lidar_features(x.contiguous(), w1, b1, w2, b2)
+    assert torch.equal(feat_t, feat_x)
+    ga, gc = torch.randn(n, 4096, generator=g).cuda(), torch.randn(n, 4096, generator=g).cuda()
+    got_t = policy_ops.lidar_features_backward(table, w1, b1, w2, feat_t, ga, gc)
+    got_x = policy_ops.lidar_features_backward(x.contiguous(), w1, b1, w2, feat_x, ga, gc)
+    for name, a, b in zip(("dw1", "db1", "dw2", "db2"), got_t, got_x):
+        assert torch.equal(a, b), name
+
+
+def test_update_through_the_frame_store_equals_the_update_through_gathered_stacks():
+    """ppo._ppo_epochs with a one-frame-per-tick buffer: the fused front end reads the minibatch's stacks through a FrameTable
+    (FrameRows.lazy); the parameters after an update equal, bit for bit, those of the same update fed gathered stacks."""
+    from mrca import net, ppo
+    T, N = 6, 64
+    g = torch.Generator().manual_seed(3)
+    frames = (torch.rand(T + 2, N, 512, generator=g) - 0.5).cuda()
+    fidx = torch.stack([torch.stack([torch.arange(t, t + 3) for _ in range(N)]) for t in range(T)]).cuda()      # [T, N, 3]
+    fidx[2, 5] = torch.tensor([4, 4, 4], device="cuda")          # a robot that restarted: its stack repeats one frame
+    rows = ppo.FrameRows(frames, fidx)
+    goals, speeds = (torch.randn(T, N, 2, generator=g).cuda() for _ in range(2))
+    actions = torch.rand(T, N, 2, generator=g).cuda()
+    logprobs = (torch.randn(T, N, 1, generator=g) * 0.1 - 2.0).cuda()
+    targets, advs = (torch.randn(T, N, 1, generator=g).cuda() for _ in range(2))
+    batches = lambda n: list(torch.arange(n, device="cuda").flip(0).split(128))      # noqa: E731  (a fixed order, three minibatches)
+    outs = []
+    for lazy_allowed in (True, False):
+        torch.manual_seed(11)
+        policy = net.CNNPolicy(frames=3, action_space=2).cuda()
+        policy.fused_train = True
+        opt = torch.optim.Adam(policy.parameters(), lr=1e-3)
+        obss = rows if lazy_allowed else rows.materialise()            # FrameRows | [T, N, 3, 512]
+        memory = (obss, goals, speeds, actions, logprobs, targets, None, None, advs)
+        ppo.ppo_update_stage1(policy, opt, 128, memory, epoch=2, num_step=T, num_env=N, frames=3, obs_size=512, act_size=2,
+                              index_batches=batches)
+        outs.append([p.detach().clone() for p in policy.parameters()])
+        if lazy_allowed:
+            assert rows.lazy, "the fused update did not switch the frame store to row tables"
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -188,3 +188,25 @@ def test_one_frame_buffer_row_indices_follow_the_deque_rule():
     t, n = 4, int(np.argmax(fresh_log[4])) if fresh_log[4].any() else 0
     if fresh_log[4].any():
         assert float(stacks[t, n, 0, 0]) == float(stacks[t, n, F - 1, 0]) == 104.0    # restarted: F copies of its fresh scan
+
+
+def test_frame_rows_lazy_index_names_the_rows_the_gather_reads():
+    """FrameRows.lazy (the fused update, mrca/ppo.py): an integer index returns a FrameTable -- the flattened frame store and, per
+    sample, the rows of its three frames -- whose gather() is the [mb, 3, 512] tensor the eager index returns, also behind a
+    boolean keep-mask (Stage-2 filtering)."""
+    import torch
+    from mrca import ppo
+    T, N = 5, 7
+    g = torch.Generator().manual_seed(0)
+    frames = torch.rand(T + 2, N, 512, generator=g)
+    fidx = torch.randint(0, T + 2, (T, N, 3), generator=g)
+    eager, lazy = ppo.FrameRows(frames, fidx), ppo.FrameRows(frames, fidx, lazy=True)
+    index = torch.randperm(T * N, generator=g)[:13]
+    table = lazy[index]
+    assert table.rows.dtype == torch.int32 and tuple(table.rows.shape) == (13, 3) and tuple(table.shape) == (13, 3, 512)
+    assert torch.equal(table.gather(), eager[index])
+    keep = torch.rand(T * N, generator=g) > 0.4
+    sub_e, sub_l = eager[keep], lazy[keep]
+    assert sub_l.lazy and not sub_e.lazy
+    idx2 = torch.arange(int(keep.sum()))[::2]
+    assert torch.equal(sub_l[idx2].gather(), sub_e[idx2])
