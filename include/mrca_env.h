@@ -392,12 +392,25 @@ int mrca_policy_heads_backward(const float* a_dev, const float* c_dev, const flo
                                const float* gvalue_dev, int32_t n, const float* w_actor1_dev, const float* w_actor2_dev,
                                const float* w_critic_dev, int32_t relu_inputs, float* da_dev, float* dc_dev, float* dw_dev,
                                void* scratch_dev, size_t scratch_bytes, void* stream);
+/* The same, and dz_bias_dev f32[256] = the column sums of da_dev [0,128) and dc_dev [128,256): with relu_inputs = 1 the gradients
+ * of act_fc2.bias / crt_fc2.bias, the layers whose outputs a_dev / c_dev are (model/net.py:45,59) -- summed where da / dc are
+ * formed, in the same fixed order, instead of by a reduction over the two matrices just written. */
+int mrca_policy_heads_backward_bias(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
+                                    const float* gvalue_dev, int32_t n, const float* w_actor1_dev, const float* w_actor2_dev,
+                                    const float* w_critic_dev, int32_t relu_inputs, float* da_dev, float* dc_dev, float* dw_dev,
+                                    float* dz_bias_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* out[n,260] = [relu(h1[n,256]), goal[n,2], speed[n,2]]: F.relu(act_fc1(a)) and torch.cat((a, goal, speed), dim=-1) of
  * model/net.py:43-45 (the critic tower alike, :57-59) in one launch, and its backward dh1[n,256] = gout[:, :256] where h1 > 0
  * (goal and speed are data).  h1 / out / gout / dh1 16-byte aligned, goal / speed 8-byte. */
 int mrca_relu_cat(const float* h1_dev, const float* goal_dev, const float* speed_dev, int32_t n, float* out_dev, void* stream);
 int mrca_relu_cat_backward(const float* h1_dev, const float* gout_dev, int32_t n, float* dh1_dev, void* stream);
+/* ... with db_dev f32[256] = the column sums of dh1: the gradient of the bias of the fc1 layer that produced h1 (model/net.py:41,57),
+ * per-workgroup sums added in a fixed order in float64 (deterministic).  scratch_dev: caller-owned, at least
+ * mrca_relu_cat_backward_bias_scratch() bytes, 16-byte aligned. */
+int mrca_relu_cat_backward_bias_scratch(size_t* bytes_out);
+int mrca_relu_cat_backward_bias(const float* h1_dev, const float* gout_dev, int32_t n, float* dh1_dev, float* db_dev,
+                                void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* The learner's rollout buffer, written by the library: what the reference appends to `buff` every step and turns into arrays
  * before the update (ppo_stage1.py:102-103; model/ppo.py:22-54 transform_buffer), kept on the device with ONE lidar frame per

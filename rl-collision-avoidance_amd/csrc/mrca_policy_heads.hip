@@ -28,8 +28,12 @@ constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / 64;
 constexpr int kMaxBlocks = 256;            // 1024 waves: 16 rows each at 16 384 rows
 constexpr int kRowsInFlight = 4;           // row pairs a wave loads before it computes on any of them
-constexpr int kOut = 3 * kFeat + 3;        // dW actor1, dW actor2, dW critic, db actor1, db actor2, db critic
-constexpr int kPartialPitch = 3 * kFeat + 4;
+constexpr int kHeadOut = 3 * kFeat + 3;    // dW actor1, dW actor2, dW critic, db actor1, db actor2, db critic
+// ... and, behind them, the column sums of da and dc: the gradients of act_fc2.bias / crt_fc2.bias (the layers that produced a
+// and c) -- formed where da / dc are formed instead of by two `sum` launches over the 8 MB just written (model/ppo.py:186-188
+// back-propagates through fc2; as autograd nodes those sums were 2 of the 4 reduce kernels of a minibatch)
+constexpr int kOut = kHeadOut + 2 * kFeat;
+constexpr int kPartialPitch = kOut + 1;
 constexpr size_t kScratchBytes = sizeof(float) * kPartialPitch * kMaxBlocks;       // one record per workgroup
 
 __device__ __forceinline__ float4 load4(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void heads_backward_kernel(
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
     // (the weight rows are slices of the optimiser's flat buffer: 4-byte aligned only)
     const float4 w1q = load4(w1 + 4 * q), w2q = load4(w2 + 4 * q), wcq = load4(wc + 4 * q);
-    float4 acc1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), acc2 = acc1, accc = acc1;
+    float4 acc1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), acc2 = acc1, accc = acc1, sda = acc1, sdc = acc1;
     float sb0 = 0.0f, sb1 = 0.0f, sbv = 0.0f;
     const int pairs = (n + 1) >> 1;
     const int per_wave = (pairs + nwaves - 1) / nwaves;
@@ -136,6 +140,8 @@ __global__ __launch_bounds__(kThreads) void heads_backward_kernel(
                 }
                 reinterpret_cast<float4*>(da)[r] = dav;
                 reinterpret_cast<float4*>(dc)[r] = dcv;
+                sda.x += dav.x; sda.y += dav.y; sda.z += dav.z; sda.w += dav.w;
+                sdc.x += dcv.x; sdc.y += dcv.y; sdc.z += dcv.z; sdc.w += dcv.w;
             }
             if (RELU) {
                 aq[j] = relu4(aq[j]);
@@ -153,6 +159,8 @@ __global__ __launch_bounds__(kThreads) void heads_backward_kernel(
     acc1.x += __shfl_xor(acc1.x, 32); acc1.y += __shfl_xor(acc1.y, 32); acc1.z += __shfl_xor(acc1.z, 32); acc1.w += __shfl_xor(acc1.w, 32);
     acc2.x += __shfl_xor(acc2.x, 32); acc2.y += __shfl_xor(acc2.y, 32); acc2.z += __shfl_xor(acc2.z, 32); acc2.w += __shfl_xor(acc2.w, 32);
     accc.x += __shfl_xor(accc.x, 32); accc.y += __shfl_xor(accc.y, 32); accc.z += __shfl_xor(accc.z, 32); accc.w += __shfl_xor(accc.w, 32);
+    sda.x += __shfl_xor(sda.x, 32); sda.y += __shfl_xor(sda.y, 32); sda.z += __shfl_xor(sda.z, 32); sda.w += __shfl_xor(sda.w, 32);
+    sdc.x += __shfl_xor(sdc.x, 32); sdc.y += __shfl_xor(sdc.y, 32); sdc.z += __shfl_xor(sdc.z, 32); sdc.w += __shfl_xor(sdc.w, 32);
     sb0 += __shfl_xor(sb0, 32);
     sb1 += __shfl_xor(sb1, 32);
     sbv += __shfl_xor(sbv, 32);
@@ -168,6 +176,11 @@ __global__ __launch_bounds__(kThreads) void heads_backward_kernel(
             mine[3 * kFeat + 1] = sb1;
             mine[3 * kFeat + 2] = sbv;
         }
+        // (kHeadOut is not a multiple of 4: scalar stores)
+        float* za = mine + kHeadOut + 4 * q;
+        float* zc = mine + kHeadOut + kFeat + 4 * q;
+        za[0] = sda.x; za[1] = sda.y; za[2] = sda.z; za[3] = sda.w;
+        zc[0] = sdc.x; zc[1] = sdc.y; zc[2] = sdc.z; zc[3] = sdc.w;
     }
     __syncthreads();
     float* rec = partial + (size_t)blockIdx.x * kPartialPitch;
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void heads_backward_kernel(
 // eight groups meet in LDS
 constexpr int kFinK = 32, kFinGroups = 8;
 __global__ __launch_bounds__(kFinK * kFinGroups) void heads_finalize_kernel(const float* __restrict__ partial, int nrec,
-                                                                            float* __restrict__ dw) {
+                                                                            float* __restrict__ dw, float* __restrict__ dzb) {
     __shared__ double sh[kFinGroups][kFinK];
     const int kk = threadIdx.x & (kFinK - 1), grp = threadIdx.x / kFinK;
     const int k = blockIdx.x * kFinK + kk;
@@ -193,7 +206,8 @@ __global__ __launch_bounds__(kFinK * kFinGroups) void heads_finalize_kernel(cons
         double t = sh[0][kk];
 #pragma unroll
         for (int g = 1; g < kFinGroups; ++g) t += sh[g][kk];
-        dw[k] = (float)t;
+        if (k < kHeadOut) dw[k] = (float)t;
+        else if (dzb) dzb[k - kHeadOut] = (float)t;      // [0, 128): act_fc2.bias, [128, 256): crt_fc2.bias
     }
 }
 
@@ -226,6 +240,54 @@ __global__ __launch_bounds__(kThreads) void relu_cat_backward_kernel(const float
         const long row = k / (kFc1 / 4);
         const int c4 = (int)(k - row * (kFc1 / 4));
         dh1[k] = mask4(gout[row * (kCat / 4) + c4], h1[k]);
+    }
+}
+
+// the same with the column sums of dh1 -- the gradient of fc1's bias (model/net.py:41: act_fc1 / crt_fc1 produced h1) -- formed on
+// the way: a thread keeps ONE float4 column for all its rows (the grid's stride is a multiple of the 64 float4 of a row), the
+// four row groups of a workgroup meet in LDS, one record of 256 sums per workgroup; colsum_finalize_kernel adds the records in a
+// fixed order in float64.  As an autograd node that sum was a `reduce_kernel` over the 16 MB this kernel has just written.
+constexpr int kBiasBlocks = 256;
+__global__ __launch_bounds__(kThreads) void relu_cat_backward_bias_kernel(const float4* __restrict__ h1, const float4* __restrict__ gout,
+                                                                          long n, float4* __restrict__ dh1, float* __restrict__ partial) {
+    const int c4 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (long row = (long)blockIdx.x * kWavesPerBlock + grp; row < n; row += (long)gridDim.x * kWavesPerBlock) {
+        const float4 d = mask4(gout[row * (kCat / 4) + c4], h1[row * (kFc1 / 4) + c4]);
+        dh1[row * (kFc1 / 4) + c4] = d;
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+    __shared__ float4 red[kWavesPerBlock][kFc1 / 4];
+    red[grp][c4] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        float4 t = red[0][c4];
+#pragma unroll
+        for (int g = 1; g < kWavesPerBlock; ++g) {
+            t.x += red[g][c4].x; t.y += red[g][c4].y; t.z += red[g][c4].z; t.w += red[g][c4].w;
+        }
+        reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * kFc1)[c4] = t;
+    }
+}
+
+// out[k] = sum over the nrec records of partial[r][k], k < nout (pitch = nout), in a fixed order in float64
+__global__ __launch_bounds__(kFinK * kFinGroups) void colsum_finalize_kernel(const float* __restrict__ partial, int nrec, int nout,
+                                                                             float* __restrict__ out) {
+    __shared__ double sh[kFinGroups][kFinK];
+    const int kk = threadIdx.x & (kFinK - 1), grp = threadIdx.x / kFinK;
+    const int k = blockIdx.x * kFinK + kk;
+    double s = 0.0;
+    if (k < nout) {
+#pragma unroll 8
+        for (int r = grp; r < nrec; r += kFinGroups) s += (double)partial[(size_t)r * nout + k];
+    }
+    sh[grp][kk] = s;
+    __syncthreads();
+    if (grp == 0 && k < nout) {
+        double t = sh[0][kk];
+#pragma unroll
+        for (int g = 1; g < kFinGroups; ++g) t += sh[g][kk];
+        out[k] = (float)t;
     }
 }
 
@@ -270,11 +332,10 @@ extern "C" int mrca_policy_heads_backward_scratch(size_t* bytes_out) {
     return MRCA_OK;
 }
 
-extern "C" int mrca_policy_heads_backward(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
-                                          const float* gvalue_dev, int32_t n, const float* w_actor1_dev,
-                                          const float* w_actor2_dev, const float* w_critic_dev, int32_t relu_inputs,
-                                          float* da_dev, float* dc_dev, float* dw_dev, void* scratch_dev, size_t scratch_bytes,
-                                          void* stream) {
+static int policy_heads_backward_impl(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
+                                      const float* gvalue_dev, int32_t n, const float* w_actor1_dev, const float* w_actor2_dev,
+                                      const float* w_critic_dev, int32_t relu_inputs, float* da_dev, float* dc_dev, float* dw_dev,
+                                      float* dzb_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
     using namespace mrca_heads;
     if (!a_dev || !c_dev || !mean_dev || !w_actor1_dev || !w_actor2_dev || !w_critic_dev || !da_dev || !dc_dev || !dw_dev ||
         !scratch_dev)
@@ -294,11 +355,30 @@ extern "C" int mrca_policy_heads_backward(const float* a_dev, const float* c_dev
     else
         hipLaunchKernelGGL(heads_backward_kernel<false>, dim3(blocks), dim3(kThreads), 0, s, a_dev, c_dev, mean_dev, gmean_dev,
                            gvalue_dev, n, w_actor1_dev, w_actor2_dev, w_critic_dev, da_dev, dc_dev, static_cast<float*>(scratch_dev));
-    hipLaunchKernelGGL(heads_finalize_kernel, dim3((kOut + kFinK - 1) / kFinK), dim3(kFinK * kFinGroups), 0, s,
-                       static_cast<const float*>(scratch_dev), blocks, dw_dev);
+    hipLaunchKernelGGL(heads_finalize_kernel, dim3(((dzb_dev ? kOut : kHeadOut) + kFinK - 1) / kFinK), dim3(kFinK * kFinGroups), 0, s,
+                       static_cast<const float*>(scratch_dev), blocks, dw_dev, dzb_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_policy_heads_backward launch: %s", hipGetErrorString(e));
     return MRCA_OK;
+}
+
+extern "C" int mrca_policy_heads_backward(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
+                                          const float* gvalue_dev, int32_t n, const float* w_actor1_dev,
+                                          const float* w_actor2_dev, const float* w_critic_dev, int32_t relu_inputs,
+                                          float* da_dev, float* dc_dev, float* dw_dev, void* scratch_dev, size_t scratch_bytes,
+                                          void* stream) {
+    return policy_heads_backward_impl(a_dev, c_dev, mean_dev, gmean_dev, gvalue_dev, n, w_actor1_dev, w_actor2_dev, w_critic_dev,
+                                      relu_inputs, da_dev, dc_dev, dw_dev, nullptr, scratch_dev, scratch_bytes, stream);
+}
+
+extern "C" int mrca_policy_heads_backward_bias(const float* a_dev, const float* c_dev, const float* mean_dev, const float* gmean_dev,
+                                               const float* gvalue_dev, int32_t n, const float* w_actor1_dev,
+                                               const float* w_actor2_dev, const float* w_critic_dev, int32_t relu_inputs,
+                                               float* da_dev, float* dc_dev, float* dw_dev, float* dz_bias_dev, void* scratch_dev,
+                                               size_t scratch_bytes, void* stream) {
+    if (!dz_bias_dev) return mrca::set_error(MRCA_ERR_INVALID, "mrca_policy_heads_backward_bias: dz_bias_dev is NULL");
+    return policy_heads_backward_impl(a_dev, c_dev, mean_dev, gmean_dev, gvalue_dev, n, w_actor1_dev, w_actor2_dev, w_critic_dev,
+                                      relu_inputs, da_dev, dc_dev, dw_dev, dz_bias_dev, scratch_dev, scratch_bytes, stream);
 }
 
 extern "C" int mrca_relu_cat(const float* h1_dev, const float* goal_dev, const float* speed_dev, int32_t n, float* out_dev,
@@ -333,5 +413,36 @@ extern "C" int mrca_relu_cat_backward(const float* h1_dev, const float* gout_dev
                        reinterpret_cast<float4*>(dh1_dev));
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_relu_cat_backward launch: %s", hipGetErrorString(e));
+    return MRCA_OK;
+}
+
+extern "C" int mrca_relu_cat_backward_bias_scratch(size_t* bytes_out) {
+    if (!bytes_out) return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat_backward_bias_scratch: bytes_out is NULL");
+    *bytes_out = sizeof(float) * mrca_heads::kBiasBlocks * mrca_heads::kFc1;
+    return MRCA_OK;
+}
+
+extern "C" int mrca_relu_cat_backward_bias(const float* h1_dev, const float* gout_dev, int32_t n, float* dh1_dev, float* db_dev,
+                                           void* scratch_dev, size_t scratch_bytes, void* stream) {
+    using namespace mrca_heads;
+    if (!h1_dev || !gout_dev || !dh1_dev || !db_dev || !scratch_dev)
+        return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat_backward_bias: NULL pointer");
+    if (n < 1) return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat_backward_bias: n = %d", n);
+    if (scratch_bytes < sizeof(float) * kBiasBlocks * kFc1)
+        return mrca::set_error(MRCA_ERR_NOMEM, "mrca_relu_cat_backward_bias: scratch of %zu bytes < %zu", scratch_bytes,
+                               sizeof(float) * kBiasBlocks * kFc1);
+    if (!aligned16(h1_dev) || !aligned16(gout_dev) || !aligned16(dh1_dev) || !aligned16(scratch_dev))
+        return mrca::set_error(MRCA_ERR_INVALID, "mrca_relu_cat_backward_bias: the buffers and the scratch must be 16-byte aligned");
+    mrca::DeviceGuard guard(mrca::device_of(h1_dev));
+    int blocks = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > kBiasBlocks) blocks = kBiasBlocks;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(relu_cat_backward_bias_kernel, dim3(blocks), dim3(kThreads), 0, s, reinterpret_cast<const float4*>(h1_dev),
+                       reinterpret_cast<const float4*>(gout_dev), (long)n, reinterpret_cast<float4*>(dh1_dev),
+                       static_cast<float*>(scratch_dev));
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((kFc1 + kFinK - 1) / kFinK), dim3(kFinK * kFinGroups), 0, s,
+                       static_cast<const float*>(scratch_dev), blocks, kFc1, db_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return mrca::set_error(MRCA_ERR_HIP, "mrca_relu_cat_backward_bias launch: %s", hipGetErrorString(e));
     return MRCA_OK;
 }

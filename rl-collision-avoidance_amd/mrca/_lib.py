@@ -29,7 +29,8 @@ EXPORTS = ["mrca_abi_version", "mrca_last_error", "mrca_arena_bytes", "mrca_crea
            "mrca_policy_tail", "mrca_ppo_loss", "mrca_ppo_loss_scratch", "mrca_adam_step",
            "mrca_rollout_store_state", "mrca_rollout_store_outcome",
            "mrca_policy_heads", "mrca_policy_heads_backward_scratch", "mrca_policy_heads_backward", "mrca_relu_cat",
-           "mrca_relu_cat_backward"]
+           "mrca_relu_cat_backward", "mrca_policy_heads_backward_bias", "mrca_relu_cat_backward_bias_scratch",
+           "mrca_relu_cat_backward_bias"]
 
 
 class RolloutRows(C.Structure):
@@ -107,6 +108,11 @@ def load(path=None):
     lib.mrca_policy_heads_backward_scratch.argtypes = [C.POINTER(C.c_size_t)]
     lib.mrca_policy_heads_backward.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] + \
         [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+    lib.mrca_policy_heads_backward_bias.argtypes = [C.c_void_p] * 5 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] + \
+        [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
+    lib.mrca_relu_cat_backward_bias_scratch.argtypes = [C.POINTER(C.c_size_t)]
+    lib.mrca_relu_cat_backward_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.c_void_p]
     lib.mrca_relu_cat.argtypes = [C.c_void_p] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]
     lib.mrca_relu_cat_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mrca_adam_step.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 4 + [C.c_int32, C.c_void_p]

@@ -84,12 +84,18 @@ class CNNPolicy(nn.Module):
             # as row kernels (csrc/mrca_policy_heads.hip): relu + cat with goal and speed in one launch, fc2's ReLU applied
             # by the head kernels as they load, the three Linear(128, 1) heads with sigmoid / tanh forward and backward (as
             # library GEMMs the heads alone are ~25 launches per minibatch)
-            z = []
+            # fc1 / fc2 add their biases DETACHED: the bias gradients are column sums of dh1 / dz, which the row kernels behind
+            # them form on the way (relu_cat's and the heads' backward) -- as autograd nodes they were four `sum` launches over
+            # the matrices those kernels had just written
+            z, zb = [], []
             for tw, f in (("act", fa), ("crt", fc)):
-                x2 = policy_ops.relu_cat(getattr(self, f"{tw}_fc1")(f), goal, speed)
-                z.append(getattr(self, f"{tw}_fc2")(x2))
+                fc1, fc2 = getattr(self, f"{tw}_fc1"), getattr(self, f"{tw}_fc2")
+                x2 = policy_ops.relu_cat(F.linear(f, fc1.weight, fc1.bias.detach()), goal, speed, h1_bias=fc1.bias)
+                z.append(F.linear(x2, fc2.weight, fc2.bias.detach()))
+                zb.append(fc2.bias)
             return policy_ops.policy_heads(z[0], z[1], self.actor1.weight, self.actor1.bias, self.actor2.weight,
-                                           self.actor2.bias, self.critic.weight, self.critic.bias, relu_inputs=True)
+                                           self.actor2.bias, self.critic.weight, self.critic.bias, relu_inputs=True,
+                                           z_bias=tuple(zb))
         else:
             a = self._tower("act", x, goal, speed)
             c = self._tower("crt", x, goal, speed)

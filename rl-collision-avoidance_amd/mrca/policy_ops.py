@@ -343,7 +343,10 @@ class _PolicyHeads(torch.autograd.Function):
     row kernels (csrc/mrca_policy_heads.hip) instead of three skinny GEMMs forward and six backward."""
 
     @staticmethod
-    def forward(ctx, a, c, w1, b1, w2, b2, wc, bc, relu_inputs=False):
+    def forward(ctx, a, c, w1, b1, w2, b2, wc, bc, relu_inputs=False, zb_a=None, zb_c=None):
+        # zb_a / zb_c: the biases of the layers that produced a / c (act_fc2.bias / crt_fc2.bias), or None.  Not used forward --
+        # the caller added them with the bias DETACHED (F.linear(x, W, b.detach())) -- they are here to receive their gradient:
+        # the column sums of da / dc, which the backward kernel forms on the way (mrca_policy_heads_backward_bias)
         lib = _lib.load()
         n = a.shape[0]
         a, c = a.detach().contiguous(), c.detach().contiguous()
@@ -361,6 +364,7 @@ class _PolicyHeads(torch.autograd.Function):
         ctx.save_for_backward(a, c, mean, ws[0], ws[2], ws[4])
         ctx.shapes = (w1.shape, b1.shape, w2.shape, b2.shape, wc.shape, bc.shape)
         ctx.relu_inputs = bool(relu_inputs)
+        ctx.z_bias = (zb_a is not None, zb_c is not None)
         return mean, value
 
     @staticmethod
@@ -375,28 +379,56 @@ class _PolicyHeads(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             scratch = _heads_backward_scratch(dev, stream.value or 0)
-            _lib.check(lib.mrca_policy_heads_backward(a.data_ptr(), c.data_ptr(), mean.data_ptr(),
-                                                      None if gmean is None else gmean.data_ptr(),
-                                                      None if gvalue is None else gvalue.data_ptr(), n, w1.data_ptr(), w2.data_ptr(),
-                                                      wc.data_ptr(), int(ctx.relu_inputs), da.data_ptr(), dc.data_ptr(), dw.data_ptr(),
-                                                      scratch.data_ptr(), scratch.numel(), stream), "mrca_policy_heads_backward")
+            head = (a.data_ptr(), c.data_ptr(), mean.data_ptr(), None if gmean is None else gmean.data_ptr(),
+                    None if gvalue is None else gvalue.data_ptr(), n, w1.data_ptr(), w2.data_ptr(), wc.data_ptr(),
+                    int(ctx.relu_inputs), da.data_ptr(), dc.data_ptr(), dw.data_ptr())
+            dzb = None
+            if any(ctx.z_bias):
+                dzb = torch.empty(256, dtype=torch.float32, device=dev)
+                _lib.check(lib.mrca_policy_heads_backward_bias(*head, dzb.data_ptr(), scratch.data_ptr(), scratch.numel(), stream),
+                           "mrca_policy_heads_backward_bias")
+            else:
+                _lib.check(lib.mrca_policy_heads_backward(*head, scratch.data_ptr(), scratch.numel(), stream),
+                           "mrca_policy_heads_backward")
         s = ctx.shapes
         return (da, dc, dw[0:128].view(s[0]), dw[384:385].view(s[1]), dw[128:256].view(s[2]), dw[385:386].view(s[3]),
-                dw[256:384].view(s[4]), dw[386:387].view(s[5]), None)
+                dw[256:384].view(s[4]), dw[386:387].view(s[5]), None,
+                dzb[0:128] if ctx.z_bias[0] else None, dzb[128:256] if ctx.z_bias[1] else None)
 
 
-def policy_heads(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic, relu_inputs=False):
+def policy_heads(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic, relu_inputs=False, z_bias=None):
     """-> (mean [n,2], value [n,1]) of the three output heads, differentiable with respect to the first eight arguments
     (include/mrca_env.h: mrca_policy_heads / _backward).  ``relu_inputs``: ``a`` / ``c`` are fc2's outputs BEFORE their ReLU --
-    the kernels apply it (and its mask on the way back)."""
-    return _PolicyHeads.apply(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic, relu_inputs)
+    the kernels apply it (and its mask on the way back).  ``z_bias`` = (bias of the layer that produced a, ... that produced c):
+    they receive the column sums of da / dc as their gradient -- for a caller that formed a / c with those biases detached
+    (``F.linear(x, W, b.detach())``), so that autograd does not sum the same columns again."""
+    zb_a, zb_c = z_bias if z_bias is not None else (None, None)
+    return _PolicyHeads.apply(a, c, w_actor1, b_actor1, w_actor2, b_actor2, w_critic, b_critic, relu_inputs, zb_a, zb_c)
+
+
+_relu_cat_scratches = {}
+
+
+def _relu_cat_scratch(device, stream):
+    """per (device, stream), like the heads' scratch: the per-workgroup records of relu_cat's backward with bias sums"""
+    key = (device.type, device.index, int(stream))
+    if key not in _relu_cat_scratches:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("relu_cat backward: first use on this stream inside a graph capture -- call it once before capturing")
+        lib = _lib.load()
+        n = C.c_size_t()
+        _lib.check(lib.mrca_relu_cat_backward_bias_scratch(C.byref(n)), "mrca_relu_cat_backward_bias_scratch")
+        _relu_cat_scratches[key] = torch.empty(n.value, dtype=torch.uint8, device=device)
+    return _relu_cat_scratches[key]
 
 
 class _ReluCat(torch.autograd.Function):
     """[relu(h1), goal, speed] (model/net.py:43-45) and dh1 = gout[:, :256] where h1 > 0, one launch each."""
 
     @staticmethod
-    def forward(ctx, h1, goal, speed):
+    def forward(ctx, h1, goal, speed, h1_bias=None):
+        # h1_bias: the bias of the layer that produced h1 (act_fc1.bias / crt_fc1.bias) or None -- not used forward (the caller
+        # added it DETACHED), here to receive its gradient: the column sums of dh1 (mrca_relu_cat_backward_bias)
         lib = _lib.load()
         n = h1.shape[0]
         h1, goal, speed = h1.detach().contiguous(), goal.detach().contiguous(), speed.detach().contiguous()
@@ -408,6 +440,7 @@ class _ReluCat(torch.autograd.Function):
             stream = C.c_void_p(torch.cuda.current_stream(h1.device).cuda_stream)
             _lib.check(lib.mrca_relu_cat(h1.data_ptr(), goal.data_ptr(), speed.data_ptr(), n, out.data_ptr(), stream), "mrca_relu_cat")
         ctx.save_for_backward(h1)
+        ctx.h1_bias = h1_bias is not None
         return out
 
     @staticmethod
@@ -416,13 +449,22 @@ class _ReluCat(torch.autograd.Function):
         (h1,) = ctx.saved_tensors
         gout = gout.contiguous()
         dh1 = torch.empty_like(h1)
+        db = None
         with torch.cuda.device(h1.device):
             stream = C.c_void_p(torch.cuda.current_stream(h1.device).cuda_stream)
-            _lib.check(lib.mrca_relu_cat_backward(h1.data_ptr(), gout.data_ptr(), h1.shape[0], dh1.data_ptr(), stream),
-                       "mrca_relu_cat_backward")
-        return dh1, None, None
+            if ctx.h1_bias:
+                db = torch.empty(256, dtype=torch.float32, device=h1.device)
+                scratch = _relu_cat_scratch(h1.device, stream.value or 0)
+                _lib.check(lib.mrca_relu_cat_backward_bias(h1.data_ptr(), gout.data_ptr(), h1.shape[0], dh1.data_ptr(), db.data_ptr(),
+                                                           scratch.data_ptr(), scratch.numel(), stream), "mrca_relu_cat_backward_bias")
+            else:
+                _lib.check(lib.mrca_relu_cat_backward(h1.data_ptr(), gout.data_ptr(), h1.shape[0], dh1.data_ptr(), stream),
+                           "mrca_relu_cat_backward")
+        return dh1, None, None, db
 
 
-def relu_cat(h1, goal, speed):
-    """-> f32[n,260] = cat(relu(h1), goal, speed); differentiable with respect to ``h1`` (goal and speed are data)."""
-    return _ReluCat.apply(h1, goal, speed)
+def relu_cat(h1, goal, speed, h1_bias=None):
+    """-> f32[n,260] = cat(relu(h1), goal, speed); differentiable with respect to ``h1`` (goal and speed are data).
+    ``h1_bias``: the bias of the layer that produced ``h1``, for a caller that added it detached: it receives the column sums of
+    dh1 as its gradient (see ``policy_heads``' ``z_bias``)."""
+    return _ReluCat.apply(h1, goal, speed, h1_bias)

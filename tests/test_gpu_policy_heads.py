@@ -134,3 +134,43 @@ def test_relu_cat_equals_relu_then_cat(built, n):
     assert torch.equal(a.grad, b.grad)
     with pytest.raises(ValueError):
         policy_ops.relu_cat(h1[:, :128], goal, speed)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1000, 16384])
+def test_bias_gradients_formed_by_the_row_kernels(built, n):
+    """relu_cat(h1_bias=...) and policy_heads(z_bias=...): the biases of the layers in front receive the column sums of dh1 / dz
+    as their gradient -- equal to the float64 sums of the gradients the same kernels write (the kernels add fp32 per-thread partials,
+    then float64), and everything else unchanged to the bit."""
+    from mrca import policy_ops
+    g = torch.Generator(device="cuda").manual_seed(31 * n)
+    h1 = torch.randn(n, 256, device="cuda", generator=g)
+    goal, speed = torch.randn(n, 2, device="cuda", generator=g), torch.rand(n, 2, device="cuda", generator=g)
+    gout = torch.randn(n, 260, device="cuda", generator=g)
+    a, b = h1.clone().requires_grad_(True), h1.clone().requires_grad_(True)
+    bias = torch.zeros(256, device="cuda", requires_grad=True)
+    (policy_ops.relu_cat(a, goal, speed, h1_bias=bias) * gout).sum().backward()
+    (policy_ops.relu_cat(b, goal, speed) * gout).sum().backward()
+    assert torch.equal(a.grad, b.grad)
+    want = b.grad.double().sum(0)
+    tol = 1e-6 * float(b.grad.abs().double().sum(0).max()) + 1e-7
+    assert float((bias.grad.double() - want).abs().max()) <= tol
+
+    ws = [torch.randn(1, 128, device="cuda", generator=g) * 0.2 for _ in range(3)]
+    bs = [torch.randn(1, device="cuda", generator=g) for _ in range(3)]
+    za, zc = torch.randn(n, 128, device="cuda", generator=g), torch.randn(n, 128, device="cuda", generator=g)
+    gm, gv = torch.randn(n, 2, device="cuda", generator=g), torch.randn(n, 1, device="cuda", generator=g)
+    res = []
+    for with_bias in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (za, zc, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])]
+        zb = (torch.zeros(128, device="cuda", requires_grad=True), torch.zeros(128, device="cuda", requires_grad=True))
+        mean, value = policy_ops.policy_heads(*leaves, relu_inputs=True, z_bias=zb if with_bias else None)
+        ((mean * gm).sum() + (value * gv).sum()).backward()
+        res.append(([t.grad for t in leaves], zb))
+    for p, q in zip(res[0][0], res[1][0]):
+        assert torch.equal(p, q)
+    assert res[1][1][0].grad is None
+    for k in range(2):
+        dz = res[0][0][k]
+        want = dz.double().sum(0)
+        tol = 1e-6 * float(dz.abs().double().sum(0).max()) + 1e-7
+        assert float((res[0][1][k].grad.double() - want).abs().max()) <= tol, k
