@@ -80,11 +80,11 @@ def _kernel_rates():
     def row(name, us, flop, n, src):
         tf = flop * n / (us * 1e-6) / 1e12
         return {"kernel": name, "avg_us": us, "tflops": tf, "frac": tf / FP32_MFMA_PEAK_TFLOPS, "source": src}
-    roll = [row("fc1 GEMM (hipBLASLt, both towers batched)", 123.0, fc1, 4096, "profiles/r06_w_rollout_kernel_stats.csv"),
-            row("lidar_features_kernel<true> (conv1 + conv2, fp32 MFMA)", 86.6, conv, 4096, "profiles/r06_w_rollout_kernel_stats.csv")]
-    train = [row("lidar_features_bwd_kernel (conv1 + conv2 backward)", 745.2, 2 * conv, 16384, "profiles/r06_w_train_kernel_stats.csv"),
-             row("fc1 GEMMs of the update (forward / dgrad / wgrad, per tower)", (244.4 + 236.5 + 234.1) / 3, fc1 / 2, 16384, "profiles/r06_w_train_kernel_stats.csv"),
-             row("lidar_features_kernel<false> (conv forward of the update)", 315.1, conv, 16384, "profiles/r06_w_train_kernel_stats.csv")]
+    roll = [row("fc1 GEMM (hipBLASLt, both towers batched)", 124.5, fc1, 4096, "profiles/r06_am_rollout_kernel_stats.csv"),
+            row("lidar_features_kernel<true> (conv1 + conv2, fp32 MFMA)", 91.8, conv, 4096, "profiles/r06_am_rollout_kernel_stats.csv")]
+    train = [row("lidar_features_bwd_kernel (conv1 + conv2 backward)", 721.4, 2 * conv, 16384, "profiles/r06_am_train_kernel_stats.csv"),
+             row("fc1 GEMMs of the update (forward / dgrad / wgrad, per tower)", (244.7 + 236.7 + 235.7) / 3, fc1 / 2, 16384, "profiles/r06_am_train_kernel_stats.csv"),
+             row("lidar_features_kernel<false> (conv forward of the update)", 310.8, conv, 16384, "profiles/r06_am_train_kernel_stats.csv")]
     return roll, train
 
 

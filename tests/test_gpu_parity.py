@@ -227,6 +227,32 @@ def test_bench_schedule_leaves_the_world_where_the_c_oracle_leaves_it(hip, name,
     env.close()
 
 
+@pytest.mark.parametrize("chains", [1, 2, 3])
+def test_step_many_of_every_short_length(hip, chains):
+    """The run-ahead pass enqueues its ticks in blocks -- [0], [1], [2], [3], then fours -- with the move launches three blocks
+    ahead of the ray casts (csrc/mrca_abi.hip run_ahead_pass): calls of 1, 2, ... 11 ticks one after the other (every shape of a
+    pass's head and tail, blocks that do not exist included) leave the world where the C oracle's tick-by-tick run leaves it."""
+    import bench
+    sc = S.stage1(num_worlds=6, robots_per_world=16, seed=77)
+    env = hip.VecStageWorld(sc)
+    ora = U.COracleEnv(sc)
+    pool = bench.action_pool(sc.num_robots, env.device, 9, depth=80)
+    host_pool = [a.cpu().numpy() for a in pool]
+    env.reset()
+    ora.reset()
+    k = 0
+    for K in range(1, 12):
+        env.step_many(pool, k, K, chains)
+        for j in range(K):
+            ora.step(host_pool[(k + j) % len(host_pool)])
+        k += K
+        torch.cuda.synchronize()
+        U.assert_state_equal(U.HostView(env), ora, what=f"after a call of {K} ticks ({k} in all), chains={chains}")
+    U.assert_hits_equal(env, ora, what="after calls of 1 .. 11 ticks")
+    env.check()
+    env.close()
+
+
 @pytest.mark.parametrize("chains", [1, 2])
 def test_step_many_inside_a_graph_capture(hip, chains):
     """mrca_step_many is "capturable like any other call" (include/mrca_env.h): eight ticks of two world ranges captured into
