@@ -903,9 +903,10 @@ static void log_end() {
 // w(k) = K - 1 - k (slot 0 = the env's own fields: the pass starts from them and its last tick leaves them current), reading
 // slot w(k - 1); tick 0 goes out on the caller's stream, ticks 1 .. K - 1 on the env's move stream, back to back -- a slot per
 // tick, so a move launch waits for no ray cast.  The ray casts of world range c run on the range's stream (range 0: the
-// caller's), tick after tick, each behind the event "tick k's move launch is through".  Nothing else is ordered: the ray
-// casts are what a tick costs (19.5 us for 4096 robots as two ranges, profiles/r06_a_ray_only_probe.txt), the move launches
-// (8.5 us) run beside them.  Every dependency is a stream order or an event; nothing spins.
+// caller's), tick after tick, each BLOCK of ticks behind the event "the block's last move launch is through" (the blocks and the
+// host order of the enqueues: below).  Nothing else is ordered: the ray casts are what a tick costs (16.4 us for 4096 robots as
+// two ranges -- two residency rounds of a workgroup's lifetime), the move launches (8.5 us) run beside them.
+// Every dependency is a stream order or an event; nothing spins.
 static int run_ahead_pass(mrca_env* env, const float* const* act, int K, int P, hipStream_t s0) {
     const int W = env->view.W, R = env->view.R;
     auto stream_of = [&](int c) { return c == 0 ? s0 : env->chain_stream[c - 1]; };
