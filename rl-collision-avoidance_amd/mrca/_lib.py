@@ -63,6 +63,12 @@ def load(path=None):
     path = path or LIB_PATH
     if path in _libs:
         return _libs[path]
+    # torch FIRST.  The library needs libamdhip64.so.7; the torch wheel bundles its own HIP runtime under another file name
+    # (torch/lib/libamdhip64.so).  Loaded after torch, the library binds to the runtime torch has already loaded (same SONAME):
+    # one runtime in the process.  Loaded BEFORE torch it pulls in /opt/rocm's copy, torch then loads its own, and the second HSA
+    # runtime to initialise finds "no ROCm-capable device" -- seen as a failing mrca_create on a healthy MI355X box when
+    # __graft_entry__.build() (which ends in this call) ran before the first `import torch` of the process.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: the MI355X HIP library has not been built "

@@ -123,3 +123,23 @@ def test_bench_refuses_a_multi_gpu_run_it_cannot_start():
         pytest.skip("this box really has 8 GPUs")
     assert out.returncode == 2 and "refusing" in out.stderr
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_library_loaded_before_torch_still_shares_torchs_hip_runtime():
+    """mrca._lib.load() imports torch before it dlopens libmrca_env.so: whatever the order of the caller's imports, ONE HIP runtime is
+    mapped into the process (two -- /opt/rocm's next to the torch wheel's -- and the second to initialise sees no device:
+    mrca_create failed on the GPU box when build() ran before `import torch`)."""
+    import subprocess
+    import sys
+    pkg = os.path.join(U.ROOT, "rl-collision-avoidance_amd")
+    code = "\n".join([
+        "import sys",
+        f"sys.path.insert(0, {pkg!r})",
+        "from mrca import _lib",
+        "_lib.load()",
+        "import torch",
+        "maps = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}",
+        "print(len(maps), sorted(maps))"])
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.split()[0] == "1", out.stdout
