@@ -164,11 +164,14 @@ def policy_tail(h1, goal, speed, fc2_w, fc2_b, head_w, head_b, critic_w, critic_
 _scratch = {}
 
 
-def _backward_scratch(device):
-    """Per-device scratch of the backward kernel's per-wave partial sums (allocated once, reused by every call on the
-    device's current stream order)."""
-    key = (device.type, device.index)
+def _backward_scratch(device, stream=0):
+    """Scratch of the backward kernel's per-wave partial sums, one buffer per (device, STREAM) like the loss kernel's and the
+    heads': the partials live between the kernel and its finalize launch on one stream, and two trainers, rank threads or side
+    streams of one process must not overwrite each other's."""
+    key = (device.type, device.index, int(stream))
     if key not in _scratch:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("lidar_features_backward: first use on this stream inside a graph capture -- call it once before capturing")
         lib = _lib.load()
         n = C.c_size_t()
         with torch.cuda.device(device):
@@ -193,9 +196,9 @@ def lidar_features_backward(obs, w1, b1, w2, feat, gfeat_act, gfeat_crt):
     dev = obs.device
     dw1, db1 = torch.empty_like(w1), torch.empty_like(b1)
     dw2, db2 = torch.empty_like(w2), torch.empty(2, 32, dtype=torch.float32, device=dev)
-    scratch = _backward_scratch(dev)
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        scratch = _backward_scratch(dev, stream.value or 0)
         tail = (N, 3, 512, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), feat.data_ptr(), gfeat_act.data_ptr(), gfeat_crt.data_ptr(),
                 dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), scratch.data_ptr(), scratch.numel(), stream)
         if table is None:
