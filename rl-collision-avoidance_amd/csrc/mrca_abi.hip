@@ -551,6 +551,7 @@ int mrca_create(const mrca_config* cfg, void* arena_dev, size_t arena_bytes, mrc
     v.r_magic = R <= 64 ? (uint32_t)(((1ull << 32) + (uint64_t)R - 1) / (uint64_t)R) : 0u;
     v.debug_flags = 0;
     v.dev = nullptr;                      // (upload_view, at the end of mrca_create)
+    v.eager_views = 0;                    // (set per launch by the step paths of an env with lazy_obs = 0)
 #if defined(MRCA_PROFILING)
     v.launch_stamps = nullptr;
     v.launch_slot = 0;
@@ -697,8 +698,9 @@ static int step_impl(mrca_env* env, const float* actions_dev, int32_t first, int
     if (phases & kPhaseMove) mrca::launch_move(v, actions_dev, s, rec ? ev[0] : nullptr, rec ? ev[1] : nullptr);
     if (phases & kPhaseObserve) {
         mrca::launch_lidar_grid(v, /*counted=*/1, s);
+        // (lazy_obs = 0: the ray cast forms MRCA_F_SCAN / MRCA_F_OBS of its robots itself -- no materialize launch behind it)
+        v.eager_views = env->cfg.lazy_obs ? 0 : (MRCA_VIEW_SCAN | MRCA_VIEW_OBS);
         mrca::launch_raycast(v, /*only_fresh=*/0, s, rec ? ev[2] : nullptr, rec ? ev[3] : nullptr);
-        if (!env->cfg.lazy_obs) mrca::launch_materialize(v, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, s);
     }
     if (rec) env->ev_used += 4;
     HIP_TRY(hipGetLastError());
@@ -962,9 +964,9 @@ static int run_ahead_pass(mrca_env* env, const float* const* act, int K, int P, 
                 rv.ray_count = wn * R;
                 rv.world_first = w0;
                 rv.world_count = wn;
+                rv.eager_views = env->cfg.lazy_obs ? 0 : (MRCA_VIEW_SCAN | MRCA_VIEW_OBS);
                 MRCA_LOG_TAG(rv, "ray", k, c);
                 mrca::launch_raycast(rv, /*only_fresh=*/0, sc);
-                if (!env->cfg.lazy_obs) mrca::launch_materialize(rv, MRCA_VIEW_SCAN | MRCA_VIEW_OBS, sc);
             }
         }
     };

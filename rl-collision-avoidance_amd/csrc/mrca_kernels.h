@@ -101,6 +101,7 @@ struct EnvView {
     uint32_t r_magic;     // ceil(2^32 / R) for R <= 64: n / R == umulhi(n, r_magic) for every robot index n < 2^24
     int32_t debug_flags;  // profiling ablations only (mrca_set_debug_flags, -DMRCA_PROFILING builds)
     uint32_t* status;     // [1] sticky device-side error bits (kStatus*), read and cleared by mrca_check()
+    int32_t eager_views;  // HOST side only (travels to the kernel in RayIn): the views the next ray cast forms itself, see RayIn
     const EnvView* dev;   // the env's copy of this struct in device memory (mrca_abi.hip: uploaded by mrca_create, again by the
                           // profiling build's debug switches); a host-side copy with other slots / ranges keeps pointing at it
 #if defined(MRCA_PROFILING)
@@ -151,6 +152,7 @@ struct RayIn {
     const float* goal;
     const uint8_t* fresh;
     const OutlineBits* outline;
+    int32_t views;          // MRCA_VIEW_SCAN | MRCA_VIEW_OBS: the ray cast also forms these views of its robots (lazy_obs = 0)
 #if defined(MRCA_PROFILING)
     unsigned long long* launch_stamps;
     int32_t launch_slot;

@@ -813,12 +813,14 @@ __device__ __forceinline__ int block_to_robot(int b, int N) {
 // run-time branch the default launch was 0.85 us slower (A/B on one box, profiles/r04_h_ab_raster_path_in_default_kernel.txt:
 // twice the instructions for the same instruction cache).  Since round 5 a beam's return from another robot's outline is a
 // closed form over that robot's 16-byte outline record (ray_outline_entry) instead of a walk through a window of LDS bits.
-template <int K, bool BIG, bool SEQ, int RKW>
+template <int K, bool BIG, bool SEQ, int RKW, bool VIEWS>
 __device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int ray_count, int R_, const float* __restrict__ pose_p,
                                              const float4* __restrict__ head_p, const float* __restrict__ bcos_p,
-                                             const float* __restrict__ bsin_p, uint8_t* ring_head_p, const EnvView& e);
+                                             const float* __restrict__ bsin_p, uint8_t* ring_head_p, const EnvView& e, int views);
 
-template <int K, bool BIG, bool SEQ, int RKW = 0>
+// VIEWS: the epilogue also forms MRCA_F_SCAN / MRCA_F_OBS (lazy_obs = 0) -- an instantiation of its own, so that the default
+// kernel carries nothing of it (as a run-time branch it put 22 scalar instructions per wave into every launch)
+template <int K, bool BIG, bool SEQ, int RKW = 0, bool VIEWS = false>
 __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int only_fresh, int ray_first, int ray_count, int R_,
                                                        const float* __restrict__ pose_p, const float4* __restrict__ head_p,
                                                        const float* __restrict__ bcos_p, const float* __restrict__ bsin_p,
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int o
     e.launch_slot = in.launch_slot;
 #endif
     MRCA_LAUNCH_BEGIN(e);
-    raycast_body<K, BIG, SEQ, RKW>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e);
+    raycast_body<K, BIG, SEQ, RKW, VIEWS>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e, in.views);
     MRCA_LAUNCH_END(e);
 #if defined(MRCA_PROFILING)
     // debug flag 128: every workgroup casts its robot's beams a SECOND time inside the same launch -- everything it touches
@@ -843,15 +845,15 @@ __global__ __launch_bounds__(1024, (RKW == 4 ? 8 : 1)) void raycast_kernel(int o
     // results of a launch under this flag are for the clock only.)  tools/hot_pass_probe.py, DESIGN.md 10.2.
     if (MRCA_DBG(e, 128)) {
         __syncthreads();
-        raycast_body<K, BIG, SEQ, RKW>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e);
+        raycast_body<K, BIG, SEQ, RKW, VIEWS>(only_fresh, ray_first, ray_count, R_, pose_p, head_p, bcos_p, bsin_p, ring_head_p, e, in.views);
     }
 #endif
 }
 
-template <int K, bool BIG, bool SEQ, int RKW>
+template <int K, bool BIG, bool SEQ, int RKW, bool VIEWS>
 __device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int ray_count, int R_, const float* __restrict__ pose_p,
                                              const float4* __restrict__ head_p, const float* __restrict__ bcos_p,
-                                             const float* __restrict__ bsin_p, uint8_t* ring_head_p, const EnvView& e) {
+                                             const float* __restrict__ bsin_p, uint8_t* ring_head_p, const EnvView& e, int views) {
     // (the leading arguments repeat e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head: 14
     // dwords preloaded into SGPRs, see move_kernel)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1174,6 +1176,27 @@ __device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int 
             } else {
                 __builtin_nontemporal_store(r, &ring_row[new_slot * e.B + b]);
                 if (word_lane) hit_row[new_slot * words + (b >> 6)] = hm;
+            }
+            // lazy_obs = 0: the two reference-shaped views of this robot, formed here instead of by a materialize_kernel launch
+            // behind every ray cast (get_laser_observation, stage_world1.py:127-141: the newest scan; the stack in deque order,
+            // x / 6 - 0.5) -- the same numbers: norm_obs of the ring's rows, the older ones as earlier launches stored them.  The
+            // launch uses 5 % of HBM: the 8 kB per robot ride along (131 -> ... M agent-steps/s for a reference-shaped caller).
+            if (VIEWS && views) {
+                const float nr = norm_obs(r);
+                if (views & 1) e.scan[(size_t)n * (uint32_t)e.B + b] = r;
+                if (views & 2) {
+                    float* dst = e.obs + (size_t)row * (uint32_t)e.B + b;
+                    if (fresh) {
+                        for (int f = 0; f < e.F; ++f) dst[f * e.B] = nr;
+                    } else {
+                        int slot = new_slot;
+                        for (int f = 0; f < e.F - 1; ++f) {        // oldest first: the slot behind the newest, and on round the ring
+                            slot = slot + 1 == e.F ? 0 : slot + 1;
+                            dst[f * e.B] = norm_obs(fabsf(ring_row[slot * e.B + b]));
+                        }
+                        dst[(e.F - 1) * e.B] = nr;
+                    }
+                }
             }
         }
         if (tid == 0 && !fresh) ring_head_p[n] = (uint8_t)new_slot;
@@ -1692,7 +1715,7 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t 
     const dim3 grid(e.ray_count);
     if (e.ray_count <= 0) return;
     const bool seq = e.ray_sequential != 0;
-    RayIn rin{e.goal, e.fresh, e.outline};
+    RayIn rin{e.goal, e.fresh, e.outline, e.eager_views};
 #if defined(MRCA_PROFILING)
     rin.launch_stamps = e.launch_stamps;
     rin.launch_slot = e.launch_slot;
@@ -1700,12 +1723,16 @@ void launch_raycast(const EnvView& e, int only_fresh, hipStream_t s, hipEvent_t 
 #define MRCA_RAY(K, BIG, SEQ) MRCA_RAY4(K, BIG, SEQ, 0)
 #define MRCA_RAY4(K, BIG, SEQ, RKWV)                                                                                          \
     do {                                                                                                               \
-        if (start || stop)                                                                                             \
-            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0,     \
+        if (rin.views)                                                                                                 \
+            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV, true>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0, \
+                                  only_fresh, e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin,         \
+                                  e.ring_head, e.dev, rin);                                                              \
+        else if (start || stop)                                                                                        \
+            hipExtLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV, false>), grid, dim3(threads), (uint32_t)lds, s, start, stop, 0, \
                                   only_fresh, e.ray_first, e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin,         \
                                   e.ring_head, e.dev, rin);                                                              \
         else                                                                                                           \
-            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV>), grid, dim3(threads), lds, s, only_fresh, e.ray_first,    \
+            hipLaunchKernelGGL((raycast_kernel<K, BIG, SEQ, RKWV, false>), grid, dim3(threads), lds, s, only_fresh, e.ray_first,    \
                                e.ray_count, e.R, e.pose, e.head, e.beam_cos, e.beam_sin, e.ring_head, e.dev, rin);     \
     } while (0)
     if (raster_mode) {

@@ -396,6 +396,14 @@ def test_eager_views_env_matches_the_lazy_one(hip):
         eager.step(a)
         torch.cuda.synchronize()
         assert torch.equal(eager._obs, lazy.obs) and torch.equal(eager._scan, lazy.scan)   # _obs: the raw field, no materialise call
+    # ... and through mrca_step_many (two world ranges, the run-ahead pass): the ray casts form the views of their own robots
+    import bench
+    pool = bench.action_pool(sc.num_robots, lazy.device, 3, depth=40)
+    for first, count in ((0, 1), (1, 7), (8, 30)):
+        lazy.step_many(pool, first, count, 2)
+        eager.step_many(pool, first, count, 2)
+        torch.cuda.synchronize()
+        assert torch.equal(eager._obs, lazy.obs) and torch.equal(eager._scan, lazy.scan), (first, count)
     lazy.close()
     eager.close()
 
