@@ -135,7 +135,7 @@ typedef struct mrca_config {
     float collision_raster;
     /* ABI 3 / 4.  0: MRCA_F_SCAN and MRCA_F_OBS are brought up to date by every mrca_reset / mrca_step* -- what a caller
      * written against ABI 2 expects; since round 6 the stepping calls' ray cast writes the two views of its robots itself
-     * (8 kB per robot beside its 2 kB ring row: 155 instead of 247 M agent-steps/s at 4096 robots; as a pass of its own behind
+     * (8 kB per robot beside its 2 kB ring row: 180 instead of 247 M agent-steps/s at 4096 robots; as a pass of its own behind
      * every ray cast it was 131).  1: only mrca_materialize() does that; callers that read MRCA_F_SCAN_RING +
      * MRCA_F_RING_HEAD (mrca_lidar_features does) never pay for it. */
     int32_t lazy_obs;

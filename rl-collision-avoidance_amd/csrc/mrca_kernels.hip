@@ -1183,18 +1183,19 @@ __device__ __forceinline__ void raycast_body(int only_fresh, int ray_first, int 
             // launch uses 5 % of HBM: the 8 kB per robot ride along (131 -> ... M agent-steps/s for a reference-shaped caller).
             if (VIEWS && views) {
                 const float nr = norm_obs(r);
-                if (views & 1) e.scan[(size_t)n * (uint32_t)e.B + b] = r;
+                // (nontemporal like the ring row: the launch does not read them again)
+                if (views & 1) __builtin_nontemporal_store(r, &e.scan[(size_t)n * (uint32_t)e.B + b]);
                 if (views & 2) {
                     float* dst = e.obs + (size_t)row * (uint32_t)e.B + b;
                     if (fresh) {
-                        for (int f = 0; f < e.F; ++f) dst[f * e.B] = nr;
+                        for (int f = 0; f < e.F; ++f) __builtin_nontemporal_store(nr, &dst[f * e.B]);
                     } else {
                         int slot = new_slot;
                         for (int f = 0; f < e.F - 1; ++f) {        // oldest first: the slot behind the newest, and on round the ring
                             slot = slot + 1 == e.F ? 0 : slot + 1;
-                            dst[f * e.B] = norm_obs(fabsf(ring_row[slot * e.B + b]));
+                            __builtin_nontemporal_store(norm_obs(fabsf(ring_row[slot * e.B + b])), &dst[f * e.B]);
                         }
-                        dst[(e.F - 1) * e.B] = nr;
+                        __builtin_nontemporal_store(nr, &dst[(e.F - 1) * e.B]);
                     }
                 }
             }
